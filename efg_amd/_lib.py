@@ -1,0 +1,117 @@
+"""ctypes binding of libefg_hip.so (C ABI declared in include/efg_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails this module
+raises.  Tensors are passed as raw device pointers plus the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libefg_hip.so")
+_lib = None
+
+c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); pointers are passed as c_void_p
+_SIGS = {
+    "efg_last_error": (ctypes.c_char_p, []),
+    "efg_version": (ctypes.c_char_p, []),
+    "efg_dynamic_voxelize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "efg_hard_voxelize_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "efg_hard_voxelize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_scatter_workspace_bytes": (c_size_t, [c_int64, c_int, c_void_p]),
+    "efg_scatter_index": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "efg_scatter_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "efg_scatter_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_index_bytes": (c_size_t, [c_int, c_void_p]),
+    "efg_spconv_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
+    "efg_spconv_index_from_indices": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_size_t, c_void_p]),
+    "efg_spconv_index_downsample": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_index_emit": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "efg_spconv_build_nbr": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "efg_spconv_build_rnbr": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "efg_spconv_forward_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
+                                       c_void_p, c_void_p]),
+    "efg_spconv_dgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p,
+                                     c_void_p]),
+    "efg_spconv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "efg_spconv_wgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "efg_sparse_to_dense_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "efg_dense_to_sparse_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "efg_msda_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_void_p, c_void_p]),
+    "efg_msda_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libefg_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                "efg_amd: %s is missing. Build it with `python -m efg_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback on the product path." % _LIB_PATH)
+        _lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("efg_hip: " + lib().efg_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "efg_hip ops need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "efg_amd ops run on MI355X only (got a %s tensor); there is no CPU fallback" % t.device.type)
+
+
+def host_f32(vals, n):
+    vals = [float(v) for v in vals]
+    assert len(vals) == n
+    return (ctypes.c_float * n)(*vals)
+
+
+def host_i32(vals, n=None):
+    vals = [int(v) for v in vals]
+    assert n is None or len(vals) == n
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def host_i64(vals):
+    vals = [int(v) for v in vals]
+    return (ctypes.c_int64 * len(vals))(*vals)

@@ -1,0 +1,402 @@
+// Point-cloud voxelization for gfx950 (wave64).
+//
+// Replaces efg::dynamic_voxelize / efg::hard_voxelize
+// (reference: efg/operators/src/voxelize/voxelization.h:51-83; CPU semantics
+// voxelization_cpu.cpp:7-99; the CUDA version voxelization_cuda.cu:100-174 is an O(N^2)
+// predecessor scan plus a <<<1,1>>> serial pass).
+//
+// Parallel, bit-exact formulation of the serial first-come-first-kept loop:
+//   K1 insert   one open-addressing hash insert per point on a 64-bit {cell, point} word:
+//               atomicMin keeps, per occupied cell, the LOWEST point index = first occurrence;
+//   K2 count    per 1024-point tile, count the points that are the first of their voxel;
+//   K3 assign   block-scan the first-flags in POINT ORDER: voxel id = rank of its first point;
+//               rank == max_voxels marks i_break (the reference's `break`);
+//   K4 cascade  every later point of a kept voxel inserts its index into the voxel's sorted
+//               max_points-entry list with a chain of atomicMin (carry = max(old, mine));
+//               entry r ends up holding the (r+1)-th smallest point index of the voxel;
+//   K5 gather   copy the selected points, zero padding, counts and the fused per-voxel mean.
+// All scenes of a batch are processed by one launch per stage (blockIdx.y = scene).
+#include "common.h"
+
+namespace efg {
+namespace {
+
+constexpr int kMaxBatch = 64;
+constexpr int kTile = 1024;  // points per block in the ordered stages (256 threads x 4)
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr int kInf = 0x7f7f7f7f;  // memset(0x7f) pattern: "no point"
+constexpr int kFirstFlag = 1 << 30;
+
+struct VoxGeom {
+  float vs[3];
+  float rmin[3];
+  int grid[3];  // x, y, z
+};
+
+struct SceneOffsets {
+  long long off[kMaxBatch + 1];
+};
+
+// c = floor((p - min) / vs) per axis in IEEE fp32 (true division, no contraction): a point on a
+// voxel boundary must land in the same voxel as on the CPU (voxelization_cpu.cpp:24).
+__device__ __forceinline__ bool point_cell(const float* __restrict__ p, const VoxGeom& g, int& cx, int& cy,
+                                           int& cz) {
+  const float vx = floorf(__fdiv_rn(__fsub_rn(p[0], g.rmin[0]), g.vs[0]));
+  const float vy = floorf(__fdiv_rn(__fsub_rn(p[1], g.rmin[1]), g.vs[1]));
+  const float vz = floorf(__fdiv_rn(__fsub_rn(p[2], g.rmin[2]), g.vs[2]));
+  // NaN fails every comparison -> outside
+  const bool ok = (vx >= 0.0f) && (vx < (float)g.grid[0]) && (vy >= 0.0f) && (vy < (float)g.grid[1]) &&
+                  (vz >= 0.0f) && (vz < (float)g.grid[2]);
+  cx = (int)vx;
+  cy = (int)vy;
+  cz = (int)vz;
+  return ok;
+}
+
+__global__ void __launch_bounds__(256) dynamic_voxelize_kernel(const float* __restrict__ pts, long long n, int f,
+                                                                VoxGeom g, int* __restrict__ coors) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int cx, cy, cz;
+    const bool ok = point_cell(pts + i * f, g, cx, cy, cz);
+    coors[i * 3 + 0] = ok ? cz : -1;
+    coors[i * 3 + 1] = ok ? cy : -1;
+    coors[i * 3 + 2] = ok ? cx : -1;
+  }
+}
+
+__device__ __forceinline__ unsigned hash_cell(unsigned key, int shift) { return (key * 2654435761u) >> shift; }
+
+// K1: slot_of_point[i] = hash slot of the point's cell (or -1); table[slot] = {cell, min point}.
+__global__ void __launch_bounds__(256)
+vox_insert_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom g, unsigned vol,
+                  unsigned long long* __restrict__ table, unsigned tmask, int tshift, int* __restrict__ slot_of_point) {
+  const int scene = blockIdx.y;
+  const long long beg = so.off[scene], end = so.off[scene + 1];
+  for (long long i = beg + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+       i += (long long)gridDim.x * blockDim.x) {
+    int cx, cy, cz;
+    if (!point_cell(pts + i * f, g, cx, cy, cz)) {
+      slot_of_point[i] = -1;
+      continue;
+    }
+    const unsigned key = (unsigned)scene * vol + ((unsigned)cz * g.grid[1] + cy) * g.grid[0] + cx;
+    const unsigned long long mine = ((unsigned long long)key << 32) | (unsigned)i;
+    unsigned h = hash_cell(key, tshift);
+    while (true) {
+      unsigned long long cur = table[h];
+      if (cur == kEmpty) {
+        cur = atomicCAS(&table[h], kEmpty, mine);
+        if (cur == kEmpty) break;  // claimed
+      }
+      if ((unsigned)(cur >> 32) == key) {
+        atomicMin(&table[h], mine);
+        break;
+      }
+      h = (h + 1) & tmask;
+    }
+    slot_of_point[i] = (int)h;
+  }
+}
+
+// K2: tag first points (kFirstFlag in slot_of_point) and count them per tile.
+__global__ void __launch_bounds__(256)
+vox_count_kernel(SceneOffsets so, const unsigned long long* __restrict__ table, int* __restrict__ slot_of_point,
+                 int* __restrict__ tile_counts, int tiles_per_scene) {
+  __shared__ int smem[17];
+  const int scene = blockIdx.y;
+  const long long beg = so.off[scene], end = so.off[scene + 1];
+  const long long base = beg + (long long)blockIdx.x * kTile + threadIdx.x * 4;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + j;
+    if (i < end) {
+      const int s = slot_of_point[i];
+      if (s >= 0 && (unsigned)table[s] == (unsigned)i) {
+        slot_of_point[i] = s | kFirstFlag;
+        ++cnt;
+      }
+    }
+  }
+  cnt = wave_reduce_sum(cnt);
+  if (lane_id() == 0) smem[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[scene * tiles_per_scene + blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+// K2b: per scene totals -> kept voxel count and output base row (one block per launch).
+__global__ void vox_totals_kernel(const int* __restrict__ tile_counts, int tiles_per_scene, int batch, int max_voxels,
+                                  int* __restrict__ scene_base /*[batch+1]*/, int* __restrict__ voxel_num) {
+  __shared__ int tot[kMaxBatch];
+  for (int b = threadIdx.x >> 6; b < batch; b += blockDim.x >> 6) {
+    int s = 0;
+    for (int t = lane_id(); t < tiles_per_scene; t += 64) s += tile_counts[b * tiles_per_scene + t];
+    s = wave_reduce_sum(s);
+    if (lane_id() == 0) tot[b] = min(s, max_voxels);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < batch; ++b) {
+      scene_base[b] = acc;
+      voxel_num[b] = tot[b];
+      acc += tot[b];
+    }
+    scene_base[batch] = acc;
+  }
+}
+
+// K3: voxel ids in first-occurrence order; first point goes to list entry 0.
+__global__ void __launch_bounds__(256)
+vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table, const int* __restrict__ slot_of_point,
+                  const int* __restrict__ tile_counts, int tiles_per_scene, const int* __restrict__ scene_base,
+                  int max_voxels, int max_points, unsigned vol, VoxGeom g, int* __restrict__ vid_of_slot,
+                  int* __restrict__ lists, int* __restrict__ i_break, int* __restrict__ coors, int coors_cols) {
+  __shared__ int smem[17];
+  __shared__ int s_prefix;
+  const int scene = blockIdx.y;
+  const long long beg = so.off[scene], end = so.off[scene + 1];
+  // firsts in earlier tiles of this scene
+  int pre = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += blockDim.x) pre += tile_counts[scene * tiles_per_scene + t];
+  pre = wave_reduce_sum(pre);
+  if (lane_id() == 0) smem[threadIdx.x >> 6] = pre;
+  __syncthreads();
+  if (threadIdx.x == 0) s_prefix = smem[0] + smem[1] + smem[2] + smem[3];
+  __syncthreads();
+  const long long base = beg + (long long)blockIdx.x * kTile + threadIdx.x * 4;
+  int slot[4];
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + j;
+    slot[j] = (i < end) ? slot_of_point[i] : -1;
+    if (slot[j] >= 0 && (slot[j] & kFirstFlag)) ++cnt;
+  }
+  int total;
+  int rank = block_exclusive_scan(cnt, smem, &total) + s_prefix;
+  const int out_base = scene_base[scene];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (slot[j] >= 0 && (slot[j] & kFirstFlag)) {
+      const int s = slot[j] & ~kFirstFlag;
+      const long long i = base + j;
+      if (rank < max_voxels) {
+        const int vid = out_base + rank;
+        vid_of_slot[s] = vid;
+        lists[(long long)vid * max_points] = (int)i;
+        unsigned cell = (unsigned)(table[s] >> 32) - (unsigned)scene * vol;
+        const int cx = cell % g.grid[0];
+        cell /= g.grid[0];
+        const int cy = cell % g.grid[1];
+        const int cz = cell / g.grid[1];
+        int* c = coors + (long long)vid * coors_cols;
+        if (coors_cols == 4) *c++ = scene;
+        c[0] = cz;
+        c[1] = cy;
+        c[2] = cx;
+      } else {
+        vid_of_slot[s] = -1;
+        if (rank == max_voxels) i_break[scene] = (int)i;  // the point at which the reference breaks
+      }
+      ++rank;
+    }
+  }
+}
+
+// K4: later points of kept voxels; sorted-list insertion by atomicMin chain.
+__global__ void __launch_bounds__(256)
+vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const int* __restrict__ vid_of_slot,
+                   const int* __restrict__ i_break, int max_points, int* __restrict__ lists) {
+  const int scene = blockIdx.y;
+  const long long beg = so.off[scene];
+  const long long end = min(so.off[scene + 1], (long long)i_break[scene]);
+  for (long long i = beg + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int s = slot_of_point[i];
+    if (s < 0 || (s & kFirstFlag)) continue;
+    const int vid = vid_of_slot[s];
+    if (vid < 0) continue;
+    int* lst = lists + (long long)vid * max_points;
+    int carry = (int)i;
+    for (int r = 1; r < max_points; ++r) {
+      const int old = atomicMin(&lst[r], carry);
+      if (old == kInf) break;          // landed in an empty entry
+      carry = max(old, carry);         // the larger index moves on
+    }
+  }
+}
+
+// K5: one thread per (voxel, feature): copy the <= max_points selected rows, zero pad, mean.
+__global__ void __launch_bounds__(256)
+vox_gather_kernel(const float* __restrict__ pts, int f, const int* __restrict__ lists, int max_points,
+                  const int* __restrict__ scene_base, int batch, float* __restrict__ voxels, int* __restrict__ npv,
+                  float* __restrict__ mean) {
+  const long long m = scene_base[batch];
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * f) return;
+  const long long vid = e / f;
+  const int k = (int)(e - vid * f);
+  const int* lst = lists + vid * max_points;
+  float sum = 0.0f;
+  int cnt = 0;
+  for (int r = 0; r < max_points; ++r) {
+    const int idx = lst[r];
+    float v = 0.0f;
+    if (idx != kInf) {
+      v = pts[(long long)idx * f + k];
+      ++cnt;
+    }
+    voxels[(vid * max_points + r) * f + k] = v;
+    sum = __fadd_rn(sum, v);
+  }
+  if (k == 0) npv[vid] = cnt;
+  if (mean) mean[vid * f + k] = __fdiv_rn(sum, (float)cnt);
+}
+
+int make_geom(const float* vs, const float* cr, VoxGeom* g, unsigned long long* vol) {
+  for (int i = 0; i < 3; ++i) {
+    EFG_CHECK_ARG(vs[i] > 0.0f, "voxel_size[%d] must be positive", i);
+    g->vs[i] = vs[i];
+    g->rmin[i] = cr[i];
+    // grid = round((max - min) / vs) in fp32, voxelization_cpu.cpp:119-122
+    g->grid[i] = (int)roundf((cr[3 + i] - cr[i]) / vs[i]);
+    EFG_CHECK_ARG(g->grid[i] > 0, "empty grid on axis %d", i);
+  }
+  *vol = (unsigned long long)g->grid[0] * g->grid[1] * g->grid[2];
+  return EFG_OK;
+}
+
+struct HardLayout {
+  unsigned tsize;
+  int tshift;
+  int tiles_per_scene;
+  size_t table_b, slot_b, vid_b, lists_b, tiles_b, small_b;
+};
+
+HardLayout hard_layout(int64_t n_total, int64_t max_scene_pts, int batch, int max_points, int max_voxels) {
+  HardLayout L;
+  unsigned t = 1024;
+  int lg = 10;
+  while ((int64_t)t < 2 * n_total) {
+    t <<= 1;
+    ++lg;
+  }
+  L.tsize = t;
+  L.tshift = 32 - lg;
+  L.tiles_per_scene = (int)std::max<int64_t>(1, ceil_div(max_scene_pts, kTile));
+  L.table_b = align_up((size_t)t * 8, 256);
+  L.slot_b = align_up((size_t)std::max<int64_t>(n_total, 1) * 4, 256);
+  L.vid_b = align_up((size_t)t * 4, 256);
+  L.lists_b = align_up((size_t)batch * max_voxels * max_points * 4, 256);
+  L.tiles_b = align_up((size_t)batch * L.tiles_per_scene * 4, 256);
+  L.small_b = align_up((size_t)(2 * kMaxBatch + 2) * 4, 256);
+  return L;
+}
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" int efg_dynamic_voxelize_f32(const float* points, int64_t n, int f, const float* vs, const float* cr,
+                                        int32_t* coors, void* stream) {
+  EFG_CHECK_ARG(f >= 3, "points need >= 3 features, got %d", f);
+  EFG_CHECK_ARG(n >= 0, "negative point count");
+  VoxGeom g;
+  unsigned long long vol;
+  if (int rc = make_geom(vs, cr, &g, &vol)) return rc;
+  if (n == 0) return EFG_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+  hipLaunchKernelGGL(dynamic_voxelize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, points,
+                     (long long)n, f, g, coors);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int max_points, int max_voxels) {
+  if (n_total < 0 || batch < 1 || max_points < 1 || max_voxels < 1) return 0;
+  // tiles_per_scene is bounded by the total point count
+  HardLayout L = hard_layout(n_total, n_total, batch, max_points, max_voxels);
+  return L.table_b + L.slot_b + L.vid_b + L.lists_b + L.tiles_b + L.small_b + 256;
+}
+
+extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, int batch, int f, const float* vs,
+                                     const float* cr, int max_points, int max_voxels, float* voxels, int32_t* coors,
+                                     int coors_cols, int32_t* npv, int32_t* voxel_num, float* mean, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "batch must be in [1,%d], got %d", kMaxBatch, batch);
+  EFG_CHECK_ARG(f >= 3, "points need >= 3 features, got %d", f);
+  EFG_CHECK_ARG(max_points >= 1 && max_voxels >= 1,
+                "max_points/max_voxels must be >= 1 (the -1 'uncapped' modes are routed to dynamic_voxelize by "
+                "efg/operators/voxelize.py:34-37)");
+  EFG_CHECK_ARG(coors_cols == 3 || coors_cols == 4, "coors_cols must be 3 or 4");
+  EFG_CHECK_ARG((long long)batch * max_voxels * max_points < (1ll << 31), "voxel capacity too large");
+  VoxGeom g;
+  unsigned long long vol;
+  if (int rc = make_geom(vs, cr, &g, &vol)) return rc;
+  EFG_CHECK_ARG(vol * (unsigned long long)batch < 0xffffffffull, "grid volume x batch must be < 2^32-1 cells");
+  SceneOffsets so;
+  int64_t max_scene = 0;
+  for (int b = 0; b <= batch; ++b) {
+    so.off[b] = offs[b];
+    if (b) {
+      EFG_CHECK_ARG(offs[b] >= offs[b - 1], "point_offsets must be non-decreasing");
+      max_scene = std::max(max_scene, offs[b] - offs[b - 1]);
+    }
+  }
+  EFG_CHECK_ARG(offs[0] == 0, "point_offsets[0] must be 0");
+  const int64_t n_total = offs[batch];
+  EFG_CHECK_ARG(n_total < (1ll << 29), "too many points");
+  HardLayout L = hard_layout(n_total, max_scene, batch, max_points, max_voxels);
+  Workspace w(ws, ws_bytes);
+  auto* table = w.take<unsigned long long>(L.tsize);
+  int* slot_of_point = w.take<int>(std::max<int64_t>(n_total, 1));
+  int* vid_of_slot = w.take<int>(L.tsize);
+  int* lists = w.take<int>((size_t)batch * max_voxels * max_points);
+  int* tile_counts = w.take<int>((size_t)batch * L.tiles_per_scene);
+  int* small = w.take<int>(2 * kMaxBatch + 2);
+  if (!w.ok) {
+    set_error("hard_voxelize workspace too small: need %zu bytes, got %zu",
+              efg_hard_voxelize_workspace_bytes(n_total, batch, max_points, max_voxels), ws_bytes);
+    return EFG_E_WORKSPACE;
+  }
+  int* scene_base = small;               // [batch+1]
+  int* i_break = small + kMaxBatch + 1;  // [batch]
+  EFG_HIP_TRY(hipMemsetAsync(table, 0xff, (size_t)L.tsize * 8, stream));
+  EFG_HIP_TRY(hipMemsetAsync(lists, 0x7f, (size_t)batch * max_voxels * max_points * 4, stream));
+  EFG_HIP_TRY(hipMemsetAsync(i_break, 0x7f, kMaxBatch * 4, stream));
+  const dim3 blk(256);
+  if (n_total > 0) {
+    const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(gx, batch), blk, 0, stream, points, so, f, g, (unsigned)vol, table,
+                       L.tsize - 1, L.tshift, slot_of_point);
+    EFG_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(vox_count_kernel, dim3(L.tiles_per_scene, batch), blk, 0, stream, so, table, slot_of_point,
+                     tile_counts, L.tiles_per_scene);
+  EFG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vox_totals_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, L.tiles_per_scene, batch,
+                     max_voxels, scene_base, voxel_num);
+  EFG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vox_assign_kernel, dim3(L.tiles_per_scene, batch), blk, 0, stream, so, table, slot_of_point,
+                     tile_counts, L.tiles_per_scene, scene_base, max_voxels, max_points, (unsigned)vol, g,
+                     vid_of_slot, lists, i_break, coors, coors_cols);
+  EFG_LAUNCH_CHECK();
+  if (n_total > 0 && max_points > 1) {
+    const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
+    hipLaunchKernelGGL(vox_cascade_kernel, dim3(gx, batch), blk, 0, stream, so, slot_of_point, vid_of_slot, i_break,
+                       max_points, lists);
+    EFG_LAUNCH_CHECK();
+  }
+  // upper bound on rows: min(points, capacity); threads beyond the real count exit early
+  const int64_t rows_ub = std::min<int64_t>(n_total, (int64_t)batch * max_voxels);
+  if (rows_ub > 0) {
+    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)ceil_div(rows_ub * f, 256)), blk, 0, stream, points, f,
+                       lists, max_points, scene_base, batch, voxels, npv, mean);
+    EFG_LAUNCH_CHECK();
+  }
+  return EFG_OK;
+}

@@ -1,0 +1,85 @@
+"""`efg.operators.box_attention_func` on MI355X (mirrors efg/operators/box_attention_func.py:9-64).
+
+`box_attn_forward/backward` and `ms_deform_attn_forward/backward` keep the Python-visible
+signatures of the reference bindings (efg/operators/src/box_attn/box_attn.h:29-83,
+efg/operators/src/deform_attn/ms_deform_attn.h:22-63); both names run the same HIP kernel family
+(csrc/msda.hip).  fp32 only, like the ConQueR path (`custom_fwd(cast_inputs=torch.float32)`).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+
+def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    L.require_gpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    for name, t in (("value", value), ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_contiguous():
+            raise RuntimeError(name + " must be contiguous.")  # CHECK_INPUT, efg_cutils.h:12-15
+        if t.dtype != torch.float32:
+            raise RuntimeError(name + " must be float32")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64")
+    batch = value.size(0)
+    step = min(batch, im2col_step)
+    if batch > 0 and batch % step != 0:
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (batch, step))  # box_attn.cu:39-41
+
+
+def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """value[B,S,H,D], shapes i64[L,2], start i64[L], loc[B,Lq,H,L,P,2], attn[B,Lq,H,L,P(or k,k)] -> [B,Lq,H*D]."""
+    _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    b, s, h, d = value.shape
+    lq, l, p = sampling_loc.size(1), spatial_shapes.size(0), sampling_loc.size(4)
+    out = torch.empty((b, lq, h * d), dtype=value.dtype, device=value.device)
+    L.check(L.lib().efg_msda_forward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
+                                         L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
+                                         L.ptr(attn_weight), b, s, h, d, l, lq, p, L.ptr(out), L.stream()))
+    return out
+
+
+def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]"""
+    _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    L.require_gpu(grad_output)
+    grad_output = grad_output.contiguous()
+    b, s, h, d = value.shape
+    lq, l, p = sampling_loc.size(1), spatial_shapes.size(0), sampling_loc.size(4)
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    L.check(L.lib().efg_msda_backward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
+                                          L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
+                                          L.ptr(attn_weight), L.ptr(grad_output), b, s, h, d, l, lq, p,
+                                          L.ptr(grad_value), L.ptr(grad_loc), L.ptr(grad_attn), L.stream()))
+    return [grad_value, grad_loc, grad_attn]
+
+
+ms_deform_attn_forward = box_attn_forward
+ms_deform_attn_backward = box_attn_backward
+
+
+class BoxAttnFunction(Function):
+    """efg/operators/box_attention_func.py:9-64 (inputs are cast to fp32 like custom_fwd there)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        value, sampling_locations, attention_weights = (value.float().contiguous(),
+                                                        sampling_locations.float().contiguous(),
+                                                        attention_weights.float().contiguous())
+        output = box_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                  attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, start, loc, attn = ctx.saved_tensors
+        grad_value, grad_loc, grad_attn = box_attn_backward(value, shapes, start, loc, attn,
+                                                            grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_attn, None

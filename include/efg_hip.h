@@ -1,0 +1,171 @@
+/*
+ * include/efg_hip.h -- C ABI of libefg_hip.so, the MI355X (gfx950) implementation of the EFG
+ * Voxel-DETR / ConQueR hot path.  This is the drop-in boundary: the entry points are what a
+ * replacement of the reference's pybind11 module `efg._C` (efg/operators/src/vision.cpp:70-122)
+ * and of the third-party `spconv` ops binds to.  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *  - tensors are dense row-major ("contiguous"), fp32 / int32 / int64 as named;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); every kernel
+ *    of a call is enqueued on it and nothing synchronises the device unless stated;
+ *  - temporaries live in a caller-owned workspace (`ws`, `ws_bytes`), sized by the matching
+ *    `*_workspace_bytes` query, so the caller's allocator (PyTorch's caching allocator) owns
+ *    all memory and calls are re-entrant (no global mutable state);
+ *  - return value: 0 = OK, negative = error (EFG_E_*); efg_last_error() returns a thread-local
+ *    message for the last failure on the calling thread.
+ */
+#ifndef EFG_HIP_H
+#define EFG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFG_OK 0
+#define EFG_E_INVALID (-1)   /* bad argument (shape, size, unsupported configuration) */
+#define EFG_E_WORKSPACE (-2) /* workspace too small */
+#define EFG_E_HIP (-3)       /* a HIP runtime call / kernel launch failed */
+
+const char* efg_last_error(void);
+/* "efg_hip <version> gfx950" */
+const char* efg_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelization.  Replaces efg::dynamic_voxelize / efg::hard_voxelize
+ * (efg/operators/src/voxelize/voxelization.h:51-83; CPU semantics voxelization_cpu.cpp:7-99).
+ * Grid volume (x batch) must be < 2^32 - 1 cells.
+ * ---------------------------------------------------------------------------------------- */
+
+/* coors[n,3] int32 (z,y,x); (-1,-1,-1) for points outside coors_range (CPU encoding,
+ * voxelization_cpu.cpp:32-37).  NaN coordinates count as outside. */
+int efg_dynamic_voxelize_f32(const float* points, int64_t n, int f, const float* voxel_size_host,
+                             const float* coors_range_host, int32_t* coors, void* stream);
+
+size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int max_points, int max_voxels);
+
+/*
+ * Batched hard voxelization of `batch` scenes in one call.  Scene b owns the point rows
+ * [point_offsets_host[b], point_offsets_host[b+1]).  Per scene the result is bit-identical to
+ * the reference loop (voxelization_cpu.cpp:43-99): voxels in first-occurrence order, at most
+ * max_points points per voxel in point order, processing stops at the first point that would
+ * open voxel number max_voxels.
+ *
+ * Outputs are CONCATENATED over scenes (the layout efg/data/datasets/waymo/waymo.py:143-183
+ * `collate` produces): rows [base_b, base_b + M_b) belong to scene b, base_b = sum_{b'<b} M_b'.
+ *   voxels   f32 [batch*max_voxels, max_points, f]  rows < sum M fully written (zero padded)
+ *   coors    i32 [batch*max_voxels, coors_cols]     coors_cols = 3: (z,y,x); 4: (b,z,y,x)
+ *   npv      i32 [batch*max_voxels]
+ *   voxel_num i32 [batch]                           M_b (device; read it after the stream syncs)
+ *   mean     f32 [batch*max_voxels, f] or NULL      fused VoxelMeanFeatureExtractor
+ *                                                   (efg/modeling/readers/voxel_reader.py:14-19)
+ * With batch == 1 and coors_cols == 3 this is exactly efg::hard_voxelize.
+ */
+int efg_hard_voxelize_f32(const float* points, const int64_t* point_offsets_host, int batch, int f,
+                          const float* voxel_size_host, const float* coors_range_host, int max_points,
+                          int max_voxels, float* voxels, int32_t* coors, int coors_cols, int32_t* npv,
+                          int32_t* voxel_num, float* mean, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dynamic scatter.  Replaces efg::dynamic_point_to_voxel_forward / _backward
+ * (voxelization.h:96-128; scatter_points_cuda.cu:209-352).  reduce: 0 sum, 1 mean, 2 max.
+ * Two-phase forward because M (number of distinct voxels) sizes the outputs:
+ *   efg_scatter_index   builds point2voxel[n] (voxel id = rank of the linearised coordinate,
+ *                       -1 for rows with a negative coordinate) and writes M to *m_dev;
+ *   efg_scatter_reduce  fills voxel_feats[M,c], voxel_coors[M,ndim], count[M].
+ * ---------------------------------------------------------------------------------------- */
+size_t efg_scatter_workspace_bytes(int64_t n, int ndim, const int32_t* dims_host);
+/* dims_host[ndim] = per-column max + 1 (the caller computes coors.max(0)+1 as the reference
+ * does at scatter_points_cuda.cu:220). */
+int efg_scatter_index(const int32_t* coors, int64_t n, int ndim, const int32_t* dims_host,
+                      int32_t* point2voxel, int32_t* m_dev, void* ws, size_t ws_bytes, void* stream);
+int efg_scatter_reduce_f32(const float* feats, const int32_t* coors, const int32_t* point2voxel, int64_t n,
+                           int c, int ndim, int reduce, int64_t m, float* voxel_feats, int32_t* voxel_coors,
+                           int32_t* count, void* stream);
+/* grad_feats[n,c] is fully written.  ws: m*c int32 (max only). */
+int efg_scatter_backward_f32(float* grad_feats, const float* grad_voxel_feats, const float* feats,
+                             const float* voxel_feats, const int32_t* point2voxel, const int32_t* count,
+                             int64_t n, int64_t m, int c, int reduce, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution.  Replaces the spconv ops reached from
+ * efg/modeling/backbones/sparse_net.py:79-98,120-165,273-309,485-545 (SparseConvTensor,
+ * SubMConv3d, SparseConv3d, .dense()).  indices are int32 (b,z,y,x) rows.
+ *
+ * Geometry is held in an "index" = bitmap of active cells + exclusive popcount prefix, packed
+ * as uint2 {bits, prefix} per 32 cells of the linearised grid ((b*D+z)*H+y)*W+x: the rank of a
+ * set bit is the row of that site in canonical (ascending linear index) order.
+ * ---------------------------------------------------------------------------------------- */
+size_t efg_spconv_index_bytes(int batch, const int* shape_host);       /* bytes of one index    */
+size_t efg_spconv_index_workspace_bytes(int batch, const int* shape_host);
+
+/* Build the index of a given set of sites.  perm (i32[m]) receives canonical-rank -> row of
+ * `indices` (identity when the rows are already in canonical order). */
+int efg_spconv_index_from_indices(const int32_t* indices, int64_t m, int batch, const int* shape_host,
+                                  void* index, int32_t* perm, void* ws, size_t ws_bytes, void* stream);
+
+/* Regular SparseConv3d geometry: mark every output site touched by an input site, rank them.
+ * out_shape_host receives (in + 2p - k)/s + 1 per axis.  *m_out_dev receives the site count;
+ * the caller reads it back, allocates out_indices[m_out,4] and calls efg_spconv_index_emit. */
+int efg_spconv_index_downsample(const int32_t* in_indices, int64_t m_in, int batch, const int* in_shape_host,
+                                const int* ksize_host, const int* stride_host, const int* pad_host,
+                                void* out_index, int* out_shape_host, int32_t* m_out_dev, void* ws,
+                                size_t ws_bytes, void* stream);
+int efg_spconv_index_emit(const void* index, int batch, const int* shape_host, int32_t* out_indices,
+                          void* stream);
+
+/* nbr[kvol][m_out] int32: row (in the INPUT tensor's row order) of the active input at
+ * out*stride - pad + k, or -1.  in_perm may be NULL when input rows are in canonical order. */
+int efg_spconv_build_nbr(const void* in_index, const int32_t* in_perm, int batch, const int* in_shape_host,
+                         const int32_t* out_indices, int64_t m_out, const int* ksize_host,
+                         const int* stride_host, const int* pad_host, int32_t* nbr, void* stream);
+/* Reverse table for dgrad: rnbr[kvol][m_in] = output row o with nbr[k][o] == i, or -1. */
+int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m_in, int32_t* rnbr,
+                          void* stream);
+
+/* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:].  weight f32 [cout][kvol][cin]
+ * (spconv 2.x layout [Cout,kd,kh,kw,Cin]); bias may be NULL. */
+int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* weight,
+                           const float* bias, int cout, int kvol, const int32_t* nbr, int64_t m_out,
+                           float* out_feat, void* stream);
+/* grad_in[i][:] = sum_k W[:,k,:]^T . grad_out[rnbr[k][i]][:] */
+int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* weight, int cin,
+                         int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in, void* stream);
+size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
+/* grad_w[cout][kvol][cin] = sum_o grad_out[o]^T (x) in[nbr[k][o]]  (deterministic two-pass) */
+int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
+                         int cout, int kvol, const int32_t* nbr, float* grad_w, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* SparseConvTensor.dense(): dense f32 [batch, c, D, H, W], fully written (zeros where inactive).
+ * feat rows must be in canonical order (perm == NULL) or mapped through perm. */
+int efg_sparse_to_dense_f32(const float* feat, int c, const void* index, const int32_t* perm, int batch,
+                            const int* shape_host, float* dense, void* stream);
+/* backward of dense(): grad_feat[m,c] gathered from grad_dense. */
+int efg_dense_to_sparse_f32(const float* grad_dense, int c, const int32_t* indices, int64_t m, int batch,
+                            const int* shape_host, float* grad_feat, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Box / multi-scale deformable attention.  One kernel family behind both
+ * efg::box_attn_forward/backward (efg/operators/src/box_attn/box_attn.h:29-83) and
+ * efg::ms_deform_attn_forward/backward (efg/operators/src/deform_attn/ms_deform_attn.h:22-63).
+ *   value f32 [b,s,h,d]; shapes i64 [l,2] (H,W); level_start i64 [l];
+ *   loc f32 [b,lq,h,l,p,2] (x,y in [0,1]); attn f32 [b,lq,h,l,p]; out f32 [b,lq,h*d].
+ * d must be a multiple of 4 and <= 256.
+ * ---------------------------------------------------------------------------------------- */
+int efg_msda_forward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                         const float* loc, const float* attn, int b, int s, int h, int d, int l, int lq, int p,
+                         float* out, void* stream);
+/* grad_value must be zero-filled by the caller (it is accumulated into); grad_loc / grad_attn
+ * are fully written. */
+int efg_msda_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                          const float* loc, const float* attn, const float* grad_out, int b, int s, int h,
+                          int d, int l, int lq, int p, float* grad_value, float* grad_loc, float* grad_attn,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""GPU parity: HIP voxelizers (through the C ABI) vs the oracle and the reference's golden
+vectors.  Bar: bit-exact (integer indices, copied fp32 payloads)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "voxelize_*.npz")))
+
+
+def _run_hard(dev, pts, vs, cr, mp, mv):
+    from efg_amd.operators import voxelization
+
+    out = voxelization(torch.from_numpy(pts).to(dev), list(map(float, vs)), list(map(float, cr)), mp, mv)
+    return [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_hard_voxelize_golden(dev, case):
+    g = golden(case)
+    v, c, n = _run_hard(dev, g["points"], g["voxel_size"], g["coors_range"], int(g["max_points"]),
+                        int(g["max_voxels"]))
+    assert v.shape == g["voxels"].shape
+    assert np.array_equal(c, g["coors"])
+    assert np.array_equal(n, g["num_points_per_voxel"])
+    assert np.array_equal(v, g["voxels"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dynamic_voxelize_golden(dev, case):
+    from efg_amd.operators import voxelization
+
+    g = golden(case)
+    coors = voxelization(torch.from_numpy(g["points"]).to(dev), g["voxel_size"].tolist(), g["coors_range"].tolist(),
+                         -1, -1)
+    assert np.array_equal(coors.cpu().numpy(), g["dynamic_coors"])
+
+
+@pytest.mark.parametrize("n,sweeps,mp,mv", [(180000, 1, 5, 120000), (180000, 1, 5, 30000), (720000, 4, 5, 200000),
+                                            (720000, 4, 5, 50000), (50000, 1, 1, 120000)])
+def test_hard_voxelize_full_size_vs_oracle(dev, oracle_mod, n, sweeps, mp, mv):
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+
+    pts, _, _ = make_scene(2000 + n % 97 + mv % 13, n_points=n, n_sweeps=sweeps)
+    ev, ec, en = oracle_mod.hard_voxelize(pts, VOXEL_SIZE, PC_RANGE, mp, mv)
+    v, c, k = _run_hard(dev, pts, VOXEL_SIZE, PC_RANGE, mp, mv)
+    assert np.array_equal(c, ec) and np.array_equal(k, en) and np.array_equal(v, ev)
+
+
+def test_module_api_and_modes(dev, oracle_mod):
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators import Voxelization
+
+    pts, _, _ = make_scene(5, n_points=20000)
+    m = Voxelization(list(VOXEL_SIZE), list(PC_RANGE), 5, max_voxels=(3000, 9000))
+    assert m.grid_size.tolist() == [1504, 1504, 40]
+    t = torch.from_numpy(pts).to(dev)
+    m.train()
+    v, c, n = m(t)
+    assert v.shape[0] == 3000 and c.dtype == torch.int32 and n.dtype == torch.int32
+    m.eval()
+    v2, c2, n2 = m(t)
+    e = oracle_mod.hard_voxelize(pts, VOXEL_SIZE, PC_RANGE, 5, 9000)
+    assert np.array_equal(v2.cpu().numpy(), e[0]) and np.array_equal(c2.cpu().numpy(), e[1])
+    assert "max_voxels=(3000, 9000)" in repr(m)
+
+
+def test_edge_cases(dev, oracle_mod):
+    from efg_amd.operators import voxelization
+
+    vs, cr = [0.5, 0.5, 0.5], [0.0, 0.0, 0.0, 4.0, 4.0, 4.0]
+    # empty input
+    v, c, n = voxelization(torch.zeros((0, 4), device=dev), vs, cr, 3, 10)
+    assert v.shape == (0, 3, 4) and c.shape == (0, 3) and n.shape == (0,)
+    # everything outside, NaN counted as outside
+    pts = torch.full((9, 4), -3.0, device=dev)
+    pts[3, 0] = float("nan")
+    v, c, n = voxelization(pts, vs, cr, 3, 10)
+    assert v.shape[0] == 0
+    assert (voxelization(pts, vs, cr, -1, -1) == -1).all()
+    # one voxel, many points (slot ranks must follow point order)
+    rng = np.random.default_rng(0)
+    p = np.concatenate([rng.uniform(1.0, 1.49, (300, 3)), rng.uniform(0, 1, (300, 1))], 1).astype(np.float32)
+    v, c, n = voxelization(torch.from_numpy(p).to(dev), vs, cr, 7, 4)
+    e = oracle_mod.hard_voxelize(p, vs, cr, 7, 4)
+    assert np.array_equal(v.cpu().numpy(), e[0]) and np.array_equal(n.cpu().numpy(), e[2])
+    # CPU tensors are refused loudly (no fallback)
+    with pytest.raises(RuntimeError):
+        voxelization(torch.zeros((4, 4)), vs, cr, 3, 10)
+
+
+def test_batched_matches_per_scene(dev, oracle_mod):
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators import voxelize_batch
+
+    scenes = [make_scene(300 + i, n_points=n)[0] for i, n in enumerate([40000, 25000, 0, 33000])]
+    scenes[2] = np.zeros((0, 5), np.float32)
+    mv = 20000
+    out = voxelize_batch([torch.from_numpy(s).to(dev) for s in scenes], VOXEL_SIZE, PC_RANGE, 5, mv)
+    base = 0
+    for b, s in enumerate(scenes):
+        ev, ec, en = oracle_mod.hard_voxelize(s, VOXEL_SIZE, PC_RANGE, 5, mv)
+        m = out["num_voxels"][b]
+        assert m == ev.shape[0]
+        sl = slice(base, base + m)
+        assert np.array_equal(out["voxels"][sl].cpu().numpy(), ev)
+        co = out["coordinates"][sl].cpu().numpy()
+        assert (co[:, 0] == b).all() and np.array_equal(co[:, 1:], ec)
+        assert np.array_equal(out["num_points_per_voxel"][sl].cpu().numpy(), en)
+        np.testing.assert_allclose(out["voxel_mean"][sl].cpu().numpy(), oracle_mod.voxel_mean(ev, en), rtol=1e-6,
+                                   atol=1e-6)
+        base += m
+    assert out["voxels"].shape[0] == base
