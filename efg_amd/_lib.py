@@ -38,6 +38,8 @@ _SIGS = {
     "efg_spconv_build_nbr": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "efg_spconv_build_rnbr": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "efg_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "efg_spconv_pack_weight_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "efg_spconv_forward_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                        c_void_p, c_void_p]),
     "efg_spconv_dgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p,
@@ -70,6 +72,8 @@ def lib():
                 "There is no CPU fallback on the product path." % _LIB_PATH)
         _lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGS.items():
+            if os.environ.get("EFG_DEV_PARTIAL_LIB") and not hasattr(_lib, name):
+                continue  # bring-up only: a half-built library during kernel development
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args

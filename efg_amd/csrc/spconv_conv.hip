@@ -1,0 +1,419 @@
+// Sparse convolution arithmetic for gfx950: output-stationary gathered implicit GEMM on
+// v_mfma_f32_16x16x4_f32 (exact fp32, the dtype the reference trains in), forward / dgrad / wgrad.
+//
+// Replaces spconv's gather -> GEMM -> scatter-add per kernel offset as exercised by
+// efg/modeling/backbones/sparse_net.py:79-98,120-165,273-309,485-545 (contract SURVEY.md B.6).
+// No scatter and no atomics: with nbr[k][o] (spconv_index.hip) every output row is produced once,
+//     out[o][:] = sum_k  in[nbr[k][o]][:] . W[:,k,:]^T
+// and dgrad is the SAME kernel driven by the transposed table rnbr and transposed weights.
+//
+// forward / dgrad kernel, per wave (waves are independent; a 256-thread block is 4 of them):
+//   * 16 output rows x all output channels: NT accumulator tiles of 16x16 (4 VGPRs each);
+//   * the wave's nbr column block (kvol x 16 ints) is staged in LDS once; offsets k for which none
+//     of the 16 rows has a neighbour are skipped entirely (rows are in spatial order, so validity is
+//     spatially coherent);
+//   * for an active k the 16 gathered input rows are read as contiguous 256-byte runs (one row per
+//     load instruction, 16 loads in flight), staged in a wave-private LDS tile with row stride
+//     CK+2 (bank-conflict-free ds_read_b32 of the A fragment), double-buffered against the MFMAs;
+//   * the B fragments come straight from L1/L2 as 16-byte loads of weights pre-packed into MFMA
+//     operand order (efg_spconv_pack_weight_f32): one load feeds four MFMAs.
+// wgrad: per (row chunk, 64x64 block of dW, group of offsets) workgroup; G^T x gathered-A on the
+// same MFMA, partial sums to a workspace, deterministic second-pass reduce.
+#include "common.h"
+
+namespace efg {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCK = 64;           // channels per staged chunk
+constexpr int kAStride = kCK + 2;  // 2 x odd -> conflict-free A-fragment reads
+constexpr int kMaxKvol = 64;
+
+__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
+
+// ---- weight packing -----------------------------------------------------------------------
+// packed[((k*R16 + r16)*NP + n)*16 + kk*4 + j] = W(red = r16*16 + 4*j + kk, n) for offset k,
+// where (red, n) = (ci, co) forward, (co, ci) dgrad; zero padded to multiples of 16.
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin,
+                                                           int for_dgrad, float* __restrict__ packed) {
+  const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
+  const int r16n = round16(red) / 16, np = round16(nn);
+  const long long total = (long long)kvol * r16n * np * 16;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(e & 15);
+    const int kk = t >> 2, j = t & 3;
+    long long q = e >> 4;
+    const int n = (int)(q % np);
+    q /= np;
+    const int r16 = (int)(q % r16n);
+    const int k = (int)(q / r16n);
+    const int r = r16 * 16 + 4 * j + kk;
+    float v = 0.0f;
+    if (r < red && n < nn) {
+      const int co = for_dgrad ? r : n, ci = for_dgrad ? n : r;
+      v = w[((long long)co * kvol + k) * cin + ci];
+    }
+    packed[e] = v;
+  }
+}
+
+// ---- forward / dgrad ------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;     // [m_in][cin]
+  const float* wp;     // packed
+  const float* bias;   // [cout] or null
+  const int* nbr;      // [kvol][m_out]
+  float* out;          // [m_out][cout]
+  long long m_out;
+  int cin, cout, kvol;
+  int c16n;            // round16(cin)/16
+  int np;              // round16(cout)
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
+  __shared__ float a_tile[4][2][16 * kAStride];
+  __shared__ int nbr_tile[4][kMaxKvol * 16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long r0 = ((long long)blockIdx.x * 4 + wv) * 16;
+  if (r0 >= a.m_out) return;  // whole wave out of range (waves never sync with each other)
+  float* at0 = a_tile[wv][0];
+  float* at1 = a_tile[wv][1];
+  int* nb = nbr_tile[wv];
+  const int n_tile0 = blockIdx.y * NT;  // first n-tile of this block
+
+  // stage the wave's rulebook block and find the active offsets
+  for (int e = lane; e < a.kvol * 16; e += 64) {
+    const int k = e >> 4, j = e & 15;
+    nb[e] = (r0 + j < a.m_out) ? a.nbr[(long long)k * a.m_out + r0 + j] : -1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned long long active = 0;
+  for (int k = 0; k < a.kvol; ++k) {
+    const int v = (lane < 16) ? nb[k * 16 + lane] : -1;
+    if (__ballot(v >= 0)) active |= 1ull << k;
+  }
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float b = 0.0f;
+    const int co = (n_tile0 + t) * 16 + (lane & 15);
+    if (a.bias && co < a.cout) b = a.bias[co];
+    acc[t] = f32x4{b, b, b, b};
+  }
+
+  const int nchunk = (a.c16n * 16 + kCK - 1) / kCK;  // channel chunks of 64 per offset
+  float pre[16];
+
+  // gather of (k, chunk) into registers: row j of the wave -> pre[j] (lane = channel)
+  auto gather = [&](int k, int ch) {
+    const int c = ch * kCK + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = nb[k * 16 + j];
+      pre[j] = (row >= 0 && c < a.cin) ? a.in[(long long)row * a.cin + c] : 0.0f;
+    }
+  };
+  auto stash = [&](float* at) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) at[j * kAStride + lane] = pre[j];
+  };
+  auto compute = [&](const float* at, int k, int ch) {
+    const int c16_lo = ch * (kCK / 16);
+    const int c16_hi = min(c16_lo + kCK / 16, a.c16n);
+    const int m = lane & 15, kk = lane >> 4;
+    for (int c16 = c16_lo; c16 < c16_hi; ++c16) {
+      const float* ap = at + m * kAStride + (c16 - c16_lo) * 16 + kk;
+      const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+      const float* bp = a.wp + (((long long)k * a.c16n + c16) * a.np + n_tile0 * 16 + m) * 16 + kk * 4;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + t * 256);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  // software pipeline over the (active offset, chunk) steps
+  const int nsteps = __popcll(active) * nchunk;
+  if (nsteps > 0) {
+    unsigned long long rem = active;
+    int k_cur = __ffsll((long long)rem) - 1, ch_cur = 0;
+    gather(k_cur, ch_cur);
+    stash(at0);
+    for (int s = 0; s < nsteps; ++s) {
+      // next step coordinates
+      int k_nxt = k_cur, ch_nxt = ch_cur + 1;
+      if (ch_nxt == nchunk) {
+        ch_nxt = 0;
+        rem &= rem - 1;
+        k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+      }
+      const bool more = (s + 1 < nsteps);
+      if (more) gather(k_nxt, ch_nxt);  // global loads in flight during the MFMAs below
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      compute((s & 1) ? at1 : at0, k_cur, ch_cur);
+      if (more) stash((s & 1) ? at0 : at1);
+      k_cur = k_nxt;
+      ch_cur = ch_nxt;
+    }
+  }
+
+  // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = (n_tile0 + t) * 16 + (lane & 15);
+    if (co < a.cout) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = r0 + (lane >> 4) * 4 + r;
+        if (row < a.m_out) a.out[row * a.cout + co] = acc[t][r];
+      }
+    }
+  }
+}
+
+// ---- wgrad ------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* in;    // [m_in][cin]
+  const float* go;    // [m_out][cout]
+  const int* nbr;     // [kvol][m_out]
+  float* partial;     // [splits][kvol][cout][cin]
+  long long m_out;
+  int cin, cout, kvol;
+  int rows_per_split;  // multiple of 64
+  int nci_blk;         // ceil(cin / 64)
+  int kgroups;
+};
+
+constexpr int kWStride = 64 + 16;  // row stride of the LDS tiles (== 16 mod 32)
+
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+  __shared__ float g_tile[64 * kWStride];   // grad_out rows x 64 co
+  __shared__ float x_tile[64 * kWStride];   // gathered input rows x 64 ci
+  __shared__ int rows_s[64];
+  __shared__ int any_s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int split = blockIdx.x;
+  const int co0 = (blockIdx.y / a.nci_blk) * 64, ci0 = (blockIdx.y % a.nci_blk) * 64;
+  const int kg = blockIdx.z;
+  const int k_per = (a.kvol + a.kgroups - 1) / a.kgroups;
+  const int k_lo = kg * k_per, k_hi = min(k_lo + k_per, a.kvol);
+  const long long row_lo = (long long)split * a.rows_per_split;
+  const long long row_hi = min(row_lo + a.rows_per_split, a.m_out);
+  const int m = lane & 15, kk = lane >> 4;
+  // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles of the block
+  for (int k = k_lo; k < k_hi; ++k) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long t0 = row_lo; t0 < row_hi; t0 += 64) {
+      __syncthreads();  // previous tile fully consumed
+      if (threadIdx.x == 0) any_s = 0;
+      __syncthreads();
+      if (wv == 0) {
+        const int r = (t0 + lane < row_hi) ? a.nbr[(long long)k * a.m_out + t0 + lane] : -1;
+        rows_s[lane] = r;
+        if (r >= 0) any_s = 1;
+      }
+      __syncthreads();
+      if (!any_s) continue;  // no pair of this offset in the tile (block-uniform)
+      // stage: wave wv loads rows wv, wv+4, ... ; lane = channel
+      for (int j = wv; j < 64; j += 4) {
+        const int r = rows_s[j];
+        float g = 0.f, x = 0.f;
+        if (r >= 0) {
+          if (co0 + lane < a.cout) g = a.go[(t0 + j) * a.cout + co0 + lane];
+          if (ci0 + lane < a.cin) x = a.in[(long long)r * a.cin + ci0 + lane];
+        }
+        g_tile[j * kWStride + lane] = g;
+        x_tile[j * kWStride + lane] = x;
+      }
+      __syncthreads();
+      // dW[co][ci] += sum_rows G[row][co] * X[row][ci]; reduction dim = rows, 4 per MFMA
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const int row = s * 4 + kk;
+        const float av = g_tile[row * kWStride + wv * 16 + m];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float bv = x_tile[row * kWStride + t * 16 + m];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // write the partial block: row (co) = (lane>>4)*4 + reg, col (ci) = lane & 15
+    float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ci = ci0 + t * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wv * 16 + (lane >> 4) * 4 + r;
+        if (co < a.cout && ci < a.cin) p[(long long)co * a.cin + ci] = acc[t][r];
+      }
+    }
+  }
+}
+
+// grad_w[co][k][ci] = sum_s partial[s][k][co][ci]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int kvol,
+                                                            int cout, int cin, float* __restrict__ gw) {
+  const long long per = (long long)kvol * cout * cin;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per;
+       e += (long long)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int sp = 0; sp < splits; ++sp) s += partial[sp * per + e];
+    const int ci = (int)(e % cin);
+    long long q = e / cin;
+    const int co = (int)(q % cout);
+    const int k = (int)(q / cout);
+    gw[((long long)co * kvol + k) * cin + ci] = s;
+  }
+}
+
+struct WgradPlan {
+  int splits, rows_per_split, nco_blk, nci_blk, kgroups;
+  size_t bytes;
+};
+
+WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
+  WgradPlan p;
+  p.nco_blk = (cout + 63) / 64;
+  p.nci_blk = (cin + 63) / 64;
+  p.kgroups = kvol >= 27 ? 3 : 1;
+  const size_t per = (size_t)kvol * cout * cin * 4;
+  const int64_t budget_splits = std::max<int64_t>(1, (int64_t)((64ull << 20) / std::max<size_t>(per, 1)));
+  const int64_t want = std::max<int64_t>(1, ceil_div(m_out, 256));
+  const int64_t fill = std::max<int64_t>(1, 1024 / (p.nco_blk * p.nci_blk * p.kgroups));
+  int64_t s = std::min(std::min(want, budget_splits), fill);
+  int64_t rows = ceil_div(std::max<int64_t>(m_out, 1), s);
+  rows = ceil_div(rows, 64) * 64;
+  s = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), rows));
+  p.splits = (int)s;
+  p.rows_per_split = (int)rows;
+  p.bytes = (size_t)p.splits * per;
+  return p;
+}
+
+template <int NT>
+void launch_fwd(const ConvArgs& a, int nblk_y, hipStream_t stream) {
+  const unsigned gx = (unsigned)ceil_div(a.m_out, 64);
+  hipLaunchKernelGGL((conv_fwd_kernel<NT>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
+}
+
+int run_conv(const float* in, int cin, const float* wp, const float* bias, int cout, int kvol, const int* nbr,
+             int64_t m_out, float* out, hipStream_t stream) {
+  EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv: bad channel counts");
+  EFG_CHECK_ARG(kvol >= 1 && kvol <= kMaxKvol, "spconv: kernel volume must be in [1,%d], got %d", kMaxKvol, kvol);
+  if (m_out == 0) return EFG_OK;
+  ConvArgs a;
+  a.in = in;
+  a.wp = wp;
+  a.bias = bias;
+  a.nbr = nbr;
+  a.out = out;
+  a.m_out = m_out;
+  a.cin = cin;
+  a.cout = cout;
+  a.kvol = kvol;
+  a.c16n = (cin + 15) / 16;
+  a.np = (cout + 15) / 16 * 16;
+  const int ntiles = a.np / 16;
+  // n-tiles per wave: smallest of {1,2,4,8,16} covering the tiles; wider outputs tile over grid.y
+  if (ntiles > 8) launch_fwd<16>(a, (ntiles + 15) / 16, stream);
+  else if (ntiles > 4) launch_fwd<8>(a, 1, stream);
+  else if (ntiles > 2) launch_fwd<4>(a, 1, stream);
+  else if (ntiles > 1) launch_fwd<2>(a, 1, stream);
+  else launch_fwd<1>(a, 1, stream);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad) {
+  if (cout < 1 || cin < 1 || kvol < 1) return 0;
+  const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
+  // + one tile row of slack: kernels with NT > tiles read (zero-weight) past the last n-tile
+  return ((size_t)kvol * ((red + 15) / 16) * ((nn + 15) / 16 * 16) * 16 + 16 * 256) * sizeof(float);
+}
+
+extern "C" int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad,
+                                          float* packed, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(cout >= 1 && cin >= 1 && kvol >= 1, "spconv: bad weight shape");
+  const size_t bytes = efg_spconv_packed_weight_bytes(cout, kvol, cin, for_dgrad);
+  EFG_HIP_TRY(hipMemsetAsync(packed, 0, bytes, stream));
+  const long long total = (long long)(bytes / sizeof(float)) - 16 * 256;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256),
+                     0, stream, weight, cout, kvol, cin, for_dgrad, packed);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
+                                      const float* bias, int cout, int kvol, const int32_t* nbr, int64_t m_out,
+                                      float* out_feat, void* stream) {
+  (void)m_in;
+  return run_conv(in_feat, cin, packed_weight, bias, cout, kvol, nbr, m_out, out_feat, (hipStream_t)stream);
+}
+
+extern "C" int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight,
+                                    int cin, int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in,
+                                    void* stream) {
+  (void)m_out;
+  return run_conv(grad_out, cout, packed_weight, nullptr, cin, kvol, rnbr, m_in, grad_in, (hipStream_t)stream);
+}
+
+extern "C" size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol) {
+  if (cin < 1 || cout < 1 || kvol < 1 || m_out < 0) return 0;
+  return wgrad_plan(m_out, cin, cout, kvol).bytes + 256;
+}
+
+extern "C" int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out,
+                                    int64_t m_out, int cout, int kvol, const int32_t* nbr, float* grad_w, void* ws,
+                                    size_t ws_bytes, void* stream_) {
+  (void)m_in;
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(cin >= 1 && cout >= 1 && kvol >= 1 && kvol <= kMaxKvol, "spconv wgrad: bad sizes");
+  if (m_out == 0) {
+    EFG_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)cout * kvol * cin * 4, stream));
+    return EFG_OK;
+  }
+  const WgradPlan p = wgrad_plan(m_out, cin, cout, kvol);
+  if (ws_bytes < p.bytes) {
+    set_error("spconv wgrad workspace too small: need %zu bytes, got %zu", p.bytes + 256, ws_bytes);
+    return EFG_E_WORKSPACE;
+  }
+  WgradArgs a;
+  a.in = in_feat;
+  a.go = grad_out;
+  a.nbr = nbr;
+  a.partial = static_cast<float*>(ws);
+  a.m_out = m_out;
+  a.cin = cin;
+  a.cout = cout;
+  a.kvol = kvol;
+  a.rows_per_split = p.rows_per_split;
+  a.nci_blk = p.nci_blk;
+  a.kgroups = p.kgroups;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.splits, p.nco_blk * p.nci_blk, p.kgroups), dim3(256), 0, stream, a);
+  EFG_LAUNCH_CHECK();
+  const long long per = (long long)kvol * cout * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(per, 256), 4096)), dim3(256), 0,
+                     stream, a.partial, p.splits, kvol, cout, cin, grad_w);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}

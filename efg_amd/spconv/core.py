@@ -1,0 +1,355 @@
+"""spconv-style sparse tensors and convolutions on MI355X.
+
+The reference backbone (efg/modeling/backbones/sparse_net.py:6-11) imports third-party
+`spconv.pytorch`; this module provides the subset it calls -- `SparseConvTensor`, `SparseModule`,
+`SparseSequential`, `SubMConv3d`, `SparseConv3d`, `.dense()`, `.replace_feature()` -- with spconv
+2.x constructor signatures and parameter layout (`weight` is [Cout, kd, kh, kw, Cin]), on top of
+the HIP kernels in csrc/spconv_index.hip and csrc/spconv_conv.hip.
+
+Semantics: SubMConv3d keeps the input's sites AND row order; SparseConv3d activates
+every output site touched by an input site and returns rows in canonical order (ascending
+(b,z,y,x) linear index), so two convolutions with equal geometry over the same input are
+row-aligned (required by `out.features + shortcut.features`, sparse_net.py:162).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return tuple(int(x) for x in v)
+    return (int(v),) * 3
+
+
+class SiteIndex:
+    """Rank index (bitmap + popcount prefix) of a set of active sites; see csrc/rank_index.h."""
+
+    def __init__(self, index, perm, batch_size, spatial_shape):
+        self.index = index            # uint8 storage of uint2[words]
+        self.perm = perm              # int32[M] canonical rank -> row, or None if rows are canonical
+        self.batch_size = batch_size
+        self.spatial_shape = tuple(spatial_shape)
+
+    @staticmethod
+    def _alloc(batch_size, spatial_shape, device):
+        lib = L.lib()
+        shp = L.host_i32(spatial_shape, 3)
+        nbytes = lib.efg_spconv_index_bytes(batch_size, shp)
+        if nbytes == 0:
+            raise RuntimeError("efg_hip: " + lib.efg_last_error().decode())
+        ws_bytes = lib.efg_spconv_index_workspace_bytes(batch_size, shp)
+        index = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        return lib, shp, index, ws, ws_bytes
+
+    @classmethod
+    def from_indices(cls, indices, batch_size, spatial_shape, canonical=False):
+        lib, shp, index, ws, ws_bytes = cls._alloc(batch_size, spatial_shape, indices.device)
+        m = indices.shape[0]
+        perm = None if canonical else torch.empty(max(m, 1), dtype=torch.int32, device=indices.device)
+        L.check(lib.efg_spconv_index_from_indices(L.ptr(indices), m, batch_size, shp, L.ptr(index), L.ptr(perm),
+                                                  L.ptr(ws), ws_bytes, L.stream()))
+        return cls(index, perm, batch_size, spatial_shape)
+
+
+class Rulebook:
+    """Output-stationary neighbour table of one convolution geometry."""
+
+    def __init__(self, nbr, m_in, m_out, kvol, subm):
+        self.nbr = nbr          # int32 [kvol, m_out]
+        self.m_in, self.m_out, self.kvol, self.subm = m_in, m_out, kvol, subm
+        self._rnbr = None
+
+    @property
+    def rnbr(self):
+        """int32 [kvol, m_in]: transpose of nbr, for dgrad."""
+        if self._rnbr is None:
+            if self.subm:
+                self._rnbr = self.nbr.flip(0).contiguous()  # symmetric window: rnbr[k] = nbr[kvol-1-k]
+            else:
+                r = torch.empty((self.kvol, max(self.m_in, 1)), dtype=torch.int32, device=self.nbr.device)
+                L.check(L.lib().efg_spconv_build_rnbr(L.ptr(self.nbr), self.m_out, self.kvol, self.m_in, L.ptr(r),
+                                                      L.stream()))
+                self._rnbr = r[:, : self.m_in] if self.m_in > 0 else r[:, :0]
+                self._rnbr = self._rnbr.contiguous()
+        return self._rnbr
+
+
+class SparseConvTensor:
+    """spconv.pytorch.SparseConvTensor(features[M,C], indices int32[M,4] (b,z,y,x), spatial_shape[3],
+    batch_size) as constructed at sparse_net.py:289,531."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
+                 benchmark=False, _site_index=None):
+        L.require_gpu(features, indices)
+        if indices.dtype != torch.int32:
+            raise RuntimeError("SparseConvTensor: indices must be int32")
+        if indices.dim() != 2 or indices.shape[1] != 4 or indices.shape[0] != features.shape[0]:
+            raise RuntimeError("SparseConvTensor: indices must be [M, 4] (b,z,y,x) matching features")
+        self.features = features
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = indice_dict if indice_dict is not None else {}
+        self._site_index = _site_index
+        self._conv_cache = {}
+
+    def replace_feature(self, feature):
+        new = SparseConvTensor.__new__(SparseConvTensor)
+        new.__dict__.update(self.__dict__)  # shares indices, site index, rulebook caches
+        new.features = feature
+        return new
+
+    @property
+    def spatial_size(self):
+        return int(math.prod(self.spatial_shape))
+
+    def site_index(self):
+        if self._site_index is None:
+            self._site_index = SiteIndex.from_indices(self.indices, self.batch_size, self.spatial_shape)
+        return self._site_index
+
+    def dense(self, channels_first=True):
+        """[B, C, D, H, W] (sparse_net.py:304); zeros where inactive."""
+        out = _ToDense.apply(self.features, self)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class _ToDense(Function):
+    @staticmethod
+    def forward(ctx, features, x):
+        si = x.site_index()
+        features = features.contiguous()
+        c = features.shape[1]
+        d, h, w = x.spatial_shape
+        dense = torch.empty((x.batch_size, c, d, h, w), dtype=torch.float32, device=features.device)
+        L.check(L.lib().efg_sparse_to_dense_f32(L.ptr(features), c, L.ptr(si.index), L.ptr(si.perm), x.batch_size,
+                                                L.host_i32(x.spatial_shape, 3), L.ptr(dense), L.stream()))
+        ctx.x = x
+        return dense
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_dense):
+        x = ctx.x
+        grad_dense = grad_dense.contiguous()
+        m, c = x.indices.shape[0], grad_dense.shape[1]
+        g = torch.empty((m, c), dtype=torch.float32, device=grad_dense.device)
+        L.check(L.lib().efg_dense_to_sparse_f32(L.ptr(grad_dense), c, L.ptr(x.indices), m, x.batch_size,
+                                                L.host_i32(x.spatial_shape, 3), L.ptr(g), L.stream()))
+        return g, None
+
+
+class _SparseConvFunction(Function):
+    """features[M_in,Cin] x weight[Cout,kvol,Cin] (+bias) -> [M_out,Cout] through a Rulebook."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, rb):
+        lib = L.lib()
+        features = features.contiguous()
+        cout, cin = weight.shape[0], weight.shape[-1]
+        kvol = rb.kvol
+        w = weight.reshape(cout, kvol, cin).contiguous()
+        packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
+                             device=features.device)
+        L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
+        out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
+        L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
+                                           L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
+        ctx.save_for_backward(features, w)
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        lib = L.lib()
+        features, w = ctx.saved_tensors
+        rb = ctx.rb
+        grad_out = grad_out.contiguous()
+        cout, kvol, cin = w.shape
+        dev = grad_out.device
+        grad_in = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8, device=dev)
+            L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
+            grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=dev)
+            L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol,
+                                             L.ptr(rb.rnbr), rb.m_in, L.ptr(grad_in), L.stream()))
+        if ctx.needs_input_grad[1]:
+            ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=dev)
+            L.check(lib.efg_spconv_wgrad_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
+                                             L.ptr(rb.nbr), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
+            grad_w = grad_w.view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = grad_out.sum(0)
+        return grad_in, grad_w, grad_b, None
+
+
+def _build_nbr(si_in, out_indices, m_out, ksize, stride, padding):
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    nbr = torch.empty((kvol, max(m_out, 1)), dtype=torch.int32, device=out_indices.device)
+    if m_out > 0:
+        L.check(L.lib().efg_spconv_build_nbr(L.ptr(si_in.index), L.ptr(si_in.perm), si_in.batch_size,
+                                             L.host_i32(si_in.spatial_shape, 3), L.ptr(out_indices), m_out,
+                                             L.host_i32(ksize, 3), L.host_i32(stride, 3), L.host_i32(padding, 3),
+                                             L.ptr(nbr), L.stream()))
+    return nbr if m_out > 0 else nbr[:, :0].contiguous()
+
+
+class SparseModule(nn.Module):
+    """Marker base class (spconv.pytorch.SparseModule): modules that take a SparseConvTensor."""
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """spconv.pytorch.SparseSequential: sparse modules get the tensor, plain nn.Modules (BatchNorm1d,
+    ReLU, ...) are applied to `.features` (sparse_net.py:85-95)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(str(len(self._modules)) if name is None else name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if module is None:
+                continue
+            if is_spconv_module(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
+        return input
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, indice_key=None):
+        super().__init__()
+        assert ndim == 3 and groups == 1
+        assert _triple(dilation) == (1, 1, 1), "dilation is not used by the EFG backbones"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.subm, self.indice_key = subm, indice_key
+        if subm:
+            assert self.stride == (1, 1, 1) and all(k % 2 == 1 for k in self.kernel_size)
+        # spconv 2.x parameter layout: [Cout, kd, kh, kw, Cin]
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight.view(self.out_channels, -1), a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return "{}, {}, kernel_size={}, stride={}, padding={}, subm={}, indice_key={}".format(
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.subm,
+            self.indice_key)
+
+    def _rulebook(self, x):
+        ks, st = self.kernel_size, self.stride
+        if self.subm:
+            pad = tuple(k // 2 for k in ks)  # SubM ignores `padding`: the window is always centred
+            key = ("subm", self.indice_key, ks) if self.indice_key is not None else None
+            if key is not None and key in x.indice_dict:
+                return x.indice_dict[key], None
+            m = x.indices.shape[0]
+            nbr = _build_nbr(x.site_index(), x.indices, m, ks, (1, 1, 1), pad)
+            rb = Rulebook(nbr, m, m, nbr.shape[0], True)
+            if key is not None:
+                x.indice_dict[key] = rb
+            return rb, None
+        pad = self.padding
+        key = ("conv", ks, st, pad)
+        if key in x._conv_cache:  # main and shortcut convs of a block share one geometry
+            return x._conv_cache[key]
+        lib = L.lib()
+        dev = x.indices.device
+        out_shape = (L.ctypes.c_int * 3)()
+        in_shape = L.host_i32(x.spatial_shape, 3)
+        oshape_py = [(x.spatial_shape[a] + 2 * pad[a] - ks[a]) // st[a] + 1 for a in range(3)]
+        oshp = L.host_i32(oshape_py, 3)
+        nbytes = lib.efg_spconv_index_bytes(x.batch_size, oshp)
+        ws_bytes = lib.efg_spconv_index_workspace_bytes(x.batch_size, oshp)
+        if nbytes == 0:
+            raise RuntimeError("efg_hip: " + lib.efg_last_error().decode())
+        oindex = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        m_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.efg_spconv_index_downsample(L.ptr(x.indices), x.indices.shape[0], x.batch_size, in_shape,
+                                                L.host_i32(ks, 3), L.host_i32(st, 3), L.host_i32(pad, 3),
+                                                L.ptr(oindex), out_shape, L.ptr(m_out_dev), L.ptr(ws), ws_bytes,
+                                                L.stream()))
+        m_out = int(m_out_dev.item())  # sizes every downstream tensor of this level (one sync per level)
+        out_indices = torch.empty((max(m_out, 1), 4), dtype=torch.int32, device=dev)
+        L.check(lib.efg_spconv_index_emit(L.ptr(oindex), x.batch_size, oshp, L.ptr(out_indices), L.stream()))
+        out_indices = out_indices[:m_out]
+        nbr = _build_nbr(x.site_index(), out_indices, m_out, ks, st, pad)
+        rb = Rulebook(nbr, x.indices.shape[0], m_out, nbr.shape[0], False)
+        geom = (out_indices, SiteIndex(oindex, None, x.batch_size, oshape_py), oshape_py)
+        x._conv_cache[key] = (rb, geom)
+        return rb, geom
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        rb, geom = self._rulebook(x)
+        feats = _SparseConvFunction.apply(x.features, self.weight, self.bias, rb)
+        if self.subm:
+            return x.replace_feature(feats)
+        out_indices, site_index, out_shape = geom
+        return SparseConvTensor(feats, out_indices, out_shape, x.batch_size, indice_dict=x.indice_dict,
+                                _site_index=site_index)
+
+
+class SubMConv3d(SparseConvolution):
+    """spconv.pytorch.SubMConv3d(in, out, kernel_size, stride=1, padding=0, ..., bias=True, indice_key=None)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, 1, padding, dilation, groups, bias, True,
+                         indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    """spconv.pytorch.SparseConv3d(in, out, kernel_size, stride=1, padding=0, ..., bias=True, indice_key=None)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
+                         indice_key)

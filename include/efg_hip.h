@@ -125,13 +125,20 @@ int efg_spconv_build_nbr(const void* in_index, const int32_t* in_perm, int batch
 int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m_in, int32_t* rnbr,
                           void* stream);
 
-/* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:].  weight f32 [cout][kvol][cin]
- * (spconv 2.x layout [Cout,kd,kh,kw,Cin]); bias may be NULL. */
-int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* weight,
+/* Weights arrive in the spconv 2.x parameter layout f32 [cout][kvol][cin] ([Cout,kd,kh,kw,Cin]) and
+ * are re-packed once per call site into MFMA B-operand order (one 16-byte load per lane feeds four
+ * v_mfma_f32_16x16x4_f32):  for_dgrad = 0: packed[k][cin/16][cout_pad][16]  (reduce over cin)
+ *                           for_dgrad = 1: packed[k][cout/16][cin_pad][16]  (reduce over cout). */
+size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad);
+int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad, float* packed,
+                               void* stream);
+
+/* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:]   (bias may be NULL; packed: for_dgrad = 0) */
+int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                            const float* bias, int cout, int kvol, const int32_t* nbr, int64_t m_out,
                            float* out_feat, void* stream);
-/* grad_in[i][:] = sum_k W[:,k,:]^T . grad_out[rnbr[k][i]][:] */
-int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* weight, int cin,
+/* grad_in[i][:] = sum_k W[:,k,:]^T . grad_out[rnbr[k][i]][:]   (packed: for_dgrad = 1) */
+int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight, int cin,
                          int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in, void* stream);
 size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
 /* grad_w[cout][kvol][cin] = sum_o grad_out[o]^T (x) in[nbr[k][o]]  (deterministic two-pass) */

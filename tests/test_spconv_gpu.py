@@ -1,0 +1,144 @@
+"""GPU parity: sparse-conv geometry (bit-exact rulebooks) and arithmetic (fp32, 1e-4 relative to
+the double-accumulating oracle) through the C ABI; plus dense-equivalence and full-size properties."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_oracle_spconv import CONVS, random_sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _tensor(dev, idx, feat, batch, shape):
+    import efg_amd.spconv as spconv
+
+    return spconv.SparseConvTensor(torch.from_numpy(feat).to(dev), torch.from_numpy(idx).to(dev), shape, batch)
+
+
+@pytest.mark.parametrize("ks,st,pd", CONVS)
+@pytest.mark.parametrize("cin,cout", [(5, 16), (32, 64), (128, 128)])
+def test_regular_conv_vs_oracle(dev, oracle_mod, ks, st, pd, cin, cout):
+    import efg_amd.spconv as spconv
+
+    rng = np.random.default_rng(cin * 7 + cout)
+    batch, shape = 2, (9, 20, 24)
+    idx, feat = random_sparse(rng, batch, shape, 1500, cin)
+    conv = spconv.SparseConv3d(cin, cout, ks, st, padding=pd, bias=False).to(dev)
+    x = _tensor(dev, idx, feat, batch, shape)
+    x.features.requires_grad_(True)
+    y = conv(x)
+    w = conv.weight.detach().cpu().numpy().reshape(cout, -1, cin)
+    out_idx, oshape = oracle_mod.spconv_out_indices(idx, batch, shape, ks, st, pd)
+    nbr = oracle_mod.spconv_rulebook(idx, out_idx, batch, shape, ks, st, pd)
+    assert y.spatial_shape == oshape
+    assert np.array_equal(y.indices.cpu().numpy(), out_idx)                       # bit-exact sites + order
+    rb = conv._rulebook(x)[0]
+    assert np.array_equal(rb.nbr.cpu().numpy(), nbr)                              # bit-exact rulebook
+    ref = oracle_mod.spconv_forward(feat, w, None, nbr)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    go = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(torch.from_numpy(go).to(dev))
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), oracle_mod.spconv_dgrad(go, w, nbr, feat.shape[0]),
+                               rtol=1e-4, atol=1e-4)
+    gw = oracle_mod.spconv_wgrad(feat, go, nbr)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(gw.shape), gw, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("cin,cout,bias", [(16, 16, False), (16, 32, True), (64, 64, False), (256, 256, False),
+                                           (6, 16, True), (48, 80, False)])
+def test_subm_conv_vs_oracle(dev, oracle_mod, cin, cout, bias):
+    import efg_amd.spconv as spconv
+
+    rng = np.random.default_rng(cin + cout)
+    batch, shape = 2, (7, 24, 24)
+    idx, feat = random_sparse(rng, batch, shape, 2000, cin)
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=bias, indice_key="k").to(dev)
+    x = _tensor(dev, idx, feat, batch, shape)
+    x.features.requires_grad_(True)
+    y = conv(x)
+    assert y.indices is x.indices  # same sites, same row order
+    w = conv.weight.detach().cpu().numpy().reshape(cout, 27, cin)
+    b = conv.bias.detach().cpu().numpy() if bias else None
+    nbr = oracle_mod.spconv_rulebook(idx, idx, batch, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert np.array_equal(x.indice_dict[("subm", "k", (3, 3, 3))].nbr.cpu().numpy(), nbr)
+    ref = oracle_mod.spconv_forward(feat, w, b, nbr)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    go = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(torch.from_numpy(go).to(dev))
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), oracle_mod.spconv_dgrad(go, w, nbr, feat.shape[0]),
+                               rtol=1e-4, atol=1e-4)
+    gw = oracle_mod.spconv_wgrad(feat, go, nbr)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(gw.shape), gw, rtol=1e-4, atol=2e-4)
+    if bias:
+        np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), go.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_dense_roundtrip_and_grad(dev, oracle_mod):
+    rng = np.random.default_rng(5)
+    batch, shape, c = 3, (5, 37, 41), 70
+    idx, feat = random_sparse(rng, batch, shape, 3000, c)
+    x = _tensor(dev, idx, feat, batch, shape)
+    x.features.requires_grad_(True)
+    d = x.dense()
+    assert d.shape == (batch, c, *shape)
+    assert np.array_equal(d.detach().cpu().numpy(), oracle_mod.sparse_to_dense(feat, idx, batch, shape))
+    g = torch.randn_like(d)
+    d.backward(g)
+    ref = g.cpu()[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].numpy()
+    assert np.array_equal(x.features.grad.cpu().numpy(), ref)
+
+
+def test_sequential_block_alignment(dev):
+    """main and shortcut strided convs over the same input must be row-aligned (sparse_net.py:155-165)."""
+    import efg_amd.spconv as spconv
+
+    rng = np.random.default_rng(8)
+    idx, feat = random_sparse(rng, 2, (9, 30, 30), 2500, 16)
+    x = _tensor(dev, idx, feat, 2, (9, 30, 30))
+    main = spconv.SparseSequential(spconv.SparseConv3d(16, 32, 3, 2, padding=1, bias=False), torch.nn.BatchNorm1d(32),
+                                   torch.nn.ReLU(), spconv.SubMConv3d(32, 32, 3, padding=1, bias=False,
+                                                                      indice_key="r")).to(dev)
+    short = spconv.SparseSequential(spconv.SparseConv3d(16, 32, 3, 2, padding=1, bias=False),
+                                    torch.nn.BatchNorm1d(32)).to(dev)
+    a, b = main(x), short(x)
+    assert torch.equal(a.indices, b.indices)
+    lin = ((a.indices[:, 0].long() * 5 + a.indices[:, 1]) * 15 + a.indices[:, 2]) * 15 + a.indices[:, 3]
+    assert (lin[1:] > lin[:-1]).all()  # canonical order
+    (a.features + b.features).sum().backward()
+
+
+def test_full_size_properties(dev):
+    """180k-point scene through the ConQueR stem geometry: dense-free invariants."""
+    import efg_amd.spconv as spconv
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators import voxelize_batch
+
+    pts = [torch.from_numpy(make_scene(2000 + i, n_points=180000)[0]).to(dev) for i in range(2)]
+    vox = voxelize_batch(pts, VOXEL_SIZE, PC_RANGE, 5, 120000)
+    x = spconv.SparseConvTensor(vox["voxel_mean"], vox["coordinates"], [41, 1504, 1504], 2)
+    conv = spconv.SparseConv3d(5, 16, 3, 2, padding=1, bias=False).to(dev)
+    sub = spconv.SubMConv3d(16, 16, 3, padding=1, bias=False, indice_key="s").to(dev)
+    y = conv(x)
+    assert y.spatial_shape == [21, 752, 752]
+    ind = y.indices.long()
+    lin = ((ind[:, 0] * 21 + ind[:, 1]) * 752 + ind[:, 2]) * 752 + ind[:, 3]
+    assert (lin[1:] > lin[:-1]).all()
+    # every input site maps (k = centre-ish) into exactly the outputs that list it: pairs are consistent
+    rb = conv._rulebook(x)[0]
+    nbr = rb.nbr
+    valid = nbr >= 0
+    assert int(valid.sum()) == int((rb.rnbr >= 0).sum())           # nbr and its transpose hold the same pairs
+    assert valid.any(0).all()                                        # no output site without an input
+    # linearity of the arithmetic
+    z1 = sub(y).features
+    z2 = sub(y.replace_feature(y.features * 2.0)).features
+    torch.testing.assert_close(z2, z1 * 2.0, rtol=1e-5, atol=1e-6)
+    # a delta feature propagates only to its neighbours
+    f = torch.zeros_like(y.features)
+    f[12345, 3] = 1.0
+    z = sub(y.replace_feature(f)).features
+    touched = torch.nonzero(z.abs().sum(1) > 0).flatten()
+    centre = y.indices[12345]
+    d = (y.indices[touched] - centre).abs()
+    assert (d[:, 0] == 0).all() and (d[:, 1:] <= 1).all()
