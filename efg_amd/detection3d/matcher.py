@@ -1,0 +1,54 @@
+"""Hungarian matching of queries to GT boxes ($CQ/modules/matcher.py:9-96).  The cost matrices are
+built on the GPU for the whole batch and cross to the host ONCE per call (the reference moves one
+matrix per scene); the assignment itself is scipy's linear_sum_assignment, as in the reference."""
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from .utils import box_cxcyczlwh_to_xyxyxy, generalized_box3d_iou
+
+
+class HungarianMatcher3d(nn.Module):
+    def __init__(self, cost_class=1.0, cost_bbox=1.0, cost_giou=1.0, cost_rad=1.0):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou, self.cost_rad = cost_class, cost_bbox, cost_giou, cost_rad
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0 or cost_rad != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def cost_matrices(self, outputs, targets):
+        if "topk_indexes" in outputs:
+            idx = outputs["topk_indexes"]
+            pred_logits = torch.gather(outputs["pred_logits"], 1, idx.expand(-1, -1, outputs["pred_logits"].shape[-1]))
+            pred_boxes = torch.gather(outputs["pred_boxes"], 1, idx.expand(-1, -1, outputs["pred_boxes"].shape[-1]))
+        else:
+            pred_logits, pred_boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        bs = pred_logits.shape[0]
+        out_prob = pred_logits.sigmoid().float()
+        out_bbox, out_rad = pred_boxes.float().split(6, dim=-1)
+        alpha, gamma = 0.25, 2.0
+        neg_cost = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
+        pos_cost = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
+        mats = []
+        for i in range(bs):
+            tgt_ids = targets[i]["labels"]
+            tgt_bbox = targets[i]["gt_boxes"][..., :6].float()
+            tgt_rad = targets[i]["gt_boxes"][..., 6:].float()
+            cost_giou = -generalized_box3d_iou(box_cxcyczlwh_to_xyxyxy(out_bbox[i]), box_cxcyczlwh_to_xyxyxy(tgt_bbox))
+            cost_class = pos_cost[i][:, tgt_ids] - neg_cost[i][:, tgt_ids]
+            cost_bbox = torch.cdist(out_bbox[i], tgt_bbox, p=1)
+            cost_rad = torch.cdist(out_rad[i], tgt_rad, p=1)
+            mats.append(self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou +
+                        self.cost_rad * cost_rad)
+        return mats
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        mats = self.cost_matrices(outputs, targets)
+        nq = mats[0].shape[0] if mats else 0
+        sizes = [m.shape[1] for m in mats]
+        host = torch.cat(mats, dim=1).cpu() if mats else None  # the one D2H of this call
+        out = []
+        for c in (host.split(sizes, dim=1) if mats else []):
+            i, j = linear_sum_assignment(c.reshape(nq, -1))
+            out.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+        return out

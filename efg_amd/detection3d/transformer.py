@@ -1,0 +1,198 @@
+"""Voxel-DETR / ConQueR transformer ($CQ/transformer.py): box-attention encoder over the BEV
+tokens, top-k proposal selection, iterative-refinement decoder, momentum GT decoder.
+
+Module and parameter names follow the reference (encoder.layers.N.self_attn..., decoder.layers.N...,
+decoder.detection_head, proposal_head, decoder_gt) so state dicts are interchangeable."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .box_attention import Box3dAttention
+from .utils import MLP, flatten_with_shape, get_clones
+
+
+def _with_pos(tensor, pos):
+    return tensor if pos is None else tensor + pos
+
+
+class TransformerEncoderLayer(nn.Module):
+    """$CQ/transformer.py:206-243: box self-attention (no rotation) + FFN, post-norm."""
+
+    def __init__(self, d_model, nhead, nlevel, dim_feedforward, dropout, activation="relu"):
+        super().__init__()
+        self.self_attn = Box3dAttention(d_model, nlevel, nhead, with_rotation=False)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        assert activation == "relu"
+        self.activation = F.relu
+
+    def forward(self, src, pos, src_shape, src_start_idx, ref_windows):
+        src2 = self.self_attn(_with_pos(src, pos), src, src_shape, None, src_start_idx, None, ref_windows)[0]
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout2(src2))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, d_model, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = get_clones(encoder_layer, num_layers)
+
+    def forward(self, src, pos, src_shape, src_start_idx, ref_windows):
+        output = src
+        for layer in self.layers:
+            output = layer(output, pos, src_shape, src_start_idx, ref_windows)
+        return output
+
+
+class TransformerDecoderLayer(nn.Module):
+    """$CQ/transformer.py:258-317: MHA self-attention (bool attn_mask) -> rotated box cross-attention
+    over the encoder memory -> FFN.  Layer 0 REPLACES the query content by pos_embed_layer(ref)
+    and runs cross-attention with query_pos=None (:284-289) -- reproduced, not 'fixed'."""
+
+    def __init__(self, d_model, nhead, nlevel, dim_feedforward, dropout, activation="relu"):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = Box3dAttention(d_model, nlevel, nhead, with_rotation=True)
+        self.pos_embed_layer = MLP(10, d_model, d_model, 3)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        assert activation == "relu"
+        self.activation = F.relu
+
+    def forward(self, idx, query, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask=None):
+        if idx == 0:
+            query = self.pos_embed_layer(ref_windows)
+            q = k = query
+        elif query_pos is None:
+            query_pos = self.pos_embed_layer(ref_windows)
+            q = k = _with_pos(query, query_pos)
+        q, k, v = q.transpose(0, 1), k.transpose(0, 1), query.transpose(0, 1)
+        query2 = self.self_attn(q, k, v, attn_mask=attn_mask)[0].transpose(0, 1)
+        query = self.norm1(query + self.dropout1(query2))
+        query2 = self.multihead_attn(_with_pos(query, query_pos), memory, memory_shape, None, memory_start_idx, None,
+                                     ref_windows[..., :7])[0]
+        query = self.norm2(query + self.dropout2(query2))
+        query2 = self.linear2(self.dropout(self.activation(self.linear1(query))))
+        return self.norm3(query + self.dropout3(query2))
+
+
+class TransformerDecoder(nn.Module):
+    """$CQ/transformer.py:320-343; `detection_head` is attached by the model (voxel_detr.py:79-85)."""
+
+    def __init__(self, d_model, decoder_layer, num_layers):
+        super().__init__()
+        self.layers = get_clones(decoder_layer, num_layers)
+
+    def forward(self, query, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask=None):
+        output = query
+        intermediate, intermediate_ref_windows = [], []
+        for idx, layer in enumerate(self.layers):
+            output = layer(idx, output, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask)
+            new_ref_logits, new_ref_windows = self.detection_head(output, ref_windows[..., :7], idx)
+            ref_windows = torch.cat((new_ref_windows.detach(), new_ref_logits.sigmoid().detach()), dim=-1)
+            intermediate.append(output)
+            intermediate_ref_windows.append(new_ref_windows)
+        return torch.stack(intermediate), torch.stack(intermediate_ref_windows)
+
+
+class Transformer(nn.Module):
+    """$CQ/transformer.py:10-203."""
+
+    def __init__(self, d_model=256, nhead=8, nlevel=4, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=1024, dropout=0.1, activation="relu", num_queries=300, num_classes=3, mom=0.999):
+        super().__init__()
+        self.num_queries, self.num_classes, self.m = num_queries, num_classes, mom
+        encoder_layer = TransformerEncoderLayer(d_model, nhead, nlevel, dim_feedforward, dropout, activation)
+        self.encoder = TransformerEncoder(d_model, encoder_layer, num_encoder_layers)
+        decoder_layer = TransformerDecoderLayer(d_model, nhead, nlevel, dim_feedforward, dropout, activation)
+        self.decoder = TransformerDecoder(d_model, decoder_layer, num_decoder_layers)
+
+    def _create_ref_windows(self, tensor_list):
+        """Fixed anchors per BEV token: (x, y, z=0.5, l=w=0.025, h=0.5, angle=0) (:36-58)."""
+        device = tensor_list[0].device
+        ref_windows = []
+        for tensor in tensor_list:
+            B, _, H, W = tensor.shape
+            ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device),
+                                          torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device),
+                                          indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / H
+            ref_x = ref_x.reshape(-1)[None] / W
+            ref_xy = torch.stack((ref_x, ref_y), -1)
+            ref_wh = torch.ones_like(ref_xy) * 0.025
+            ph = torch.zeros_like(ref_xy)[..., :1]
+            ref_windows.append(torch.cat((ref_xy, ph + 0.5, ref_wh, ph + 0.5, ph), -1).expand(B, -1, -1))
+        return torch.cat(ref_windows, dim=1)
+
+    def _get_enc_proposals(self, enc_embed, ref_windows):
+        """top-k (unsorted, :65) proposals of the 1-class proposal head, detached (:60-81)."""
+        out_logits, out_ref_windows = self.proposal_head(enc_embed, ref_windows)
+        out_probs = out_logits[..., 0].sigmoid()
+        topk_probs, indexes = torch.topk(out_probs, self.num_queries, dim=1, sorted=False)
+        topk_probs, indexes = topk_probs.unsqueeze(-1), indexes.unsqueeze(-1)
+        out_ref_windows = torch.gather(out_ref_windows, 1, indexes.expand(-1, -1, out_ref_windows.shape[-1]))
+        out_ref_windows = torch.cat((out_ref_windows.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
+        return None, None, out_ref_windows, indexes
+
+    @torch.no_grad()
+    def _momentum_update_gt_decoder(self):
+        qs = [p.data for p in self.decoder.parameters()]
+        ks = [p.data for p in self.decoder_gt.parameters()]
+        # param_k = param_k * m + param_q * (1 - m) (:84-89), one fused multi-tensor pass
+        torch._foreach_mul_(ks, self.m)
+        torch._foreach_add_(ks, qs, alpha=1.0 - self.m)
+
+    def forward(self, src, pos, noised_gt_box=None, noised_gt_onehot=None, attn_mask=None, targets=None):
+        assert pos is not None, "position encoding is required!"
+        src_anchors = self._create_ref_windows(src)
+        src, src_shape = flatten_with_shape(src)
+        src_pos = torch.cat([pe.flatten(2).transpose(1, 2) for pe in pos], dim=1)
+        src_start_index = torch.cat([src_shape.new_zeros(1), src_shape.prod(1).cumsum(0)[:-1]])
+        memory = self.encoder(src, src_pos, src_shape, src_start_index, src_anchors)
+        query_embed, query_pos, topk_proposals, topk_indexes = self._get_enc_proposals(memory, src_anchors)
+        if noised_gt_box is not None:
+            noised_gt_proposals = torch.cat((noised_gt_box, noised_gt_onehot), dim=-1)
+            topk_proposals = torch.cat((noised_gt_proposals, topk_proposals), dim=1)
+        init_reference_out = topk_proposals[..., :7]
+        hs, inter_references = self.decoder(query_embed, query_pos, memory, src_shape, src_start_index, topk_proposals,
+                                            attn_mask)
+        if targets is not None:  # momentum GT decoder pass (:146-200)
+            batch_size = len(targets)
+            per_gt_num = [tgt["gt_boxes"].shape[0] for tgt in targets]
+            max_gt_num = max(per_gt_num)
+            gt_with_score = memory.new_zeros(batch_size, max_gt_num, 10)
+            for bi in range(batch_size):
+                gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
+                gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
+                                                                    num_classes=self.num_classes)
+            with torch.no_grad():
+                self._momentum_update_gt_decoder()
+                if noised_gt_box is not None:
+                    dn_group_num = noised_gt_proposals.shape[1] // (max_gt_num * 2)
+                    pos_noised = torch.cat([noised_gt_proposals[:, pi * max_gt_num:(pi + 1) * max_gt_num]
+                                            for pi in range(0, dn_group_num * 2, 2)], dim=1)
+                    gt_proposals = torch.cat((gt_with_score, pos_noised), dim=1)
+                    n = (dn_group_num + 1) * max_gt_num
+                    grp = torch.arange(n, device=memory.device) // max_gt_num
+                    gt_attn_mask = grp[:, None] != grp[None, :]  # groups see only themselves
+                else:
+                    gt_proposals, gt_attn_mask = gt_with_score, None
+                hs_gt, inter_references_gt = self.decoder_gt(None, None, memory, src_shape, src_start_index,
+                                                             gt_proposals, gt_attn_mask)
+            init_reference_out = torch.cat((init_reference_out, gt_proposals[..., :7]), dim=1)
+            hs = torch.cat((hs, hs_gt), dim=2)
+            inter_references = torch.cat((inter_references, inter_references_gt), dim=2)
+        return hs, init_reference_out, inter_references, memory, src_anchors, topk_indexes

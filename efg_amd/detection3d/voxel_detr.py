@@ -1,0 +1,234 @@
+"""VoxelDETR / ConQueR model ($CQ/voxel_detr.py:17-291), MI355X path.
+
+forward(batched_inputs) keeps the reference contract: a list of `(sample, {"annotations": ...})`
+pairs in, a dict of losses out (training) or per-scene detections (eval).  Differences, all on
+OUR side of the operator boundary and none changing a result:
+  * a sample may carry raw `points` [N,F] instead of CPU-voxelized arrays; then voxelization runs
+    on the GPU for the whole batch in one call (csrc/voxelize.hip) with the per-voxel mean fused
+    (the reference voxelizes with numba in DataLoader workers, extend_3d.py:255-283);
+  * branches of the graph that feed nothing (FPN p2/p4-output/p5, res2_out) are not evaluated
+    unless `config.model.get("eval_unused_levels")` is set (the reference computes
+    and discards them; their parameters get no gradient there either);
+  * the contrastive loss's Python double loop (:234-253) is evaluated in batched tensor form.
+"""
+import copy
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..modeling.backbones.fpn import build_resnet_fpn_backbone
+from ..modeling.readers import VoxelMeanFeatureExtractor
+from ..operators import voxelize_batch
+from .box_coder import VoxelBoxCoder3D
+from .cdn import dn_post_process, prepare_for_cdn
+from .heads import Det3DHead
+from .position_encoding import build_position_encoding
+from .transformer import Transformer
+
+
+class Backbone3d(nn.Module):
+    """reader -> sparse ResNet + FPN -> (feature, sine position embedding) per requested level
+    ($CQ/modules/backbone3d.py:6-34)."""
+
+    def __init__(self, hidden_dim, reader, extractor, position_encoding, out_features=()):
+        super().__init__()
+        self.reader = reader
+        self.extractor = extractor
+        self.position_encoding = build_position_encoding(position_encoding, hidden_dim)
+        self.out_features = list(out_features)
+        self.num_channels = [extractor.out_channels] * len(self.out_features)
+
+    def forward(self, voxels, coordinates, num_points_per_voxel, batch_size, input_shape, voxel_mean=None):
+        encoded = voxel_mean if voxel_mean is not None else self.reader(voxels, num_points_per_voxel, coordinates)
+        feats = self.extractor(encoded, coordinates, batch_size, input_shape)
+        return [(feats[of], self.position_encoding(feats[of]).type_as(feats[of])) for of in self.out_features]
+
+
+def collate(samples, device):
+    """efg/data/datasets/waymo/waymo.py:143-183 for the keys the model reads: concatenate voxels /
+    counts, left-pad coordinates with the sample index."""
+    voxels = torch.as_tensor(np.concatenate([s["voxels"] for s in samples], 0)).to(device)
+    npv = torch.as_tensor(np.concatenate([s["num_points_per_voxel"] for s in samples], 0)).to(device)
+    coors = [np.pad(s["coordinates"], ((0, 0), (1, 0)), mode="constant", constant_values=i)
+             for i, s in enumerate(samples)]
+    coors = torch.as_tensor(np.concatenate(coors, 0)).to(device)
+    return {"voxels": voxels, "num_points_per_voxel": npv, "coordinates": coors,
+            "shape": np.stack([s["shape"] for s in samples], 0)}
+
+
+class VoxelDETR(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.device = torch.device(config.model.device)
+        self.hidden_dim = config.model.hidden_dim
+        self.aux_loss = config.model.aux_loss
+        self.num_classes = len(config.dataset.classes)
+        self.num_queries = config.model.transformer.num_queries
+        input_dim = len(config.dataset.format) if config.dataset.nsweeps == 1 else len(config.dataset.format) + 1
+        self.input_dim = input_dim
+        reader = VoxelMeanFeatureExtractor(**config.model.backbone.reader, num_input_features=input_dim)
+        extractor = build_resnet_fpn_backbone(config.model.backbone.extractor, input_dim)
+        self.backbone = Backbone3d(config.model.backbone.hidden_dim, reader, extractor,
+                                   config.model.backbone.position_encoding,
+                                   out_features=config.model.backbone.out_features)
+        if not config.model.get("eval_unused_levels", False):
+            extractor.set_active_levels(list(config.model.backbone.out_features))
+        in_channels = self.backbone.num_channels
+        self.input_proj = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(in_channels[i], self.hidden_dim, kernel_size=1), nn.GroupNorm(32, self.hidden_dim))
+            for i in range(len(self.backbone.out_features))])
+        for module in self.input_proj.modules():
+            if isinstance(module, nn.Conv2d):
+                nn.init.xavier_uniform_(module.weight, gain=1)
+                nn.init.constant_(module.bias, 0)
+        tc = config.model.transformer
+        self.transformer = Transformer(d_model=tc.hidden_dim, nhead=tc.nhead,
+                                       nlevel=len(config.model.backbone.out_features),
+                                       num_encoder_layers=tc.enc_layers, num_decoder_layers=tc.dec_layers,
+                                       dim_feedforward=tc.dim_feedforward, dropout=tc.dropout,
+                                       num_queries=tc.num_queries, num_classes=self.num_classes,
+                                       mom=config.model.contrastive.mom)
+        self.transformer.proposal_head = Det3DHead(config, with_aux=False, with_metrics=False, num_classes=1,
+                                                   num_layers=1)
+        self.transformer.decoder.detection_head = Det3DHead(config, with_aux=True, with_metrics=True,
+                                                            num_classes=self.num_classes, num_layers=tc.dec_layers)
+        # momentum ("GT") decoder: a frozen copy updated by EMA every step (voxel_detr.py:86-89)
+        self.transformer.decoder_gt = copy.deepcopy(self.transformer.decoder)
+        for p in self.transformer.decoder_gt.parameters():
+            p.requires_grad = False
+        self.box_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range, device=self.device)
+        cc = config.model.contrastive
+        self.eqco, self.tau, self.contras_loss_coeff = cc.eqco, cc.tau, cc.loss_coeff
+        self.projector = nn.Sequential(nn.Linear(10, cc.dim), nn.ReLU(), nn.Linear(cc.dim, cc.dim))
+        self.predictor = nn.Sequential(nn.Linear(cc.dim, cc.dim), nn.ReLU(), nn.Linear(cc.dim, cc.dim))
+        self.similarity_f = nn.CosineSimilarity(dim=2)
+        self.config = config
+        vz = config.dataset.processors
+        self._vox_cfg = {k: vz[k].Voxelization for k in vz if "Voxelization" in vz[k]} if isinstance(vz, dict) else {}
+        pr = torch.tensor(config.dataset.pc_range, dtype=torch.float32)
+        vs = torch.tensor(config.dataset.voxel_size, dtype=torch.float32)
+        self.grid_size = torch.round((pr[3:] - pr[:3]) / vs).long().tolist()  # (x, y, z), voxel_generator.py:12-13
+        self.noise_generator = None  # optional torch.Generator for the CDN noise (tests)
+        self.to(self.device)
+
+    # ---------------------------------------------------------------------------------------------
+    def _inputs(self, batched_inputs):
+        samples = [bi[0] for bi in batched_inputs]
+        if "voxels" in samples[0]:  # reference format: CPU-voxelized arrays
+            c = collate(samples, self.device)
+            return c["voxels"], c["coordinates"], c["num_points_per_voxel"], list(c["shape"][0]), None
+        mode = "train" if self.training else "val"
+        vc = self._vox_cfg[mode]
+        pts = [torch.as_tensor(s["points"], dtype=torch.float32).to(self.device, non_blocking=True) for s in samples]
+        out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
+        return (out["voxels"], out["coordinates"], out["num_points_per_voxel"], self.grid_size,
+                out["voxel_mean"][:, : self.input_dim].contiguous())
+
+    def forward(self, batched_inputs):
+        batch_size = len(batched_inputs)
+        voxels, coords, num_points_per_voxel, input_shape, voxel_mean = self._inputs(batched_inputs)
+        if self.training:
+            targets = []
+            for bi in batched_inputs:
+                ann = bi[1]["annotations"]
+                tgt = {k: torch.as_tensor(np.asarray(ann[k])).to(self.device)
+                       for k in ["gt_boxes", "difficulty", "num_points_in_gt", "labels"] if k in ann}
+                tgt["gt_boxes"] = tgt["gt_boxes"].float().clone()
+                tgt["labels"] = tgt["labels"].long().clone()
+                targets.append(self.box_coder.encode(tgt))
+        else:
+            targets = None
+        feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
+        features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
+        pos_encodings = [fp[1] for fp in feats_pos]
+        dn = self.config.model.dn
+        if self.training and dn.enabled and dn.dn_number > 0:
+            input_query_label, input_query_bbox, attn_mask, dn_meta = prepare_for_cdn(
+                dn_args=(targets, dn.dn_number, dn.dn_label_noise_ratio, dn.dn_box_noise_scale),
+                training=self.training, num_queries=self.num_queries, num_classes=self.num_classes,
+                hidden_dim=self.hidden_dim, label_enc=None, generator=self.noise_generator)
+        else:
+            input_query_bbox = input_query_label = attn_mask = dn_meta = None
+        hidden_state, init_reference, inter_references, src_embed, src_ref_windows, src_indexes = self.transformer(
+            features, pos_encodings, input_query_bbox, input_query_label, attn_mask, targets=targets)
+        head = self.transformer.decoder.detection_head
+        outputs_classes, outputs_coords = [], []
+        for idx in range(hidden_state.shape[0]):
+            reference = init_reference if idx == 0 else inter_references[idx - 1]
+            oc, ob = head(hidden_state[idx], reference, idx)
+            outputs_classes.append(oc)
+            outputs_coords.append(ob)
+        outputs_class, outputs_coord = torch.stack(outputs_classes), torch.stack(outputs_coords)
+        if dn.dn_number > 0 and dn_meta is not None:
+            outputs_class, outputs_coord = dn_post_process(outputs_class, outputs_coord, dn_meta, self.aux_loss,
+                                                           self._set_aux_loss)
+        if not self.training:
+            return self._inference(outputs_class, outputs_coord)
+        losses = {}
+        # encoder proposal losses (class-agnostic), voxel_detr.py:198-209
+        enc_class, enc_coords = self.transformer.proposal_head(src_embed, src_ref_windows)
+        bin_targets = copy.deepcopy(targets)
+        for tgt in bin_targets:
+            tgt["labels"].fill_(0)
+        enc_outputs = {"topk_indexes": src_indexes, "pred_logits": enc_class, "pred_boxes": enc_coords}
+        enc_losses = self.transformer.proposal_head.compute_losses(enc_outputs, bin_targets)
+        losses.update({k + "_enc": v for k, v in enc_losses.items()})
+        nq = self.num_queries
+        outputs = {"pred_logits": outputs_class[-1][:, :nq], "pred_boxes": outputs_coord[-1][:, :nq],
+                   "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
+        losses.update(head.compute_losses(outputs, targets, dn_meta))
+        losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_indices"], targets,
+                                               dn_meta))
+        return losses
+
+    def _contrastive_losses(self, outputs_class, outputs_coord, matched, targets, dn_meta):
+        """voxel_detr.py:223-254 in batched form.  For decoder layer li and scene bi, every matched
+        (query p, gt g) contributes mean over the G positive-noised GT copies r = g + max_gt*pi of
+        log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau."""
+        out = {}
+        per_gt = [t["gt_boxes"].shape[0] for t in targets]
+        max_gt, num_gts = max(per_gt), sum(per_gt)
+        if num_gts == 0 or dn_meta is None:
+            return out
+        nq, groups = self.num_queries, dn_meta["num_dn_group"]
+        dev = outputs_class.device
+        pis = torch.arange(1, groups + 1, device=dev) * max_gt
+        for li in range(self.config.model.transformer.dec_layers):
+            projs = torch.cat((outputs_class[li], outputs_coord[li]), dim=-1)
+            gt_projs = self.projector(projs[:, nq:].detach())
+            pred_projs = self.predictor(self.projector(projs[:, :nq]))
+            total = projs.new_zeros(())
+            for bi, (qi, gi) in enumerate(matched):
+                if qi.numel() == 0:
+                    continue
+                qi, gi = qi.to(dev), gi.to(dev)
+                rows = (gi[:, None] + pis[None, :]).reshape(-1)                      # [n*G]
+                sim = self.similarity_f(gt_projs[bi][rows].unsqueeze(1), pred_projs[bi].unsqueeze(0)) / self.tau
+                sim = sim.view(qi.numel(), groups, nq)                               # [n, G, Q]
+                neg_mask = torch.ones(nq, dtype=torch.bool, device=dev)
+                neg_mask[qi] = False
+                pos = sim.gather(2, qi[:, None, None].expand(-1, groups, 1))         # [n, G, 1]
+                neg = (torch.exp(sim) * neg_mask).sum(dim=-1, keepdim=True)
+                total = total + (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(1, 2)).sum()
+            out[f"loss_contrastive_dec_{li}"] = self.contras_loss_coeff * total / num_gts
+        return out
+
+    def _inference(self, outputs_class, outputs_coord):
+        """voxel_detr.py:257-284: keep every (query, class) with score >= 0.1 (batch 1)."""
+        out_logits = outputs_class[-1][:, : self.num_queries]
+        out_bbox = outputs_coord[-1][:, : self.num_queries]
+        out_prob = out_logits.sigmoid().view(out_logits.shape[0], -1)
+        out_bbox = self.box_coder.decode(out_bbox.clone())
+        keep = torch.nonzero(out_prob >= 0.1, as_tuple=True)[1]
+        scores = out_prob[:, keep]
+        ncls = out_logits.shape[2]
+        box_idx = keep.view(1, -1).div(ncls, rounding_mode="floor")
+        labels = keep.view(1, -1) % ncls + 1
+        boxes = torch.gather(out_bbox, 1, box_idx.unsqueeze(-1).repeat(1, 1, out_bbox.shape[-1]))
+        return [{"scores": s.detach().cpu(), "labels": l.detach().cpu(), "boxes3d": b.detach().cpu()}
+                for s, l, b in zip(scores, labels, boxes)]
+
+    @staticmethod
+    def _set_aux_loss(outputs_class, outputs_coord):
+        return [{"pred_logits": a, "pred_boxes": b} for a, b in zip(outputs_class, outputs_coord)]

@@ -1,0 +1,75 @@
+"""Minimal training engine for the hot path: model + AdamWMulti + (optionally) DDP over RCCL.
+
+Counterpart of the slice of efg/engine/trainer.py:168-199,278-305 and efg/engine/hooks.py:68-81 that
+surrounds the path: `step()` = zero_grad -> loss_dict = model(batch) -> sum of differentiable losses
+-> backward (DDP all-reduces gradient buckets over xGMI while backward runs) -> optimizer.step().
+One process per GPU; scenes are sharded across ranks, no activation exchange."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .config import load_config
+from .data.synthetic import make_scene
+from .detection3d.optimizer import build_adamw_multi
+from .detection3d.voxel_detr import VoxelDETR
+
+DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                              "conquer_waymo_res18.yaml")
+
+
+def init_distributed():
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); backend "nccl" is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def synthetic_batch(seed_base, scenes, n_points=180000, n_sweeps=1, device=None, n_boxes=40):
+    """`scenes` (points on `device`, Waymo-style annotations) pairs in the model's input format."""
+    batch = []
+    for i in range(scenes):
+        pts, boxes, labels = make_scene(seed_base + i, n_points=n_points, n_sweeps=n_sweeps, n_boxes=n_boxes)
+        pts = torch.from_numpy(pts)
+        if device is not None:
+            pts = pts.to(device)
+        ann = {"gt_boxes": boxes, "labels": labels, "difficulty": np.zeros(len(labels), np.int64),
+               "num_points_in_gt": np.full(len(labels), 50, np.int64)}
+        batch.append(({"points": pts}, {"annotations": ann}))
+    return batch
+
+
+class Trainer:
+    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None):
+        cfg = load_config(config or DEFAULT_CONFIG, overrides)
+        if device is not None:
+            cfg.model.device = str(device)
+        torch.manual_seed(seed)
+        self.cfg = cfg
+        self.model = VoxelDETR(cfg)
+        self.model.train()
+        self.optimizer = build_adamw_multi(cfg, self.model)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        use_ddp = (world > 1) if ddp is None else ddp
+        self.wrapped = self.model
+        if use_ddp:
+            dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
+            self.wrapped = torch.nn.parallel.DistributedDataParallel(
+                self.model, device_ids=dev_ids, broadcast_buffers=False,
+                find_unused_parameters=cfg.ddp.find_unused_parameters, bucket_cap_mb=25)
+
+    def step(self, batch):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss_dict = self.wrapped(batch)
+        losses = sum(v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad)
+        losses.backward()
+        self.optimizer.step()
+        return loss_dict, losses

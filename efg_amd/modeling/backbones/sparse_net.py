@@ -1,0 +1,255 @@
+"""Sparse 3-D backbones over efg_amd.spconv (reference: efg/modeling/backbones/sparse_net.py).
+
+Module / parameter names, channel plans, strides, kernel geometry and the dense BEV output layout
+follow the reference so its state dicts load unchanged:
+  SparseBasicStem :79-103, SparseBasicResBlock :120-165, SparseResNet :239-316,
+  build_sparse_resnet_backbone :318-397, SparseBasicBlock :429-470, SpMiddleResNetFHD :473-545.
+"""
+import collections
+
+import numpy as np
+from torch import nn
+
+from .. import common
+from ... import spconv
+from ...spconv import SparseConv3d, SubMConv3d
+
+ShapeSpec = collections.namedtuple("ShapeSpec", ["channels", "height", "width", "stride"],
+                                   defaults=(None, None, None, None))
+
+
+class SparseBasicStem(spconv.SparseModule):
+    """SparseConv3d(k3,s2,p1) + 2 x SubMConv3d(k3), each followed by norm + activation (:85-95)."""
+
+    def __init__(self, in_channels=16, out_channels=32, stem_width=32, norm="BN1d", activation=None, indice_key=None):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv1 = spconv.SparseSequential(
+            SparseConv3d(in_channels, stem_width, 3, 2, padding=1, bias=False),
+            common.get_norm(norm, stem_width),
+            common.get_activation(activation),
+            SubMConv3d(stem_width, stem_width, 3, padding=1, bias=False, indice_key=indice_key),
+            common.get_norm(norm, stem_width),
+            common.get_activation(activation),
+            SubMConv3d(stem_width, out_channels, 3, padding=1, bias=False, indice_key=indice_key),
+            common.get_norm(norm, out_channels),
+            common.get_activation(activation),
+        )
+
+    def forward(self, x):
+        return self.conv1(x)
+
+    @property
+    def stride(self):
+        return 2
+
+
+class SparseBasicResBlock(spconv.SparseModule):
+    """Two 3x3x3 convs + identity / strided-conv shortcut (:120-165).  With stride 2 both the first
+    conv and the shortcut are regular SparseConv3d over the same input -> row-aligned outputs."""
+
+    def __init__(self, in_channels=32, out_channels=64, stride=1, norm="BN1d", activation=None, indice_key=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        if in_channels != out_channels:
+            self.shortcut = spconv.SparseSequential(
+                SparseConv3d(in_channels, out_channels, 3, padding=1, stride=stride, bias=False),
+                common.get_norm(norm, out_channels),
+            )
+        else:
+            self.shortcut = None
+        self.activation = common.get_activation(activation)
+        first = (SubMConv3d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=False,
+                            indice_key=indice_key) if stride == 1 else
+                 SparseConv3d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=False))
+        self.conv = spconv.SparseSequential(
+            first,
+            common.get_norm(norm, out_channels),
+            common.get_activation(activation),
+            SubMConv3d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False,
+                       indice_key=indice_key),
+            common.get_norm(norm, out_channels),
+        )
+
+    def forward(self, x):
+        out = self.conv(x)
+        shortcut = self.shortcut(x) if self.shortcut is not None else x
+        out = out.replace_feature(out.features + shortcut.features)
+        return out.replace_feature(self.activation(out.features))
+
+
+def make_stage(block_class, num_blocks, first_stride, **kwargs):
+    blocks = []
+    for i in range(num_blocks):
+        blocks.append(block_class(stride=first_stride if i == 0 else 1, **kwargs))
+        kwargs["in_channels"] = kwargs["out_channels"]
+    return blocks
+
+
+class SparseResNet(nn.Module):
+    """stem -> res2..resN; each requested feature gets a `<name>_out` head that collapses z with
+    SparseConv3d((3,1,1),(2,1,1),pad (1,0,0)) + norm + ReLU and is returned DENSE as
+    [B, C*D, H, W] (:273-282, :302-307).
+
+    `dense_features` (ours): restrict which `<name>_out` heads are actually evaluated.  The
+    ConQueR graph consumes only p3 (config.yaml:116), so `res2_out` (+ its 217 MB/scene dense
+    tensor) feeds nothing; skipping it changes no output and no gradient (SURVEY.md §7 "dead
+    compute").  Parameters stay in the state dict either way.
+    """
+
+    def __init__(self, stem, stages, out_channels=None, out_features=None, norm=None):
+        super().__init__()
+        self.stem = stem
+        self.out_channels = out_channels
+        current_stride = self.stem.stride
+        self._out_feature_strides = {"stem": current_stride}
+        self._out_feature_channels = {"stem": self.stem.out_channels}
+        self.stages_and_names = []
+        for i, blocks in enumerate(stages):
+            stage = spconv.SparseSequential(*blocks)
+            name = "res" + str(i + 2)
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            self._out_feature_strides[name] = current_stride = int(current_stride * np.prod([k.stride for k in blocks]))
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        if out_features is None:
+            out_features = [name]
+        self._out_features = list(out_features)
+        children = [x[0] for x in self.named_children()]
+        for out_feature in self._out_features:
+            assert out_feature in children, "Available children: {}".format(", ".join(children))
+        out_channels_multiplier = [6, 3, 2]  # D after the z-collapsing head at 41 -> 21 -> 11 -> 6 -> 3 (:273)
+        for idx, out_feature in enumerate(self._out_features):
+            channels = self._out_feature_channels[out_feature]
+            out_layer = spconv.SparseSequential(
+                SparseConv3d(channels, channels, (3, 1, 1), (2, 1, 1), padding=(1, 0, 0), bias=False),
+                common.get_norm(norm, channels),
+                nn.ReLU(),
+            )
+            self.add_module(out_feature + "_out", out_layer)
+            self._out_feature_channels[out_feature] *= out_channels_multiplier[idx]
+        self.dense_features = None  # None = all of out_features
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]  # (z+1, y, x), :285
+        coors = coors.int()
+        x = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
+        wanted = self._out_features if self.dense_features is None else [
+            f for f in self._out_features if f in self.dense_features]
+        outputs = {}
+        x = self.stem(x)
+        if "stem" in wanted:
+            outputs["stem"] = x
+        last = max((i for i, (_, n) in enumerate(self.stages_and_names) if n in wanted), default=-1)
+        for i, (stage, name) in enumerate(self.stages_and_names):
+            if i > last:
+                break
+            x = stage(x)
+            if name in wanted:
+                outputs[name] = x
+        for out_feature in wanted:
+            out = getattr(self, out_feature + "_out")(outputs[out_feature])
+            out = out.dense()
+            n, c, d, h, w = out.shape
+            outputs[out_feature] = out.view(n, c * d, h, w)
+        return outputs
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+
+def _get(cfg, key):
+    return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+
+
+def build_sparse_resnet_backbone(config, in_channels):
+    """res18 / res34 plans of efg/modeling/backbones/sparse_net.py:318-397 (basic blocks only: the
+    bottleneck variant (depth 50) is not used by any detection.3d config)."""
+    depth = _get(config, "depth")
+    stem_width = {18: 16, "18b": 24, "18c": 32, 34: 16, "34b": 24, "34c": 32}[depth]
+    norm, activation = _get(config, "norm"), _get(config, "activation")
+    stem = SparseBasicStem(in_channels=in_channels, out_channels=_get(config, "stem_out_channels"), norm=norm,
+                           activation=activation, stem_width=stem_width, indice_key="stem")
+    out_features = list(_get(config, "out_features"))
+    in_channels = _get(config, "stem_out_channels")
+    out_channels = _get(config, "res1_out_channels")
+    num_blocks_per_stage = {18: [2, 2, 2, 2], "18b": [2, 2, 2, 2], "18c": [2, 2, 2, 2], 34: [3, 4, 6, 3],
+                            "34b": [3, 4, 6, 3], "34c": [3, 4, 6, 3]}[depth]
+    max_stage_idx = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
+    stages = []
+    for idx, stage_idx in enumerate(range(2, max_stage_idx + 1)):
+        blocks = make_stage(SparseBasicResBlock, num_blocks_per_stage[idx], 2, in_channels=in_channels,
+                            out_channels=out_channels, norm=norm, activation=activation,
+                            indice_key="res" + str(stage_idx))
+        in_channels = out_channels
+        out_channels *= 2
+        stages.append(blocks)
+    return SparseResNet(stem, stages, out_features=out_features, norm=norm)
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    """CenterPoint residual block: 2 x SubMConv3d(k3) sharing `indice_key` (:429-470)."""
+
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm="BN1d", downsample=None, indice_key=None):
+        super().__init__()
+        bias = norm is not None
+        self.conv1 = SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=bias,
+                                indice_key=indice_key)
+        self.bn1 = common.get_norm(norm, planes)
+        self.relu = nn.ReLU()
+        self.conv2 = SubMConv3d(planes, planes, kernel_size=3, stride=1, padding=1, bias=bias, indice_key=indice_key)
+        self.bn2 = common.get_norm(norm, planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.conv1(x)
+        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = self.conv2(out)
+        out = out.replace_feature(self.bn2(out.features))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = out.replace_feature(out.features + identity.features)
+        return out.replace_feature(self.relu(out.features))
+
+
+class SpMiddleResNetFHD(nn.Module):
+    """CenterPoint middle encoder (:473-545): SubM stem, 4 levels of 2 residual blocks joined by
+    strided SparseConv3d, z-collapsing `extra_conv`, dense [B, 128*D, H, W] output."""
+
+    def __init__(self, num_input_features=128, out_features=("res3",), norm="BN1d"):
+        super().__init__()
+        self.conv_input = spconv.SparseSequential(
+            SubMConv3d(num_input_features, 16, 3, bias=False, indice_key="res0"),
+            common.get_norm(norm, 16), nn.ReLU(inplace=True))
+        self.conv1 = spconv.SparseSequential(
+            SparseBasicBlock(16, 16, norm=norm, indice_key="res0"),
+            SparseBasicBlock(16, 16, norm=norm, indice_key="res0"))
+        self.conv2 = spconv.SparseSequential(
+            SparseConv3d(16, 32, 3, 2, padding=1, bias=False), common.get_norm(norm, 32), nn.ReLU(inplace=True),
+            SparseBasicBlock(32, 32, norm=norm, indice_key="res1"),
+            SparseBasicBlock(32, 32, norm=norm, indice_key="res1"))
+        self.conv3 = spconv.SparseSequential(
+            SparseConv3d(32, 64, 3, 2, padding=1, bias=False), common.get_norm(norm, 64), nn.ReLU(inplace=True),
+            SparseBasicBlock(64, 64, norm=norm, indice_key="res2"),
+            SparseBasicBlock(64, 64, norm=norm, indice_key="res2"))
+        self.conv4 = spconv.SparseSequential(
+            SparseConv3d(64, 128, 3, 2, padding=[0, 1, 1], bias=False), common.get_norm(norm, 128),
+            nn.ReLU(inplace=True),
+            SparseBasicBlock(128, 128, norm=norm, indice_key="res3"),
+            SparseBasicBlock(128, 128, norm=norm, indice_key="res3"))
+        self.extra_conv = spconv.SparseSequential(
+            SparseConv3d(128, 128, (3, 1, 1), (2, 1, 1), bias=False), common.get_norm(norm, 128), nn.ReLU())
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        ret = spconv.SparseConvTensor(voxel_features, coors.int(), sparse_shape.tolist(), batch_size)
+        x = self.conv_input(ret)
+        x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
+        ret = self.extra_conv(x).dense()
+        n, c, d, h, w = ret.shape
+        return ret.view(n, c * d, h, w)

@@ -1,0 +1,54 @@
+"""Norm / activation factories and the Conv2d(+norm) wrapper (efg/modeling/common/batch_norm.py:140-188,
+efg/modeling/common/blocks.py:45-100).  Dense ops stay on PyTorch-ROCm (MIOpen / hipBLASLt)."""
+import torch
+from torch import nn
+
+
+def get_norm(norm, out_channels):
+    """efg/modeling/common/batch_norm.py:140-168.  "BN" / "BN1d" / "GN" (32 groups); "" -> None."""
+    args = None
+    if isinstance(norm, (list, tuple)):
+        norm, args = norm
+    if isinstance(norm, str):
+        if len(norm) == 0:
+            return None
+        norm = {
+            "BN": nn.BatchNorm2d,
+            "BN1d": nn.BatchNorm1d,
+            "GN": lambda channels: nn.GroupNorm(32, channels),
+            "nnSyncBN": nn.SyncBatchNorm,
+        }[norm]
+    return norm(out_channels, **args) if args else norm(out_channels)
+
+
+def get_activation(activation):
+    """efg/modeling/common/batch_norm.py:171-188: {type: ReLU|ReLU6, inplace: bool} or None."""
+    if activation is None:
+        return None
+    atype = activation["type"] if isinstance(activation, dict) else activation.type
+    inplace = activation["inplace"] if isinstance(activation, dict) else activation.inplace
+    return {"ReLU": nn.ReLU, "ReLU6": nn.ReLU6}[atype](inplace=inplace)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d followed by an optional norm and activation (efg/modeling/common/blocks.py:45-100)."""
+
+    def __init__(self, *args, norm=None, activation=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = super().forward(x)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def c2_xavier_fill(module):
+    """efg/modeling/common/weight_init.py:52-64 (Caffe2 XavierFill == kaiming_uniform_(a=1))."""
+    nn.init.kaiming_uniform_(module.weight, a=1)
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
