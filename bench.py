@@ -1,0 +1,104 @@
+"""Benchmark of the hot path: ConQueR / Voxel-DETR single-frame Waymo TRAINING STEP on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = voxelize (GPU) -> sparse-conv backbone -> BEV/FPN -> box-attention DETR enc/dec -> losses ->
+backward -> (DDP all-reduce over RCCL) -> AdamW, on `--scenes` synthetic Waymo-shaped scenes per GPU
+that are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (configs[1]: batch 2; configs[2]: 16 / 8 GPUs)")
+    ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--queries", type=int, default=1000, help="reference YAML default (configs[2] names 900)")
+    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-graph", action="store_true", help="also evaluate the unused FPN levels like the reference")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from efg_amd import _prof
+    from efg_amd.engine import Trainer, init_distributed, synthetic_batch
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    overrides = {"model.transformer.num_queries": args.queries}
+    if args.full_graph:
+        overrides["model.eval_unused_levels"] = True
+    trainer = Trainer(device=dev, overrides=overrides, seed=0)
+    # rank-sharded scenes: scene ids are disjoint across ranks (weak scaling: fixed per-GPU work)
+    pool = [synthetic_batch(2000 + 100 * p + rank * args.scenes, args.scenes, n_points=args.points, device=dev)
+            for p in range(args.pool)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        trainer.step(pool[w % len(pool)])
+    barrier()
+    _prof.enable(True)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        trainer.step(pool[s % len(pool)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _prof.enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scenes_total = args.scenes * world * args.steps
+    line = {
+        "metric": "scenes/sec ConQueR 1-frame Waymo train step",
+        "value": scenes_total / elapsed,
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "ConQueR/Voxel-DETR res18 p3, 1-frame Waymo-shaped scenes, %d pts/scene, 0.1 m voxels, "
+                        "%d scenes/GPU, %d queries, fwd+bwd+AdamW%s" % (args.points, args.scenes, args.queries,
+                                                                     ", full reference graph" if args.full_graph
+                                                                     else ", unused FPN levels not evaluated"),
+            "global_batch": args.scenes * world,
+            "parallelism": "dp%d" % world,
+        },
+    }
+    if rank == 0:
+        line["roofline"] = _prof.roofline()
+        if not args.no_cpu_baseline and world == 1:
+            pass
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

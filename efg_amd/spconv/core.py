@@ -19,6 +19,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from .. import _prof
 
 
 def _triple(v):
@@ -51,12 +52,91 @@ class SiteIndex:
 
     @classmethod
     def from_indices(cls, indices, batch_size, spatial_shape, canonical=False):
-        lib, shp, index, ws, ws_bytes = cls._alloc(batch_size, spatial_shape, indices.device)
-        m = indices.shape[0]
-        perm = None if canonical else torch.empty(max(m, 1), dtype=torch.int32, device=indices.device)
-        L.check(lib.efg_spconv_index_from_indices(L.ptr(indices), m, batch_size, shp, L.ptr(index), L.ptr(perm),
-                                                  L.ptr(ws), ws_bytes, L.stream()))
-        return cls(index, perm, batch_size, spatial_shape)
+        return _site_index_from_indices(indices, batch_size, spatial_shape, canonical)
+
+
+# ---- the only functions of this module that touch libefg_hip.so --------------------------------
+def _site_index_from_indices(indices, batch_size, spatial_shape, canonical=False):
+    lib, shp, index, ws, ws_bytes = SiteIndex._alloc(batch_size, spatial_shape, indices.device)
+    m = indices.shape[0]
+    perm = None if canonical else torch.empty(max(m, 1), dtype=torch.int32, device=indices.device)
+    L.check(lib.efg_spconv_index_from_indices(L.ptr(indices), m, batch_size, shp, L.ptr(index), L.ptr(perm),
+                                              L.ptr(ws), ws_bytes, L.stream()))
+    return SiteIndex(index, perm, batch_size, spatial_shape)
+
+
+def _build_rnbr(nbr, m_out, kvol, m_in):
+    r = torch.empty((kvol, max(m_in, 1)), dtype=torch.int32, device=nbr.device)
+    L.check(L.lib().efg_spconv_build_rnbr(L.ptr(nbr), m_out, kvol, m_in, L.ptr(r), L.stream()))
+    return (r[:, :m_in] if m_in > 0 else r[:, :0]).contiguous()
+
+
+def _conv_forward(features, w, bias, rb):
+    """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
+    lib = L.lib()
+    cout, kvol, cin = w.shape
+    packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
+                         device=features.device)
+    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
+    out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
+    with _prof.timed("spconv_fwd", *_conv_cost(rb, cin, cout)):
+        L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
+                                           L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
+    return out
+
+
+def _conv_dgrad(grad_out, w, rb):
+    lib = L.lib()
+    cout, kvol, cin = w.shape
+    packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8,
+                         device=grad_out.device)
+    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
+    grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
+    rnbr = rb.rnbr
+    with _prof.timed("spconv_dgrad", *_conv_cost(rb, cin, cout)):
+        L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
+                                         rb.m_in, L.ptr(grad_in), L.stream()))
+    return grad_in
+
+
+def _conv_wgrad(features, grad_out, rb):
+    lib = L.lib()
+    cin, cout, kvol = features.shape[1], grad_out.shape[1], rb.kvol
+    ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
+    grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
+    with _prof.timed("spconv_wgrad", *_conv_cost(rb, cin, cout)):
+        L.check(lib.efg_spconv_wgrad_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
+                                         L.ptr(rb.nbr), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
+    return grad_w
+
+
+def _conv_cost(rb, cin, cout):
+    """Algorithmic (bytes, flops) of one sparse-conv launch, SURVEY.md §8(d):
+    4*Cin*M_in + 4*Cout*M_out + 4*K*Cin*Cout + 8*pairs bytes, 2*pairs*Cin*Cout flops."""
+    if not _prof.active("spconv_fwd") and not _prof.active("spconv_dgrad") and not _prof.active("spconv_wgrad"):
+        return 0, 0
+    pairs = rb.num_pairs()
+    return (4 * cin * rb.m_in + 4 * cout * rb.m_out + 4 * rb.kvol * cin * cout + 8 * pairs,
+            2 * pairs * cin * cout)
+
+
+def _to_dense(features, x):
+    si = x.site_index()
+    c = features.shape[1]
+    d, h, w = x.spatial_shape
+    dense = torch.empty((x.batch_size, c, d, h, w), dtype=torch.float32, device=features.device)
+    L.check(L.lib().efg_sparse_to_dense_f32(L.ptr(features), c, L.ptr(si.index), L.ptr(si.perm), x.batch_size,
+                                            L.host_i32(x.spatial_shape, 3), L.ptr(dense), L.stream()))
+    return dense
+
+
+def _from_dense(grad_dense, x):
+    m, c = x.indices.shape[0], grad_dense.shape[1]
+    g = torch.empty((m, c), dtype=torch.float32, device=grad_dense.device)
+    L.check(L.lib().efg_dense_to_sparse_f32(L.ptr(grad_dense), c, L.ptr(x.indices), m, x.batch_size,
+                                            L.host_i32(x.spatial_shape, 3), L.ptr(g), L.stream()))
+    return g
 
 
 class Rulebook:
@@ -66,6 +146,7 @@ class Rulebook:
         self.nbr = nbr          # int32 [kvol, m_out]
         self.m_in, self.m_out, self.kvol, self.subm = m_in, m_out, kvol, subm
         self._rnbr = None
+        self._pairs = None
 
     @property
     def rnbr(self):
@@ -74,12 +155,14 @@ class Rulebook:
             if self.subm:
                 self._rnbr = self.nbr.flip(0).contiguous()  # symmetric window: rnbr[k] = nbr[kvol-1-k]
             else:
-                r = torch.empty((self.kvol, max(self.m_in, 1)), dtype=torch.int32, device=self.nbr.device)
-                L.check(L.lib().efg_spconv_build_rnbr(L.ptr(self.nbr), self.m_out, self.kvol, self.m_in, L.ptr(r),
-                                                      L.stream()))
-                self._rnbr = r[:, : self.m_in] if self.m_in > 0 else r[:, :0]
-                self._rnbr = self._rnbr.contiguous()
+                self._rnbr = _build_rnbr(self.nbr, self.m_out, self.kvol, self.m_in)
         return self._rnbr
+
+    def num_pairs(self):
+        """Number of (input, output) pairs (one host read, cached; used only for roofline accounting)."""
+        if self._pairs is None:
+            self._pairs = int((self.nbr >= 0).sum().item())
+        return self._pairs
 
 
 class SparseConvTensor:
@@ -125,26 +208,13 @@ class SparseConvTensor:
 class _ToDense(Function):
     @staticmethod
     def forward(ctx, features, x):
-        si = x.site_index()
-        features = features.contiguous()
-        c = features.shape[1]
-        d, h, w = x.spatial_shape
-        dense = torch.empty((x.batch_size, c, d, h, w), dtype=torch.float32, device=features.device)
-        L.check(L.lib().efg_sparse_to_dense_f32(L.ptr(features), c, L.ptr(si.index), L.ptr(si.perm), x.batch_size,
-                                                L.host_i32(x.spatial_shape, 3), L.ptr(dense), L.stream()))
         ctx.x = x
-        return dense
+        return _to_dense(features.contiguous(), x)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_dense):
-        x = ctx.x
-        grad_dense = grad_dense.contiguous()
-        m, c = x.indices.shape[0], grad_dense.shape[1]
-        g = torch.empty((m, c), dtype=torch.float32, device=grad_dense.device)
-        L.check(L.lib().efg_dense_to_sparse_f32(L.ptr(grad_dense), c, L.ptr(x.indices), m, x.batch_size,
-                                                L.host_i32(x.spatial_shape, 3), L.ptr(g), L.stream()))
-        return g, None
+        return _from_dense(grad_dense.contiguous(), ctx.x), None
 
 
 class _SparseConvFunction(Function):
@@ -152,17 +222,10 @@ class _SparseConvFunction(Function):
 
     @staticmethod
     def forward(ctx, features, weight, bias, rb):
-        lib = L.lib()
         features = features.contiguous()
         cout, cin = weight.shape[0], weight.shape[-1]
-        kvol = rb.kvol
-        w = weight.reshape(cout, kvol, cin).contiguous()
-        packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
-                             device=features.device)
-        L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
-        out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-        L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
-                                           L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
+        w = weight.reshape(cout, rb.kvol, cin).contiguous()
+        out = _conv_forward(features, w, bias, rb)
         ctx.save_for_backward(features, w)
         ctx.rb = rb
         ctx.has_bias = bias is not None
@@ -172,29 +235,42 @@ class _SparseConvFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        lib = L.lib()
         features, w = ctx.saved_tensors
         rb = ctx.rb
         grad_out = grad_out.contiguous()
-        cout, kvol, cin = w.shape
-        dev = grad_out.device
         grad_in = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
-            packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8, device=dev)
-            L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
-            grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=dev)
-            L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol,
-                                             L.ptr(rb.rnbr), rb.m_in, L.ptr(grad_in), L.stream()))
+            grad_in = _conv_dgrad(grad_out, w, rb)
         if ctx.needs_input_grad[1]:
-            ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=dev)
-            L.check(lib.efg_spconv_wgrad_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
-                                             L.ptr(rb.nbr), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
-            grad_w = grad_w.view(ctx.wshape)
+            grad_w = _conv_wgrad(features, grad_out, rb).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = grad_out.sum(0)
         return grad_in, grad_w, grad_b, None
+
+
+def _downsample_geometry(x, ks, st, pad):
+    """Output sites of a strided SparseConv3d over x: (out_indices [m_out,4] canonical order, SiteIndex, shape)."""
+    lib = L.lib()
+    dev = x.indices.device
+    out_shape = (L.ctypes.c_int * 3)()
+    in_shape = L.host_i32(x.spatial_shape, 3)
+    oshape_py = [(x.spatial_shape[a] + 2 * pad[a] - ks[a]) // st[a] + 1 for a in range(3)]
+    oshp = L.host_i32(oshape_py, 3)
+    nbytes = lib.efg_spconv_index_bytes(x.batch_size, oshp)
+    ws_bytes = lib.efg_spconv_index_workspace_bytes(x.batch_size, oshp)
+    if nbytes == 0:
+        raise RuntimeError("efg_hip: " + lib.efg_last_error().decode())
+    oindex = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    m_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.efg_spconv_index_downsample(L.ptr(x.indices), x.indices.shape[0], x.batch_size, in_shape,
+                                            L.host_i32(ks, 3), L.host_i32(st, 3), L.host_i32(pad, 3),
+                                            L.ptr(oindex), out_shape, L.ptr(m_out_dev), L.ptr(ws), ws_bytes,
+                                            L.stream()))
+    m_out = int(m_out_dev.item())  # sizes every downstream tensor of this level (one sync per level)
+    out_indices = torch.empty((max(m_out, 1), 4), dtype=torch.int32, device=dev)
+    L.check(lib.efg_spconv_index_emit(L.ptr(oindex), x.batch_size, oshp, L.ptr(out_indices), L.stream()))
+    return out_indices[:m_out], SiteIndex(oindex, None, x.batch_size, oshape_py), oshape_py
 
 
 def _build_nbr(si_in, out_indices, m_out, ksize, stride, padding):
@@ -299,30 +375,11 @@ class SparseConvolution(SparseModule):
         key = ("conv", ks, st, pad)
         if key in x._conv_cache:  # main and shortcut convs of a block share one geometry
             return x._conv_cache[key]
-        lib = L.lib()
-        dev = x.indices.device
-        out_shape = (L.ctypes.c_int * 3)()
-        in_shape = L.host_i32(x.spatial_shape, 3)
-        oshape_py = [(x.spatial_shape[a] + 2 * pad[a] - ks[a]) // st[a] + 1 for a in range(3)]
-        oshp = L.host_i32(oshape_py, 3)
-        nbytes = lib.efg_spconv_index_bytes(x.batch_size, oshp)
-        ws_bytes = lib.efg_spconv_index_workspace_bytes(x.batch_size, oshp)
-        if nbytes == 0:
-            raise RuntimeError("efg_hip: " + lib.efg_last_error().decode())
-        oindex = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        m_out_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.check(lib.efg_spconv_index_downsample(L.ptr(x.indices), x.indices.shape[0], x.batch_size, in_shape,
-                                                L.host_i32(ks, 3), L.host_i32(st, 3), L.host_i32(pad, 3),
-                                                L.ptr(oindex), out_shape, L.ptr(m_out_dev), L.ptr(ws), ws_bytes,
-                                                L.stream()))
-        m_out = int(m_out_dev.item())  # sizes every downstream tensor of this level (one sync per level)
-        out_indices = torch.empty((max(m_out, 1), 4), dtype=torch.int32, device=dev)
-        L.check(lib.efg_spconv_index_emit(L.ptr(oindex), x.batch_size, oshp, L.ptr(out_indices), L.stream()))
-        out_indices = out_indices[:m_out]
+        out_indices, out_site_index, oshape_py = _downsample_geometry(x, ks, st, pad)
+        m_out = out_indices.shape[0]
         nbr = _build_nbr(x.site_index(), out_indices, m_out, ks, st, pad)
         rb = Rulebook(nbr, x.indices.shape[0], m_out, nbr.shape[0], False)
-        geom = (out_indices, SiteIndex(oindex, None, x.batch_size, oshape_py), oshape_py)
+        geom = (out_indices, out_site_index, oshape_py)
         x._conv_cache[key] = (rb, geom)
         return rb, geom
 
