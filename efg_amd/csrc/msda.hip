@@ -166,6 +166,132 @@ msda_kernel(const float* __restrict__ value, const long long* __restrict__ shape
   if (!kBackward && active) *reinterpret_cast<float4*>(out + tt * dm.d + c0) = acc;
 }
 
+// ---- backward, grid-structured queries (encoder self-attention) -------------------------------
+// When queries live on the value map itself (one level, Lq == H*W: box self-attention over the BEV
+// tokens), query q at (qy,qx) samples a small box around itself, so the 4*P corner updates of
+// neighbouring queries pile onto the same few cells: with global atomics that is ~10^9 contended
+// L2 atomics per layer.  Here a workgroup owns a TQ x TQ tile of queries of ONE head and
+// accumulates grad_value for the (TQ+2R)^2 window around the tile in LDS (fp64, ds_add_f64), then flushes
+// the window once with global atomics (windows of neighbouring tiles overlap).  Corners that fall
+// outside the window still go straight to global memory, so the result never depends on where the
+// samples land -- only the speed does.
+template <int D>
+__global__ void __launch_bounds__(256)
+msda_bwd_grid_kernel(const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+                     const float* __restrict__ grad_out, const long long* __restrict__ shapes, int nb, int nh,
+                     long long s_total, int np, float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                     float* __restrict__ grad_attn) {
+  constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R, LP = D / 4;
+  // the map shape lives on the device (int64 [1,2]); the grid is an upper bound over all H x W = S
+  const int Hm = (int)shapes[0], Wm = (int)shapes[1];
+  if ((long long)Hm * Wm != s_total) return;  // host dispatch guarantees this; defensive
+  if ((int)blockIdx.x >= ((Hm + TQ - 1) / TQ) * ((Wm + TQ - 1) / TQ)) return;
+  constexpr int SLOTS = 256 / LP;            // (query, head) pairs in flight per pass
+  constexpr int PASSES = TQ * TQ / SLOTS;
+  // fp64 accumulators: ds_add_f64 is native on gfx950 (3.1 lane-ops/clk/CU measured) while ds_add_f32
+  // runs at 0.33 -- a 10x slower path (scripts/ubench/lds_atomics.hip)
+  __shared__ double win[WIN * WIN * D];
+  const int tiles_x = (Wm + TQ - 1) / TQ;
+  const int ty0 = (blockIdx.x / tiles_x) * TQ, tx0 = (blockIdx.x % tiles_x) * TQ;
+  const int wy0 = ty0 - R, wx0 = tx0 - R;
+  const int m = blockIdx.y, bi = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int sub = threadIdx.x % LP;          // float4 group of this lane
+  const int slot = threadIdx.x / LP;
+  const int c0 = sub * 4;
+  const int rot = (slot + sub) & 3;          // spreads the 4 ds_add of a lane over the bank residues
+  const long long S = (long long)Hm * Wm;
+  const int row_stride = nh * D;
+  for (int i = threadIdx.x; i < WIN * WIN * D; i += 256) win[i] = 0.0;
+  __syncthreads();
+  const float* v = value + ((long long)bi * S * nh + m) * D + c0;
+  float* gv = grad_value + ((long long)bi * S * nh + m) * D + c0;
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int qi = pass * SLOTS + slot;
+    const int qy = ty0 + qi / TQ, qx = tx0 + qi % TQ;
+    const bool active = qy < Hm && qx < Wm;
+    const long long t = active ? (((long long)bi * S + (long long)qy * Wm + qx) * nh + m) : 0;
+    float4 top = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) top = ld4(grad_out + t * D + c0);
+    const float* lw = loc + t * np * 2;
+    const float* aw = attn + t * np;
+    for (int pi = 0; pi < np; ++pi) {
+      const float loc_w = lw[pi * 2], loc_h = lw[pi * 2 + 1];
+      const float wgt = aw[pi];
+      const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)Hm), 0.5f);
+      const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)Wm), 0.5f);
+      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
+      float ga = 0.f, gw = 0.f, gh = 0.f;
+      if (inside && active) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lwf;
+        const float wc[4] = {hh * hw, hh * lwf, lh * hw, lh * lwf};
+        const float4 tv = make_float4(top.x * wgt, top.y * wgt, top.z * wgt, top.w * wgt);
+        float4 vv[4];
+#pragma unroll
+        for (int cn = 0; cn < 4; ++cn) {
+          const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
+          const bool ok = cy >= 0 && cy <= Hm - 1 && cx >= 0 && cx <= Wm - 1;
+          vv[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
+            const long long o = ((long long)cy * Wm + cx) * row_stride;
+            vv[cn] = ld4(v + o);
+            const float g[4] = {wc[cn] * tv.x, wc[cn] * tv.y, wc[cn] * tv.z, wc[cn] * tv.w};
+            const int ly = cy - wy0, lx = cx - wx0;
+            if ((unsigned)ly < (unsigned)WIN && (unsigned)lx < (unsigned)WIN) {
+              double* wp = win + (ly * WIN + lx) * D + c0;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int jj = (j + rot) & 3;
+                atomicAdd(wp + jj, (double)g[jj]);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gv + o + j, g[j]);
+            }
+          }
+        }
+        float4 val;
+        val.x = bil(wc[0], wc[1], wc[2], wc[3], vv[0].x, vv[1].x, vv[2].x, vv[3].x);
+        val.y = bil(wc[0], wc[1], wc[2], wc[3], vv[0].y, vv[1].y, vv[2].y, vv[3].y);
+        val.z = bil(wc[0], wc[1], wc[2], wc[3], vv[0].z, vv[1].z, vv[2].z, vv[3].z);
+        val.w = bil(wc[0], wc[1], wc[2], wc[3], vv[0].w, vv[1].w, vv[2].w, vv[3].w);
+        ga = fmaf(top.w, val.w, fmaf(top.z, val.z, fmaf(top.y, val.y, top.x * val.x)));
+        const float gwx = fmaf(hh, vv[1].x - vv[0].x, lh * (vv[3].x - vv[2].x)), ghx = fmaf(hw, vv[2].x - vv[0].x, lwf * (vv[3].x - vv[1].x));
+        const float gwy = fmaf(hh, vv[1].y - vv[0].y, lh * (vv[3].y - vv[2].y)), ghy = fmaf(hw, vv[2].y - vv[0].y, lwf * (vv[3].y - vv[1].y));
+        const float gwz = fmaf(hh, vv[1].z - vv[0].z, lh * (vv[3].z - vv[2].z)), ghz = fmaf(hw, vv[2].z - vv[0].z, lwf * (vv[3].z - vv[1].z));
+        const float gww = fmaf(hh, vv[1].w - vv[0].w, lh * (vv[3].w - vv[2].w)), ghw = fmaf(hw, vv[2].w - vv[0].w, lwf * (vv[3].w - vv[1].w));
+        gw = (float)Wm * fmaf(gww, tv.w, fmaf(gwz, tv.z, fmaf(gwy, tv.y, gwx * tv.x)));
+        gh = (float)Hm * fmaf(ghw, tv.w, fmaf(ghz, tv.z, fmaf(ghy, tv.y, ghx * tv.x)));
+      }
+#pragma unroll
+      for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) {
+        ga += __shfl_xor(ga, dlt, 64);
+        gw += __shfl_xor(gw, dlt, 64);
+        gh += __shfl_xor(gh, dlt, 64);
+      }
+      if (active && sub == 0) {
+        grad_attn[t * np + pi] = ga;
+        grad_loc[(t * np + pi) * 2] = gw;
+        grad_loc[(t * np + pi) * 2 + 1] = gh;
+      }
+    }
+  }
+  (void)lane;
+  __syncthreads();
+  // flush the window: one thread per (cell, channel); skip untouched entries
+  for (int i = threadIdx.x; i < WIN * WIN * D; i += 256) {
+    const float g = (float)win[i];
+    if (g != 0.0f) {
+      const int cell = i / D, ch = i % D;
+      const int cy = wy0 + cell / WIN, cx = wx0 + cell % WIN;
+      if (cy >= 0 && cy < Hm && cx >= 0 && cx < Wm)
+        unsafeAtomicAdd(grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * nh + m) * D + ch, g);
+    }
+  }
+}
+
 int check_dims(int b, int s, int h, int d, int l, int lq, int p, MsdaDims* dm) {
   EFG_CHECK_ARG(b >= 0 && s >= 0 && h >= 1 && l >= 1 && lq >= 0 && p >= 1, "msda: bad dimensions");
   EFG_CHECK_ARG(d >= 4 && d % 4 == 0 && d <= 256, "msda: head dim must be a multiple of 4 in [4,256], got %d", d);
@@ -208,6 +334,17 @@ extern "C" int efg_msda_backward_f32(const float* value, const int64_t* shapes, 
   if (int rc = check_dims(b, s, h, d, l, lq, p, &dm)) return rc;
   const long long total = (long long)b * lq * h;
   if (total == 0) return EFG_OK;
+  if (l == 1 && d == 32 && s == lq && s >= 1024 && h <= 65535 && b <= 65535) {
+    // queries on the value grid (encoder self-attention): LDS-window accumulation.  H and W are
+    // device-side (int64), so the launch covers the largest tile count any H x W = S can have
+    // (<= S/64 + (S+1)/8 + 2) and surplus workgroups exit at once: no host sync.
+    const unsigned tiles_ub = (unsigned)(s / 64 + (s + 1) / 8 + 2);
+    hipLaunchKernelGGL((msda_bwd_grid_kernel<32>), dim3(tiles_ub, h, b), dim3(256), 0, (hipStream_t)stream, value, loc,
+                       attn, grad_out, (const long long*)shapes, b, h, (long long)s, p, grad_value, grad_loc,
+                       grad_attn);
+    EFG_LAUNCH_CHECK();
+    return EFG_OK;
+  }
   const int pairs_per_block = 4 * (64 / dm.lp);
   const unsigned blocks = (unsigned)ceil_div(total, pairs_per_block);
   hipLaunchKernelGGL((msda_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, value,

@@ -210,6 +210,56 @@ from_dense_kernel(const float* __restrict__ gd, int c, const int* __restrict__ i
   }
 }
 
+
+// BEV flatten fused with densify: out[b][y][x][c*D + d] = feat[row(b,d,y,x)][c] (0 if inactive), i.e.
+// SparseConvTensor.dense() -> view(N, C*D, H, W) of the reference (sparse_net.py:304-306) written
+// directly in channels-last (NHWC) order, the layout the transformer consumes ([B, H*W, C] tokens).
+// One workgroup = 8 consecutive BEV pixels; writes are fully coalesced runs of C*D floats.
+constexpr int kBevPix = 8;
+constexpr int kBevMaxD = 16;
+__global__ void __launch_bounds__(256)
+to_bev_kernel(const float* __restrict__ feat, int c, const uint2* __restrict__ idx, const int* __restrict__ perm,
+              Grid3 g, float* __restrict__ out) {
+  __shared__ int rows[kBevPix][kBevMaxD];
+  const long long hw = (long long)g.h * g.w;
+  const long long npix = (long long)g.b * hw;
+  const long long p0 = (long long)blockIdx.x * kBevPix;
+  const int cd = c * g.d;
+  if (threadIdx.x < kBevPix * g.d) {
+    const int pix = threadIdx.x / g.d, d = threadIdx.x % g.d;
+    int r = -1;
+    if (p0 + pix < npix) {
+      const long long b = (p0 + pix) / hw, yx = (p0 + pix) % hw;
+      r = rank_lookup(idx, ((unsigned long long)b * g.d + d) * hw + yx);
+      if (r >= 0 && perm) r = perm[r];
+    }
+    rows[pix][d] = r;
+  }
+  __syncthreads();
+  const int total = kBevPix * cd;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int pix = e / cd, ch = e - pix * cd;
+    if (p0 + pix >= npix) break;
+    const int cc = ch / g.d, d = ch - cc * g.d;
+    const int r = rows[pix][d];
+    out[(p0 + pix) * cd + ch] = (r >= 0) ? feat[(long long)r * c + cc] : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+from_bev_kernel(const float* __restrict__ gout, int c, const int* __restrict__ ind, long long m, Grid3 g,
+                float* __restrict__ gf) {
+  const long long total = m * c;
+  const int cd = c * g.d;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / c;
+    const int cc = (int)(e - r * c);
+    const int4 q = reinterpret_cast<const int4*>(ind)[r];
+    gf[e] = gout[(((long long)q.x * g.h + q.z) * g.w + q.w) * cd + cc * g.d + q.y];
+  }
+}
+
 int make_grid(int batch, const int* shape, Grid3* g, unsigned long long* cells) {
   EFG_CHECK_ARG(batch >= 1 && shape[0] >= 1 && shape[1] >= 1 && shape[2] >= 1, "spconv: bad grid shape");
   *g = Grid3{batch, shape[0], shape[1], shape[2]};
@@ -373,6 +423,33 @@ extern "C" int efg_dense_to_sparse_f32(const float* grad_dense, int c, const int
   if (m == 0) return EFG_OK;
   hipLaunchKernelGGL(from_dense_kernel, dim3((unsigned)ceil_div(m, 64)), dim3(256), 0, (hipStream_t)stream_,
                      grad_dense, c, indices, (long long)m, g, grad_feat);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_sparse_to_bev_f32(const float* feat, int c, const void* index, const int32_t* perm, int batch,
+                                     const int* shape, float* out, void* stream_) {
+  Grid3 g;
+  unsigned long long cells;
+  if (int rc = make_grid(batch, shape, &g, &cells)) return rc;
+  EFG_CHECK_ARG(c >= 1, "spconv: bad channel count");
+  EFG_CHECK_ARG(shape[0] <= kBevMaxD, "sparse_to_bev: depth %d > %d not supported", shape[0], kBevMaxD);
+  const long long npix = (long long)batch * shape[1] * shape[2];
+  hipLaunchKernelGGL(to_bev_kernel, dim3((unsigned)ceil_div(npix, kBevPix)), dim3(256), 0, (hipStream_t)stream_, feat,
+                     c, static_cast<const uint2*>(index), perm, g, out);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_bev_to_sparse_f32(const float* grad_out, int c, const int32_t* indices, int64_t m, int batch,
+                                     const int* shape, float* grad_feat, void* stream_) {
+  Grid3 g;
+  unsigned long long cells;
+  if (int rc = make_grid(batch, shape, &g, &cells)) return rc;
+  EFG_CHECK_ARG(c >= 1 && m >= 0, "spconv: bad sizes");
+  if (m == 0) return EFG_OK;
+  hipLaunchKernelGGL(from_bev_kernel, dim3(grid_for(m * c)), dim3(256), 0, (hipStream_t)stream_, grad_out, c, indices,
+                     (long long)m, g, grad_feat);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

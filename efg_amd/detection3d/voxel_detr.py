@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from ..modeling.backbones.fpn import build_resnet_fpn_backbone
+from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import voxelize_batch
 from .box_coder import VoxelBoxCoder3D
@@ -76,7 +77,7 @@ class VoxelDETR(nn.Module):
             extractor.set_active_levels(list(config.model.backbone.out_features))
         in_channels = self.backbone.num_channels
         self.input_proj = nn.ModuleList([
-            nn.Sequential(nn.Conv2d(in_channels[i], self.hidden_dim, kernel_size=1), nn.GroupNorm(32, self.hidden_dim))
+            nn.Sequential(Conv2d(in_channels[i], self.hidden_dim, kernel_size=1), nn.GroupNorm(32, self.hidden_dim))
             for i in range(len(self.backbone.out_features))])
         for module in self.input_proj.modules():
             if isinstance(module, nn.Conv2d):

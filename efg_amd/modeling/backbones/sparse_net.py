@@ -149,9 +149,7 @@ class SparseResNet(nn.Module):
                 outputs[name] = x
         for out_feature in wanted:
             out = getattr(self, out_feature + "_out")(outputs[out_feature])
-            out = out.dense()
-            n, c, d, h, w = out.shape
-            outputs[out_feature] = out.view(n, c * d, h, w)
+            outputs[out_feature] = out.dense_bev()  # == out.dense().view(n, c * d, h, w), channels-last memory
         return outputs
 
     def output_shape(self):
@@ -250,6 +248,4 @@ class SpMiddleResNetFHD(nn.Module):
         ret = spconv.SparseConvTensor(voxel_features, coors.int(), sparse_shape.tolist(), batch_size)
         x = self.conv_input(ret)
         x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
-        ret = self.extra_conv(x).dense()
-        n, c, d, h, w = ret.shape
-        return ret.view(n, c * d, h, w)
+        return self.extra_conv(x).dense_bev()  # == .dense().view(n, c * d, h, w), channels-last memory

@@ -1,6 +1,7 @@
 """Norm / activation factories and the Conv2d(+norm) wrapper (efg/modeling/common/batch_norm.py:140-188,
 efg/modeling/common/blocks.py:45-100).  Dense ops stay on PyTorch-ROCm (MIOpen / hipBLASLt)."""
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 
@@ -38,8 +39,18 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
         self.activation = activation
 
+    def _is_pointwise(self):
+        return (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.dilation == (1, 1) and self.groups == 1)
+
     def forward(self, x):
-        x = super().forward(x)
+        if self._is_pointwise():
+            # 1x1 conv == Linear over the channel axis of the channels-last map: goes to hipBLASLt
+            # (MIOpen's 1x1 weight-gradient picks a single-workgroup GEMM for K = B*H*W ~ 70k rows).
+            y = F.linear(x.permute(0, 2, 3, 1), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            x = y.permute(0, 3, 1, 2)
+        else:
+            x = super().forward(x)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:

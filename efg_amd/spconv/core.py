@@ -131,6 +131,25 @@ def _to_dense(features, x):
     return dense
 
 
+def _to_bev(features, x):
+    """[B, H, W, C*D] channels-last BEV map (channel = c*D + d)."""
+    si = x.site_index()
+    c = features.shape[1]
+    d, h, w = x.spatial_shape
+    out = torch.empty((x.batch_size, h, w, c * d), dtype=torch.float32, device=features.device)
+    L.check(L.lib().efg_sparse_to_bev_f32(L.ptr(features), c, L.ptr(si.index), L.ptr(si.perm), x.batch_size,
+                                          L.host_i32(x.spatial_shape, 3), L.ptr(out), L.stream()))
+    return out
+
+
+def _from_bev(grad_out, x, c):
+    m = x.indices.shape[0]
+    g = torch.empty((m, c), dtype=torch.float32, device=grad_out.device)
+    L.check(L.lib().efg_bev_to_sparse_f32(L.ptr(grad_out), c, L.ptr(x.indices), m, x.batch_size,
+                                          L.host_i32(x.spatial_shape, 3), L.ptr(g), L.stream()))
+    return g
+
+
 def _from_dense(grad_dense, x):
     m, c = x.indices.shape[0], grad_dense.shape[1]
     g = torch.empty((m, c), dtype=torch.float32, device=grad_dense.device)
@@ -203,6 +222,25 @@ class SparseConvTensor:
         """[B, C, D, H, W] (sparse_net.py:304); zeros where inactive."""
         out = _ToDense.apply(self.features, self)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+    def dense_bev(self):
+        """The BEV map the backbones build with `dense()` + `view(N, C*D, H, W)` (sparse_net.py:304-306,
+        541-545): same logical [B, C*D, H, W] tensor and values, produced in ONE pass and stored
+        channels-last (the layout the transformer's [B, H*W, C] tokens need)."""
+        return _ToBev.apply(self.features, self).permute(0, 3, 1, 2)
+
+
+class _ToBev(Function):
+    @staticmethod
+    def forward(ctx, features, x):
+        ctx.x = x
+        ctx.c = features.shape[1]
+        return _to_bev(features.contiguous(), x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        return _from_bev(grad_out.contiguous(), ctx.x, ctx.c), None
 
 
 class _ToDense(Function):

@@ -154,6 +154,13 @@ int efg_sparse_to_dense_f32(const float* feat, int c, const void* index, const i
 int efg_dense_to_sparse_f32(const float* grad_dense, int c, const int32_t* indices, int64_t m, int batch,
                             const int* shape_host, float* grad_feat, void* stream);
 
+/* BEV flatten fused with dense(): out f32 [batch, H, W, c*D] with channel index c*D + d -- the values of
+ * dense().view(N, C*D, H, W) (sparse_net.py:304-306) in channels-last order, fully written. D <= 16. */
+int efg_sparse_to_bev_f32(const float* feat, int c, const void* index, const int32_t* perm, int batch,
+                          const int* shape_host, float* out, void* stream);
+int efg_bev_to_sparse_f32(const float* grad_out, int c, const int32_t* indices, int64_t m, int batch,
+                          const int* shape_host, float* grad_feat, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Box / multi-scale deformable attention.  One kernel family behind both
  * efg::box_attn_forward/backward (efg/operators/src/box_attn/box_attn.h:29-83) and

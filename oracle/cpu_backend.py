@@ -132,6 +132,16 @@ def install():
     def to_dense(features, x):
         return torch.from_numpy(oracle.sparse_to_dense(_np(features), _np(x.indices), x.batch_size, x.spatial_shape))
 
+    def to_bev(features, x):
+        d = to_dense(features, x)  # [B, C, D, H, W]
+        b, c, dd, h, w = d.shape
+        return d.view(b, c * dd, h, w).permute(0, 2, 3, 1).contiguous()
+
+    def from_bev(grad_out, x, c):
+        b, h, w, cd = grad_out.shape
+        g = grad_out.permute(0, 3, 1, 2).reshape(b, c, cd // c, h, w)
+        return from_dense(g, x)
+
     def from_dense(grad_dense, x):
         i = x.indices.long()
         return grad_dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
@@ -145,6 +155,8 @@ def install():
     patch(core, "_conv_wgrad", conv_wgrad)
     patch(core, "_to_dense", to_dense)
     patch(core, "_from_dense", from_dense)
+    patch(core, "_to_bev", to_bev)
+    patch(core, "_from_bev", from_bev)
     try:
         yield
     finally:

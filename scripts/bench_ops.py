@@ -1,0 +1,125 @@
+"""Micro-benchmarks of the individual HIP ops at ConQueR sizes (run on the GPU box).
+usage: python scripts/bench_ops.py [msda] [spconv] [voxelize] [dense]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def bench_msda():
+    from efg_amd.operators.box_attention_func import box_attn_backward, box_attn_forward
+
+    g = torch.Generator().manual_seed(0)
+    for name, b, lq in [("encoder", 2, 188 * 188), ("decoder", 2, 1240)]:
+        s, h, d, p = 188 * 188, 8, 32, 25
+        value = torch.randn(b, s, h, d, generator=g).to(dev)
+        if name == "encoder":  # box self-attention: 5x5 lattice over a ~4.7-cell box around each token
+            ys, xs = torch.meshgrid(torch.arange(188.0), torch.arange(188.0), indexing="ij")
+            cen = torch.stack([(xs + 0.5) / 188, (ys + 0.5) / 188], -1).view(1, s, 1, 1, 1, 2)
+            k = torch.linspace(-2, 2, 5) / 5
+            ky, kx = torch.meshgrid(k, k, indexing="ij")
+            lat = torch.stack([kx, ky], -1).view(1, 1, 1, 1, 25, 2) * 0.025
+            loc = (cen + lat * (1 + 0.1 * torch.rand(b, s, h, 1, 1, 2, generator=g))).contiguous().to(dev)
+        else:
+            loc = torch.rand(b, lq, h, 1, p, 2, generator=g).to(dev)
+        attn = torch.softmax(torch.randn(b, lq, h, p, generator=g), -1).view(b, lq, h, 1, p).to(dev)
+        go = torch.randn(b, lq, h * d, generator=g).to(dev)
+        shapes = torch.tensor([[188, 188]], device=dev)
+        start = torch.zeros(1, dtype=torch.int64, device=dev)
+        tf = timeit(lambda: box_attn_forward(value, shapes, start, loc, attn, 64))
+        tb = timeit(lambda: box_attn_backward(value, shapes, start, loc, attn, go, 64))
+        fwd_bytes = 4 * (b * s * h * d + b * lq * h * p * 3 + b * lq * h * d)
+        print("msda %-8s fwd %8.1f us (%6.1f GB/s alg)   bwd %8.1f us" % (name, tf, fwd_bytes / tf / 1e3, tb))
+
+
+def bench_spconv():
+    import efg_amd.spconv as spconv
+    from efg_amd import _prof
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.modeling.backbones import build_sparse_resnet_backbone
+    from efg_amd.operators import voxelize_batch
+
+    pts = [torch.from_numpy(make_scene(2000 + i)[0]).to(dev) for i in range(2)]
+    vox = voxelize_batch(pts, VOXEL_SIZE, PC_RANGE, 5, 120000)
+    cfg = dict(depth=18, out_features=["res2", "res3", "res4"], num_groups=1, norm="BN1d",
+               activation=dict(type="ReLU", inplace=True), width_per_group=64, res1_out_channels=64,
+               stem_out_channels=32)
+    net = build_sparse_resnet_backbone(cfg, 5).to(dev)
+    net.dense_features = ["res3", "res4"]
+    feats, coors = vox["voxel_mean"], vox["coordinates"]
+    print("input voxels", feats.shape)
+
+    def fwd_bwd():
+        out = net(feats, coors, 2, [1504, 1504, 40])
+        (out["res3"].sum() + out["res4"].sum()).backward()
+
+    print("sparse backbone fwd+bwd %.1f us" % timeit(fwd_bwd, iters=5, warm=2))
+    _prof.enable(True)
+    fwd_bwd()
+    torch.cuda.synchronize()
+    _prof.enable(False)
+    for k, v in sorted(_prof.summary().items()):
+        print("  %-14s launches %3d total %8.2f ms  %7.1f GB/s alg  %6.2f TFLOP/s" % (
+            k, v["launches"], v["total_ms"], v["bytes"] / v["total_ms"] / 1e6, v["flops"] / v["total_ms"] / 1e9))
+    x = spconv.SparseConvTensor(feats, coors, [41, 1504, 1504], 2)
+    lvl = net.stem(x)
+    names = ["stem"]
+    levels = [lvl]
+    for stage, name in net.stages_and_names:
+        lvl = stage(lvl)
+        levels.append(lvl)
+        names.append(name)
+    for n, l in zip(names, levels):
+        rb = [v for k, v in l.indice_dict.items() if k[1] == n or n == "stem" and k[1] == "stem"]
+        pairs = rb[0].num_pairs() if rb else -1
+        print("  level %-5s sites %7d channels %3d subm pairs/site %.2f" % (
+            n, l.features.shape[0], l.features.shape[1], pairs / max(l.features.shape[0], 1)))
+
+
+def bench_voxelize():
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators.voxelize import _hard_voxelize_launch
+
+    for n, sw, mv, nb in [(180000, 1, 120000, 2), (720000, 4, 200000, 1), (180000, 1, 120000, 8)]:
+        scenes = [torch.from_numpy(make_scene(2000 + i, n_points=n, n_sweeps=sw)[0]).to(dev) for i in range(nb)]
+        pts = torch.cat(scenes)
+        offs = [0]
+        for s in scenes:
+            offs.append(offs[-1] + s.shape[0])
+        f = pts.shape[1]
+        cap = nb * mv
+        voxels = torch.empty((cap, 5, f), device=dev)
+        coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        npv = torch.empty(cap, dtype=torch.int32, device=dev)
+        mean = torch.empty((cap, f), device=dev)
+        num = torch.zeros(nb, dtype=torch.int32, device=dev)
+        t = timeit(lambda: _hard_voxelize_launch(pts, offs, VOXEL_SIZE, PC_RANGE, 5, mv, voxels, coors, npv, num, mean))
+        m = int(num.sum())
+        alg = 4 * f * pts.shape[0] + m * (4 * 5 * f + 16 + 4 + 4 * f)
+        print("hard_voxelize %d scenes x %d pts x %d feats -> %d voxels: %8.1f us  (%6.1f GB/s algorithmic)" % (
+            nb, n, f, m, t, alg / t / 1e3))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
+    for w in which:
+        globals()["bench_" + w]()

@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (scenes sharded by rank, DDP gradient
+all-reduce, identical parameters after the optimizer step).  The HIP ops are replaced by the oracle
+(oracle/cpu_backend.py) because this container has no GPU; on the GPU box the same Trainer runs
+over RCCL ("nccl" backend)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle  # noqa: F401
+    from oracle import cpu_backend
+
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
+    tr = Trainer(device="cpu", overrides=ov, seed=0, ddp=True)
+    tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
+    batch = synthetic_batch(500 + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
+    with cpu_backend.install():
+        loss_dict, total = tr.step(batch)
+    w = tr.model.backbone.extractor.bottom_up.stem.conv1[0].weight
+    g = w.grad.detach().clone()
+    gathered = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(gathered, g)
+    pw = [torch.zeros_like(w.data) for _ in range(world)]
+    dist.all_gather(pw, w.data)
+    if rank == 0:
+        out["grads_equal"] = bool(torch.equal(gathered[0], gathered[1]))      # all-reduced (averaged) gradient
+        out["params_equal"] = bool(torch.equal(pw[0], pw[1]))                  # same update on every rank
+        out["finite"] = bool(torch.isfinite(total))
+        out["grad_norm"] = float(g.norm())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_ddp_step(oracle_mod):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        res = dict(out)
+    assert res["finite"] and res["grads_equal"] and res["params_equal"] and res["grad_norm"] > 0

@@ -142,3 +142,20 @@ def test_full_size_properties(dev):
     centre = y.indices[12345]
     d = (y.indices[touched] - centre).abs()
     assert (d[:, 0] == 0).all() and (d[:, 1:] <= 1).all()
+
+
+def test_dense_bev_matches_dense_view(dev):
+    """dense_bev() == dense().view(N, C*D, H, W) (sparse_net.py:304-306), stored channels-last; same gradients."""
+    rng = np.random.default_rng(11)
+    batch, shape, c = 2, (6, 47, 53), 40
+    idx, feat = random_sparse(rng, batch, shape, 4000, c)
+    x = _tensor(dev, idx, feat, batch, shape)
+    x.features.requires_grad_(True)
+    bev = x.dense_bev()
+    ref = x.dense().view(batch, c * shape[0], shape[1], shape[2])
+    assert bev.shape == ref.shape and bev.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(bev, ref)
+    g = torch.randn_like(ref)
+    (g1,) = torch.autograd.grad(bev, x.features, g, retain_graph=True)
+    (g2,) = torch.autograd.grad(ref, x.features, g)
+    assert torch.equal(g1, g2)
