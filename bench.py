@@ -33,6 +33,42 @@ def parse():
     return ap.parse_args()
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass
+    (profiles/pmc_latest.json, written by scripts/collect_pmc.py on the GPU box), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(args):
+    """The same train step on the host cores with the ORACLE standing in for every HIP op
+    (oracle/cpu_backend.py) -- a bounded sample: ONE config-0 sized scene (16k points)."""
+    import oracle  # noqa: F401  (test/bench-only checker)
+    from oracle import cpu_backend
+
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    cores = min(os.cpu_count() or 1, 16)  # more threads only add oversubscription on this workload
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    tr = Trainer(device="cpu", overrides={"model.transformer.num_queries": args.queries}, seed=0, ddp=False)
+    batch = synthetic_batch(1000, 1, n_points=16000)
+    with cpu_backend.install():
+        t0 = time.perf_counter()
+        tr.step(batch)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "1 train step (fwd+bwd+AdamW) on 1 synthetic scene of 16k points (BASELINE config 0 cloud), "
+                      "full ConQueR model (%d queries), oracle C ops (OpenMP) + PyTorch CPU dense layers, %.1f s" % (
+                          args.queries, dt)}
+
+
 def main():
     args = parse()
     from efg_amd import _prof
@@ -92,9 +128,13 @@ def main():
         },
     }
     if rank == 0:
-        line["roofline"] = _prof.roofline()
+        line["roofline"] = _prof.roofline(traffic_bytes_per_launch=_pmc_traffic())
+        line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
+                               "GBps_alg": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1),
+                               "TFLOPs_alg": round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 2)}
+                           for k, v in sorted(_prof.summary().items())}
         if not args.no_cpu_baseline and world == 1:
-            pass
+            line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -5,6 +5,7 @@ Module and parameter names follow the reference (encoder.layers.N.self_attn..., 
 decoder.detection_head, proposal_head, decoder_gt) so state dicts are interchangeable."""
 import torch
 from torch import nn
+from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
 from .box_attention import Box3dAttention
@@ -161,14 +162,17 @@ class Transformer(nn.Module):
         src, src_shape = flatten_with_shape(src)
         src_pos = torch.cat([pe.flatten(2).transpose(1, 2) for pe in pos], dim=1)
         src_start_index = torch.cat([src_shape.new_zeros(1), src_shape.prod(1).cumsum(0)[:-1]])
-        memory = self.encoder(src, src_pos, src_shape, src_start_index, src_anchors)
-        query_embed, query_pos, topk_proposals, topk_indexes = self._get_enc_proposals(memory, src_anchors)
+        with record_function("efg::encoder"):
+            memory = self.encoder(src, src_pos, src_shape, src_start_index, src_anchors)
+        with record_function("efg::proposals"):
+            query_embed, query_pos, topk_proposals, topk_indexes = self._get_enc_proposals(memory, src_anchors)
         if noised_gt_box is not None:
             noised_gt_proposals = torch.cat((noised_gt_box, noised_gt_onehot), dim=-1)
             topk_proposals = torch.cat((noised_gt_proposals, topk_proposals), dim=1)
         init_reference_out = topk_proposals[..., :7]
-        hs, inter_references = self.decoder(query_embed, query_pos, memory, src_shape, src_start_index, topk_proposals,
-                                            attn_mask)
+        with record_function("efg::decoder"):
+            hs, inter_references = self.decoder(query_embed, query_pos, memory, src_shape, src_start_index,
+                                                topk_proposals, attn_mask)
         if targets is not None:  # momentum GT decoder pass (:146-200)
             batch_size = len(targets)
             per_gt_num = [tgt["gt_boxes"].shape[0] for tgt in targets]
@@ -178,7 +182,7 @@ class Transformer(nn.Module):
                 gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
                 gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
                                                                     num_classes=self.num_classes)
-            with torch.no_grad():
+            with torch.no_grad(), record_function("efg::gt_decoder"):
                 self._momentum_update_gt_decoder()
                 if noised_gt_box is not None:
                     dn_group_num = noised_gt_proposals.shape[1] // (max_gt_num * 2)

@@ -16,6 +16,7 @@ import copy
 import numpy as np
 import torch
 from torch import nn
+from torch.autograd.profiler import record_function
 
 from ..modeling.backbones.fpn import build_resnet_fpn_backbone
 from ..modeling.common import Conv2d
@@ -128,7 +129,8 @@ class VoxelDETR(nn.Module):
 
     def forward(self, batched_inputs):
         batch_size = len(batched_inputs)
-        voxels, coords, num_points_per_voxel, input_shape, voxel_mean = self._inputs(batched_inputs)
+        with record_function("efg::voxelize"):
+            voxels, coords, num_points_per_voxel, input_shape, voxel_mean = self._inputs(batched_inputs)
         if self.training:
             targets = []
             for bi in batched_inputs:
@@ -140,19 +142,22 @@ class VoxelDETR(nn.Module):
                 targets.append(self.box_coder.encode(tgt))
         else:
             targets = None
-        feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
-        features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
+        with record_function("efg::backbone+fpn"):
+            feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
+            features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
         pos_encodings = [fp[1] for fp in feats_pos]
         dn = self.config.model.dn
         if self.training and dn.enabled and dn.dn_number > 0:
-            input_query_label, input_query_bbox, attn_mask, dn_meta = prepare_for_cdn(
-                dn_args=(targets, dn.dn_number, dn.dn_label_noise_ratio, dn.dn_box_noise_scale),
-                training=self.training, num_queries=self.num_queries, num_classes=self.num_classes,
-                hidden_dim=self.hidden_dim, label_enc=None, generator=self.noise_generator)
+            with record_function("efg::cdn"):
+                input_query_label, input_query_bbox, attn_mask, dn_meta = prepare_for_cdn(
+                    dn_args=(targets, dn.dn_number, dn.dn_label_noise_ratio, dn.dn_box_noise_scale),
+                    training=self.training, num_queries=self.num_queries, num_classes=self.num_classes,
+                    hidden_dim=self.hidden_dim, label_enc=None, generator=self.noise_generator)
         else:
             input_query_bbox = input_query_label = attn_mask = dn_meta = None
-        hidden_state, init_reference, inter_references, src_embed, src_ref_windows, src_indexes = self.transformer(
-            features, pos_encodings, input_query_bbox, input_query_label, attn_mask, targets=targets)
+        with record_function("efg::transformer"):
+            hidden_state, init_reference, inter_references, src_embed, src_ref_windows, src_indexes = self.transformer(
+                features, pos_encodings, input_query_bbox, input_query_label, attn_mask, targets=targets)
         head = self.transformer.decoder.detection_head
         outputs_classes, outputs_coords = [], []
         for idx in range(hidden_state.shape[0]):
@@ -166,6 +171,11 @@ class VoxelDETR(nn.Module):
                                                            self._set_aux_loss)
         if not self.training:
             return self._inference(outputs_class, outputs_coord)
+        with record_function("efg::losses"):
+            return self._losses(outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes)
+
+    def _losses(self, outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes):
+        head = self.transformer.decoder.detection_head
         losses = {}
         # encoder proposal losses (class-agnostic), voxel_detr.py:198-209
         enc_class, enc_coords = self.transformer.proposal_head(src_embed, src_ref_windows)
@@ -178,9 +188,11 @@ class VoxelDETR(nn.Module):
         nq = self.num_queries
         outputs = {"pred_logits": outputs_class[-1][:, :nq], "pred_boxes": outputs_coord[-1][:, :nq],
                    "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
-        losses.update(head.compute_losses(outputs, targets, dn_meta))
-        losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_indices"], targets,
-                                               dn_meta))
+        with record_function("efg::losses.decoder"):
+            losses.update(head.compute_losses(outputs, targets, dn_meta))
+        with record_function("efg::losses.contrastive"):
+            losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_indices"], targets,
+                                                   dn_meta))
         return losses
 
     def _contrastive_losses(self, outputs_class, outputs_coord, matched, targets, dn_meta):

@@ -9,6 +9,7 @@ import os
 import numpy as np
 import torch
 import torch.distributed as dist
+from torch.autograd.profiler import record_function
 
 from .config import load_config
 from .data.synthetic import make_scene
@@ -68,8 +69,11 @@ class Trainer:
 
     def step(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
-        loss_dict = self.wrapped(batch)
-        losses = sum(v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad)
-        losses.backward()
-        self.optimizer.step()
+        with record_function("efg::forward"):
+            loss_dict = self.wrapped(batch)
+            losses = sum(v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad)
+        with record_function("efg::backward"):
+            losses.backward()
+        with record_function("efg::optimizer"):
+            self.optimizer.step()
         return loss_dict, losses

@@ -10,6 +10,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from .. import _prof
 
 
 def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
@@ -33,9 +34,12 @@ def box_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, att
     b, s, h, d = value.shape
     lq, l, p = sampling_loc.size(1), spatial_shapes.size(0), sampling_loc.size(4)
     out = torch.empty((b, lq, h * d), dtype=value.dtype, device=value.device)
-    L.check(L.lib().efg_msda_forward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
-                                         L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
-                                         L.ptr(attn_weight), b, s, h, d, l, lq, p, L.ptr(out), L.stream()))
+    # algorithmic bytes: value once + loc/attn + out; flops ~ 10 per (sample, channel)
+    cost = lambda: (4 * (b * s * h * d + b * lq * h * l * p * 3 + b * lq * h * d), 10 * b * lq * h * l * p * d)  # noqa: E731
+    with _prof.timed("msda_kernel<false>", cost):
+        L.check(L.lib().efg_msda_forward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
+                                             L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
+                                             L.ptr(attn_weight), b, s, h, d, l, lq, p, L.ptr(out), L.stream()))
     return out
 
 
@@ -49,10 +53,14 @@ def box_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, at
     grad_value = torch.zeros_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
-    L.check(L.lib().efg_msda_backward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
-                                          L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
-                                          L.ptr(attn_weight), L.ptr(grad_output), b, s, h, d, l, lq, p,
-                                          L.ptr(grad_value), L.ptr(grad_loc), L.ptr(grad_attn), L.stream()))
+    # bwd algorithmic bytes: fwd reads + grad_out, writes grad_value + grad_loc + grad_attn
+    cost = lambda: (4 * (2 * b * s * h * d + 2 * b * lq * h * l * p * 3 + 2 * b * lq * h * d), 30 * b * lq * h * l * p * d)  # noqa: E731
+    grid = (l == 1 and d == 32 and s == lq and s >= 1024)
+    with _prof.timed("msda_bwd_grid_kernel<32>" if grid else "msda_kernel<true>", cost):
+        L.check(L.lib().efg_msda_backward_f32(L.ptr(value), L.ptr(spatial_shapes.contiguous()),
+                                              L.ptr(level_start_index.contiguous()), L.ptr(sampling_loc),
+                                              L.ptr(attn_weight), L.ptr(grad_output), b, s, h, d, l, lq, p,
+                                              L.ptr(grad_value), L.ptr(grad_loc), L.ptr(grad_attn), L.stream()))
     return [grad_value, grad_loc, grad_attn]
 
 

@@ -79,7 +79,7 @@ def _conv_forward(features, w, bias, rb):
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-    with _prof.timed("spconv_fwd", *_conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cout), lambda: _conv_cost(rb, cin, cout)):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
                                            L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
     return out
@@ -93,7 +93,7 @@ def _conv_dgrad(grad_out, w, rb):
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     rnbr = rb.rnbr
-    with _prof.timed("spconv_dgrad", *_conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cin), lambda: _conv_cost(rb, cin, cout)):
         L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
                                          rb.m_in, L.ptr(grad_in), L.stream()))
     return grad_in
@@ -105,17 +105,22 @@ def _conv_wgrad(features, grad_out, rb):
     ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
-    with _prof.timed("spconv_wgrad", *_conv_cost(rb, cin, cout)):
+    with _prof.timed("conv_wgrad_kernel+wgrad_reduce_kernel", lambda: _conv_cost(rb, cin, cout)):
         L.check(lib.efg_spconv_wgrad_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
                                          L.ptr(rb.nbr), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
     return grad_w
 
 
+def _fwd_kernel_name(n_out_channels):
+    """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks."""
+    ntiles = (n_out_channels + 15) // 16
+    nt = 16 if ntiles > 8 else 8 if ntiles > 4 else 4 if ntiles > 2 else 2 if ntiles > 1 else 1
+    return "conv_fwd_kernel<%d>" % nt
+
+
 def _conv_cost(rb, cin, cout):
     """Algorithmic (bytes, flops) of one sparse-conv launch, SURVEY.md §8(d):
     4*Cin*M_in + 4*Cout*M_out + 4*K*Cin*Cout + 8*pairs bytes, 2*pairs*Cin*Cout flops."""
-    if not _prof.active("spconv_fwd") and not _prof.active("spconv_dgrad") and not _prof.active("spconv_wgrad"):
-        return 0, 0
     pairs = rb.num_pairs()
     return (4 * cin * rb.m_in + 4 * cout * rb.m_out + 4 * rb.kvol * cin * cout + 8 * pairs,
             2 * pairs * cin * cout)
