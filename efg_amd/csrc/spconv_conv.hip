@@ -17,8 +17,8 @@
 //     CK+2 (bank-conflict-free ds_read_b32 of the A fragment), double-buffered against the MFMAs;
 //   * the B fragments come straight from L1/L2 as 16-byte loads of weights pre-packed into MFMA
 //     operand order (efg_spconv_pack_weight_f32): one load feeds four MFMAs.
-// wgrad: per (row chunk, 64x64 block of dW, group of offsets) workgroup; G^T x gathered-A on the
-// same MFMA, partial sums to a workspace, deterministic second-pass reduce.
+// wgrad: per (row chunk, 64x64 block of dW, kernel offset) workgroup; valid pairs compacted into dense
+// 64-pair tiles, G^T x gathered-X on the same MFMA, partials to a workspace, deterministic reduce.
 #include "common.h"
 
 namespace efg {
@@ -182,6 +182,11 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
 }
 
 // ---- wgrad ------------------------------------------------------------------------------------
+// dW[co][k][ci] = sum_o G[o][co] * X[nbr[k][o]][ci].  One workgroup = (row chunk, 64x64 block of dW,
+// ONE kernel offset k).  Only rows that really have a neighbour at k enter the MFMAs: the chunk's
+// valid (out row, in row) pairs are compacted with ballot/popcount into an LDS queue and consumed as
+// dense 64-pair tiles (strided convs have 1/8 of the rows valid per offset, SubM ~60 %).  Partial
+// blocks go to a workspace; a second pass reduces them in a fixed order (deterministic).
 struct WgradArgs {
   const float* in;    // [m_in][cin]
   const float* go;    // [m_out][cout]
@@ -189,77 +194,108 @@ struct WgradArgs {
   float* partial;     // [splits][kvol][cout][cin]
   long long m_out;
   int cin, cout, kvol;
-  int rows_per_split;  // multiple of 64
+  int rows_per_split;  // multiple of 256
   int nci_blk;         // ceil(cin / 64)
-  int kgroups;
 };
 
-constexpr int kWStride = 64 + 16;  // row stride of the LDS tiles (== 16 mod 32)
+constexpr int kWStride = 64 + 16;  // row stride of the LDS tiles (== 16 mod 32: conflict-free fragment reads)
+constexpr int kQueue = 64 + 256;
 
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
-  __shared__ float g_tile[64 * kWStride];   // grad_out rows x 64 co
-  __shared__ float x_tile[64 * kWStride];   // gathered input rows x 64 ci
-  __shared__ int rows_s[64];
-  __shared__ int any_s;
+  __shared__ float g_tile[64 * kWStride];   // 64 pairs x 64 co of grad_out
+  __shared__ float x_tile[64 * kWStride];   // 64 pairs x 64 ci of the gathered input
+  __shared__ int q_out[kQueue], q_in[kQueue];
+  __shared__ int wave_cnt[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int split = blockIdx.x;
+  const int split = blockIdx.x, k = blockIdx.z;
   const int co0 = (blockIdx.y / a.nci_blk) * 64, ci0 = (blockIdx.y % a.nci_blk) * 64;
-  const int kg = blockIdx.z;
-  const int k_per = (a.kvol + a.kgroups - 1) / a.kgroups;
-  const int k_lo = kg * k_per, k_hi = min(k_lo + k_per, a.kvol);
   const long long row_lo = (long long)split * a.rows_per_split;
   const long long row_hi = min(row_lo + a.rows_per_split, a.m_out);
   const int m = lane & 15, kk = lane >> 4;
-  // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles of the block
-  for (int k = k_lo; k < k_hi; ++k) {
-    f32x4 acc[4];
+  f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long t0 = row_lo; t0 < row_hi; t0 += 64) {
-      __syncthreads();  // previous tile fully consumed
-      if (threadIdx.x == 0) any_s = 0;
-      __syncthreads();
-      if (wv == 0) {
-        const int r = (t0 + lane < row_hi) ? a.nbr[(long long)k * a.m_out + t0 + lane] : -1;
-        rows_s[lane] = r;
-        if (r >= 0) any_s = 1;
-      }
-      __syncthreads();
-      if (!any_s) continue;  // no pair of this offset in the tile (block-uniform)
-      // stage: wave wv loads rows wv, wv+4, ... ; lane = channel
-      for (int j = wv; j < 64; j += 4) {
-        const int r = rows_s[j];
-        float g = 0.f, x = 0.f;
-        if (r >= 0) {
-          if (co0 + lane < a.cout) g = a.go[(t0 + j) * a.cout + co0 + lane];
-          if (ci0 + lane < a.cin) x = a.in[(long long)r * a.cin + ci0 + lane];
-        }
-        g_tile[j * kWStride + lane] = g;
-        x_tile[j * kWStride + lane] = x;
-      }
-      __syncthreads();
-      // dW[co][ci] += sum_rows G[row][co] * X[row][ci]; reduction dim = rows, 4 per MFMA
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto process = [&](int head) {
+    __syncthreads();  // queue entries visible; previous tile fully consumed
 #pragma unroll 4
-      for (int s = 0; s < 16; ++s) {
-        const int row = s * 4 + kk;
-        const float av = g_tile[row * kWStride + wv * 16 + m];
+    for (int j = wv; j < 64; j += 4) {
+      const int o = q_out[head + j], i = q_in[head + j];
+      float g = 0.f, x = 0.f;
+      if (o >= 0) {
+        if (co0 + lane < a.cout) g = a.go[(long long)o * a.cout + co0 + lane];
+        if (ci0 + lane < a.cin) x = a.in[(long long)i * a.cin + ci0 + lane];
+      }
+      g_tile[j * kWStride + lane] = g;
+      x_tile[j * kWStride + lane] = x;
+    }
+    __syncthreads();
+    // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles; reduction dim = pairs, 4 per MFMA
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int row = s * 4 + kk;
+      const float av = g_tile[row * kWStride + wv * 16 + m];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float bv = x_tile[row * kWStride + t * 16 + m];
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
-        }
+      for (int t = 0; t < 4; ++t) {
+        const float bv = x_tile[row * kWStride + t * 16 + m];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
       }
     }
-    // write the partial block: row (co) = (lane>>4)*4 + reg, col (ci) = lane & 15
-    float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ci = ci0 + t * 16 + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wv * 16 + (lane >> 4) * 4 + r;
-        if (co < a.cout && ci < a.cin) p[(long long)co * a.cin + ci] = acc[t][r];
+  };
+
+  int qn = 0;  // block-uniform queue length
+  for (long long seg = row_lo; seg < row_hi; seg += 256) {
+    const long long row = seg + threadIdx.x;
+    const int r = (row < row_hi) ? a.nbr[(long long)k * a.m_out + row] : -1;
+    const unsigned long long mask = __ballot(r >= 0);
+    if (lane == 0) wave_cnt[wv] = __popcll(mask);
+    __syncthreads();
+    int base = qn;
+    for (int w = 0; w < wv; ++w) base += wave_cnt[w];
+    if (r >= 0) {
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      q_out[pos] = (int)row;
+      q_in[pos] = r;
+    }
+    qn += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    int head = 0;
+    while (qn - head >= 64) {
+      process(head);
+      head += 64;
+    }
+    __syncthreads();  // all reads of the queue / wave_cnt done
+    if (head > 0) {   // move the remainder (< 64 pairs) to the front
+      const int rem = qn - head;
+      int to = -1, ti = -1;
+      if ((int)threadIdx.x < rem) {
+        to = q_out[head + threadIdx.x];
+        ti = q_in[head + threadIdx.x];
       }
+      __syncthreads();
+      if ((int)threadIdx.x < rem) {
+        q_out[threadIdx.x] = to;
+        q_in[threadIdx.x] = ti;
+      }
+      qn = rem;
+    }
+  }
+  if (qn > 0) {
+    __syncthreads();
+    if ((int)threadIdx.x >= qn && threadIdx.x < 64) {
+      q_out[threadIdx.x] = -1;
+      q_in[threadIdx.x] = -1;
+    }
+    process(0);
+  }
+  // partial block: row (co) = (lane>>4)*4 + reg, col (ci) = lane & 15
+  float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ci = ci0 + t * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wv * 16 + (lane >> 4) * 4 + r;
+      if (co < a.cout && ci < a.cin) p[(long long)co * a.cin + ci] = acc[t][r];
     }
   }
 }
@@ -281,7 +317,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgradPlan {
-  int splits, rows_per_split, nco_blk, nci_blk, kgroups;
+  int splits, rows_per_split, nco_blk, nci_blk;
   size_t bytes;
 };
 
@@ -289,14 +325,14 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
   WgradPlan p;
   p.nco_blk = (cout + 63) / 64;
   p.nci_blk = (cin + 63) / 64;
-  p.kgroups = kvol >= 27 ? 3 : 1;
   const size_t per = (size_t)kvol * cout * cin * 4;
-  const int64_t budget_splits = std::max<int64_t>(1, (int64_t)((64ull << 20) / std::max<size_t>(per, 1)));
-  const int64_t want = std::max<int64_t>(1, ceil_div(m_out, 256));
-  const int64_t fill = std::max<int64_t>(1, 1024 / (p.nco_blk * p.nci_blk * p.kgroups));
-  int64_t s = std::min(std::min(want, budget_splits), fill);
+  // ~4096 workgroups (16 per CU) when the level is large enough, >= 512 rows per chunk, <= 128 MB partials
+  const int64_t by_fill = std::max<int64_t>(1, 4096 / ((int64_t)p.nco_blk * p.nci_blk * kvol));
+  const int64_t by_rows = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), 512));
+  const int64_t by_mem = std::max<int64_t>(1, (int64_t)((128ull << 20) / std::max<size_t>(per, 1)));
+  int64_t s = std::min(std::min(by_fill, by_rows), by_mem);
   int64_t rows = ceil_div(std::max<int64_t>(m_out, 1), s);
-  rows = ceil_div(rows, 64) * 64;
+  rows = ceil_div(rows, 256) * 256;
   s = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), rows));
   p.splits = (int)s;
   p.rows_per_split = (int)rows;
@@ -328,12 +364,22 @@ int run_conv(const float* in, int cin, const float* wp, const float* bias, int c
   a.c16n = (cin + 15) / 16;
   a.np = (cout + 15) / 16 * 16;
   const int ntiles = a.np / 16;
-  // n-tiles per wave: smallest of {1,2,4,8,16} covering the tiles; wider outputs tile over grid.y
-  if (ntiles > 8) launch_fwd<16>(a, (ntiles + 15) / 16, stream);
-  else if (ntiles > 4) launch_fwd<8>(a, 1, stream);
-  else if (ntiles > 2) launch_fwd<4>(a, 1, stream);
-  else if (ntiles > 1) launch_fwd<2>(a, 1, stream);
-  else launch_fwd<1>(a, 1, stream);
+  // n-tiles per wave (NT): as many as possible (A-tile reuse) while the launch still has >= ~2 waves
+  // per SIMD on the whole chip; small levels (a few thousand rows x 256 channels) otherwise run one
+  // long serial MFMA chain per wave on a third of the CUs.  Wider outputs tile over grid.y.
+  const long long row_waves = ceil_div(m_out, 16);
+  int nt = 16;
+  while (nt > 1 && (nt / 2 >= ntiles || row_waves * ((ntiles + nt - 1) / nt) < 2048)) nt >>= 1;
+  if (nt > ntiles) nt = ntiles >= 16 ? 16 : ntiles >= 8 ? 8 : ntiles >= 4 ? 4 : ntiles >= 2 ? 2 : 1;
+  while (nt < ntiles && nt < 16 && (ntiles % nt) != 0) nt <<= 1;  // keep grid.y exact where possible
+  const int ny = (ntiles + nt - 1) / nt;
+  switch (nt) {
+    case 16: launch_fwd<16>(a, ny, stream); break;
+    case 8: launch_fwd<8>(a, ny, stream); break;
+    case 4: launch_fwd<4>(a, ny, stream); break;
+    case 2: launch_fwd<2>(a, ny, stream); break;
+    default: launch_fwd<1>(a, ny, stream); break;
+  }
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
@@ -408,8 +454,7 @@ extern "C" int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin,
   a.kvol = kvol;
   a.rows_per_split = p.rows_per_split;
   a.nci_blk = p.nci_blk;
-  a.kgroups = p.kgroups;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.splits, p.nco_blk * p.nci_blk, p.kgroups), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.splits, p.nco_blk * p.nci_blk, kvol), dim3(256), 0, stream, a);
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(per, 256), 4096)), dim3(256), 0,

@@ -79,7 +79,7 @@ def _conv_forward(features, w, bias, rb):
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-    with _prof.timed(_fwd_kernel_name(cout), lambda: _conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cout, rb.m_out), lambda: _conv_cost(rb, cin, cout)):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
                                            L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
     return out
@@ -93,7 +93,7 @@ def _conv_dgrad(grad_out, w, rb):
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     rnbr = rb.rnbr
-    with _prof.timed(_fwd_kernel_name(cin), lambda: _conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cin, rb.m_in), lambda: _conv_cost(rb, cin, cout)):
         L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
                                          rb.m_in, L.ptr(grad_in), L.stream()))
     return grad_in
@@ -111,10 +111,17 @@ def _conv_wgrad(features, grad_out, rb):
     return grad_w
 
 
-def _fwd_kernel_name(n_out_channels):
-    """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks."""
+def _fwd_kernel_name(n_out_channels, n_rows):
+    """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks (same rule)."""
     ntiles = (n_out_channels + 15) // 16
-    nt = 16 if ntiles > 8 else 8 if ntiles > 4 else 4 if ntiles > 2 else 2 if ntiles > 1 else 1
+    row_waves = (n_rows + 15) // 16
+    nt = 16
+    while nt > 1 and (nt // 2 >= ntiles or row_waves * ((ntiles + nt - 1) // nt) < 2048):
+        nt >>= 1
+    if nt > ntiles:
+        nt = 16 if ntiles >= 16 else 8 if ntiles >= 8 else 4 if ntiles >= 4 else 2 if ntiles >= 2 else 1
+    while nt < ntiles and nt < 16 and ntiles % nt != 0:
+        nt <<= 1
     return "conv_fwd_kernel<%d>" % nt
 
 
