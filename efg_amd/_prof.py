@@ -63,8 +63,9 @@ def roofline(traffic_bytes_per_launch=None):
     secs = v["total_ms"] / 1e3
     gbs = v["bytes"] / secs / 1e9
     tfs = v["flops"] / secs / 1e12
-    # bound: whichever roof the kernel sits closer to
-    if tfs / F32_MFMA_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
+    # bound: the sparse-conv implicit GEMMs run on the f32 MFMA pipe (whichever roof they sit closer to);
+    # every other kernel of the path is gather / scatter / scan work: HBM
+    if name.startswith("conv_") and tfs / F32_MFMA_PEAK_TFLOPS > gbs / HBM_PEAK_GBS:
         return {"kernel": name, "bound": "mfma", "achieved": tfs, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tfs / F32_MFMA_PEAK_TFLOPS, "traffic": traffic_bytes_per_launch,
                 "avg_launch_us": v["avg_us"], "launches": v["launches"],

@@ -20,14 +20,18 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
     known_labels_expaned = known_labels.clone()
     known_bbox_expand = known_bboxs.clone()
 
+    gdev = generator.device if generator is not None else dev  # a CPU generator gives device-independent noise
+
     def rand_like(t):
-        return torch.rand(t.shape, dtype=torch.float32, device=dev, generator=generator)
+        return torch.rand(t.shape, dtype=torch.float32, device=gdev, generator=generator).to(dev)
+
+    def randint(lo, hi, shape, dtype=torch.int64):
+        return torch.randint(lo, hi, tuple(shape), device=gdev, generator=generator, dtype=dtype).to(dev)
 
     if label_noise_ratio > 0:
         p = rand_like(known_labels_expaned)
         chosen = torch.nonzero(p < (label_noise_ratio * 0.5)).view(-1)
-        new_label = torch.randint(0, num_classes, chosen.shape, device=dev, generator=generator,
-                                  dtype=known_labels_expaned.dtype)
+        new_label = randint(0, num_classes, chosen.shape, known_labels_expaned.dtype)
         known_labels_expaned.scatter_(0, chosen, new_label)
     single_pad = int(max(known_num))
     pad_size = int(single_pad * 2 * dn_number)
@@ -44,7 +48,7 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
         diff[:, :3] = known_bboxs[:, 3:6] / 2
         diff[:, 3:6] = known_bboxs[:, 3:6] / 2
         diff[:, 6:] = 0.1
-        rand_sign = torch.randint(0, 2, known_bboxs.shape, device=dev, generator=generator).float() * 2.0 - 1.0
+        rand_sign = randint(0, 2, known_bboxs.shape).float() * 2.0 - 1.0
         rand_part = rand_like(known_bboxs)
         rand_part[negative_idx] += 1.0
         rand_part *= rand_sign
