@@ -55,6 +55,8 @@ _SIGS = {
                                      c_int, c_int, c_int, c_void_p, c_void_p]),
     "efg_msda_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "efg_box_attn_fused_forward_f32": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p, c_void_p]),
+    "efg_box_attn_fused_backward_f32": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p] * 4),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

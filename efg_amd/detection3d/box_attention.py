@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..operators import BoxAttnFunction
+from ..operators import box_attention_func as _baf
 
 
 class Box3dAttention(nn.Module):
@@ -80,6 +81,14 @@ class Box3dAttention(nn.Module):
             value = value.masked_fill(v_mask[..., None], float(0))
         value = value.view(B, LV, self.num_head, self.head_dim)
         attn_weights = F.linear(query, self.linear_attn_weight, self.linear_attn_bias)
+        if (v_valid_ratios is None and not ref_windows.requires_grad
+                and _baf.box_attn_fused_available(value, ref_windows, self.head_dim, self.num_level, self.num_point)):
+            # MI355X path: geometry + softmax + sampling in one kernel (csrc/box_fused.hip); same result as the
+            # reference sequence below without materialising the [B, LQ, H, L, 25, 2] grid.
+            offsets = F.linear(query, self.linear_box_weight, self.linear_box_bias)
+            output = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, offsets, attn_weights,
+                                                     self.kernel_indices, self.num_variable)
+            return self.out_proj(output), None
         attn_weights = F.softmax(attn_weights.view(B, LQ, self.num_head, -1), dim=-1)
         attn_weights = attn_weights.view(B, LQ, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
         sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)

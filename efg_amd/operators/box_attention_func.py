@@ -91,3 +91,56 @@ class BoxAttnFunction(Function):
         grad_value, grad_loc, grad_attn = box_attn_backward(value, shapes, start, loc, attn,
                                                             grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
+
+
+# ---- fused Box3dAttention sampling (csrc/box_fused.hip) -------------------------------------------------
+FUSED_ENABLED = True
+
+
+def box_attn_fused_available(value, ref_windows, head_dim, num_level, num_point):
+    return (FUSED_ENABLED and value.is_cuda and head_dim == 32 and ref_windows.dim() == 3
+            and num_level * num_point <= 128 and value.dtype == torch.float32)
+
+
+class BoxAttnFusedFunction(Function):
+    """(value[B,S,H,D], shapes, start, ref[B,Lq,7], offsets[B,Lq,H*L*V], logits[B,Lq,H*L*P], kernel_indices[P,2])
+    -> [B,Lq,H*D].  Equivalent to _where_to_attend + softmax + BoxAttnFunction of the reference module."""
+
+    @staticmethod
+    def forward(ctx, value, shapes, start, ref, offsets, logits, kidx, num_var):
+        L.require_gpu(value, ref, offsets, logits, kidx)
+        value, ref, offsets, logits, kidx = (t.float().contiguous() for t in (value, ref, offsets, logits, kidx))
+        b, s, h, d = value.shape
+        lq, l, p = ref.shape[1], shapes.size(0), kidx.shape[0]
+        out = torch.empty((b, lq, h * d), dtype=torch.float32, device=value.device)
+        cost = lambda: (4 * (b * s * h * d + b * lq * (7 + h * l * (num_var + p)) + b * lq * h * d),  # noqa: E731
+                        10 * b * lq * h * l * p * d)
+        with _prof.timed("box_fwd_kernel", cost):
+            L.check(L.lib().efg_box_attn_fused_forward_f32(L.ptr(value), L.ptr(shapes.contiguous()),
+                                                           L.ptr(start.contiguous()), L.ptr(ref), L.ptr(offsets),
+                                                           L.ptr(logits), L.ptr(kidx), b, s, h, d, l, lq, p, num_var,
+                                                           L.ptr(out), L.stream()))
+        ctx.save_for_backward(value, shapes, start, ref, offsets, logits, kidx)
+        ctx.num_var = num_var
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, start, ref, offsets, logits, kidx = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        b, s, h, d = value.shape
+        lq, l, p = ref.shape[1], shapes.size(0), kidx.shape[0]
+        grad_value = torch.zeros_like(value)
+        grad_off = torch.empty_like(offsets)
+        grad_logits = torch.empty_like(logits)
+        cost = lambda: (4 * (2 * b * s * h * d + 2 * b * lq * (h * l * (ctx.num_var + p)) + 2 * b * lq * h * d),  # noqa: E731
+                        30 * b * lq * h * l * p * d)
+        grid = (l == 1 and s == lq and s >= 1024)
+        with _prof.timed("box_bwd_kernel<32, true>" if grid else "box_bwd_kernel<32, false>", cost):
+            L.check(L.lib().efg_box_attn_fused_backward_f32(L.ptr(value), L.ptr(shapes.contiguous()),
+                                                            L.ptr(start.contiguous()), L.ptr(ref), L.ptr(offsets),
+                                                            L.ptr(logits), L.ptr(kidx), L.ptr(grad_output), b, s, h,
+                                                            d, l, lq, p, ctx.num_var, L.ptr(grad_value),
+                                                            L.ptr(grad_off), L.ptr(grad_logits), L.stream()))
+        return grad_value, None, None, None, grad_off, grad_logits, None, None

@@ -179,6 +179,27 @@ int efg_msda_backward_f32(const float* value, const int64_t* shapes, const int64
                           int d, int l, int lq, int p, float* grad_value, float* grad_loc, float* grad_attn,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused Box3dAttention sampling ($CQ/modules/box_attention.py:62-115): box geometry (centre / relu'd
+ * size / rotation from the reference window + raw offsets), softmax over the L*P logits and the
+ * bilinear sampling of efg_msda_* in one kernel -- the [B,Lq,H,L,P,2] grid and the softmaxed weights
+ * are never materialised.
+ *   ref_windows f32 [b,lq,7] (x,y,z,l,w,h,angle; only 0,1,3,4,6 are read)
+ *   offsets     f32 [b,lq,h,l,v]  raw linear output, v = 4 (no rotation) | 5 (angle offset)
+ *   logits      f32 [b,lq,h,l*p]  raw linear output (pre-softmax)
+ *   kernel_indices f32 [p,2]      the k x k lattice (x,y)
+ * backward: grad_value must be zero-filled; grad_offsets / grad_logits are fully written; d = 32 only.
+ * ---------------------------------------------------------------------------------------- */
+int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                   const float* ref_windows, const float* offsets, const float* logits,
+                                   const float* kernel_indices, int b, int s, int h, int d, int l, int lq, int p,
+                                   int v, float* out, void* stream);
+int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                    const float* ref_windows, const float* offsets, const float* logits,
+                                    const float* kernel_indices, const float* grad_out, int b, int s, int h, int d,
+                                    int l, int lq, int p, int v, float* grad_value, float* grad_offsets,
+                                    float* grad_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ def install():
         setattr(mod, name, fn)
 
     patch(L, "require_gpu", lambda *a: None)
+    patch(baf, "FUSED_ENABLED", False)  # CPU: the reference sequence (grid + softmax + sampling op)
 
     # ---- voxelization -------------------------------------------------------------------------
     def hard_launch(points, offsets, voxel_size, coors_range, max_points, max_voxels, voxels, coors, npv, voxel_num,

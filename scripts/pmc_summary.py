@@ -12,7 +12,8 @@ with open(path) as f:
         name = row["Kernel_Name"]
         if "efg::" not in name:
             continue
-        a = acc[name.split("(")[0]]
+        base = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        a = acc[base]
         a[0] += 1
         a[1] += float(row["Counter_Value"])
 print("kernel,launches,mean_%s,total_%s" % (ctr, ctr))
