@@ -33,15 +33,13 @@ def parse():
     return ap.parse_args()
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass
-    (profiles/pmc_latest.json, written by scripts/collect_pmc.py on the GPU box), or None."""
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
+    produced on the GPU box by scripts/round_profile.sh + scripts/pmc_to_json.py), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(path):
-        return None
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -128,7 +126,10 @@ def main():
         },
     }
     if rank == 0:
-        line["roofline"] = _prof.roofline(traffic_bytes_per_launch=_pmc_traffic())
+        roof = _prof.roofline()
+        if roof is not None:
+            roof["traffic"] = _pmc_traffic(roof["kernel"])
+        line["roofline"] = roof
         line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
                                "GBps_alg": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1),
                                "TFLOPs_alg": round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 2)}

@@ -1,0 +1,24 @@
+"""profiles/pmc_latest.json from the FETCH_SIZE / WRITE_SIZE summaries of scripts/round_profile.sh.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and on
+gfx950 FETCH_SIZE reports half of the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md §HBM), which
+is what all of these kernels issue; WRITE_SIZE is used as reported (uncalibrated per the same guide)."""
+import csv
+import json
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+vals = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    with open("%s/%s.summary.csv" % (src, ctr)) as f:
+        for row in csv.DictReader(f):
+            name = row["kernel"].replace("efg::", "").replace(";", ",")
+            vals.setdefault(name, {})[ctr] = float(row["mean_" + ctr])
+            vals[name]["launches_" + ctr] = int(row["launches"])
+out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+for name, v in vals.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out["kernels"][name] = {"hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+                                "FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"]}
+json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+print(len(out["kernels"]), "kernels ->", dst)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-end evidence on the GPU box: bench line, rocprofv3 kernel stats of the SAME command, PMC HBM traffic.
+# usage: scripts/round_profile.sh r01      -> gpurun_out/r01/{bench.json,kernel_stats.csv,FETCH_SIZE.summary.csv,...}
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/$tag; mkdir -p $out /tmp/$tag.ks
+python bench.py > $out/bench.json 2> $out/bench.stderr
+tail -c 600 $out/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$tag.ks -o r -- python bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/rocprof.stderr
+cp /tmp/$tag.ks/r_kernel_stats.csv $out/kernel_stats.csv
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/$tag.$ctr && mkdir -p /tmp/$tag.$ctr
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/$tag.$ctr -o r -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc.$ctr.stderr
+  python scripts/pmc_summary.py /tmp/$tag.$ctr/r_counter_collection.csv $ctr > $out/$ctr.summary.csv
+done
+head -4 $out/FETCH_SIZE.summary.csv $out/WRITE_SIZE.summary.csv

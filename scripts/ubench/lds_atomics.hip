@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, int stride) {
       else if (MODE == 6) { atomicAdd((double*)&buf[idx & ~1u], 1.0); }
       else if (MODE == 7) { __hip_atomic_fetch_add(&buf[idx], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       else if (MODE == 8) { atomicMax((int*)&buf[idx], it); }
+      else if (MODE == 9) { atomicAdd((unsigned long long*)&buf[idx & ~1u], 1ull); }
       else if (MODE == 4) { float4* p = (float4*)&buf[idx & ~3u]; float4 v = *p; v.x += 1; v.y += 1; v.z += 1; v.w += 1; *p = v; }
     }
   }
@@ -50,6 +51,7 @@ int main() {
     run<6>("ds_add_f64", stride);
     run<7>("hip_atomic wg-scope f32", stride);
     run<8>("ds_max_i32", stride);
+    run<9>("ds_add_u64", stride);
   }
   return 0;
 }
