@@ -74,7 +74,7 @@ def main():
 
     rank, local_rank, world = init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     overrides = {"model.transformer.num_queries": args.queries}
     if args.full_graph:
         overrides["model.eval_unused_levels"] = True

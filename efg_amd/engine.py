@@ -26,11 +26,12 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("EFG_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
