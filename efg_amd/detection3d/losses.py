@@ -1,5 +1,12 @@
-"""Set-prediction losses of Voxel-DETR / ConQueR ($CQ/losses.py): focal classification, L1 box /
-angle, axis-aligned 3-D GIoU, for matched queries, auxiliary layers and denoising groups."""
+"""Set-prediction losses of Voxel-DETR / ConQueR ($CQ/losses.py:26-214): focal classification, L1 box /
+angle and axis-aligned 3-D GIoU for matched queries, for every decoder layer (auxiliary outputs) and for
+the denoising groups.
+
+Same terms, keys and values as the reference, evaluated in BATCHED form: the reference loops over decoder
+layers x {matching, denoising} x {labels, boxes} x scenes with ~40 tiny kernels and one host round trip
+each (~1000 launches and 4 syncs per step at 3 layers); here all layers are stacked, matched with ONE
+cost-matrix transfer, and each loss family is one pass whose per-layer sums are read off a vector.
+"""
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -12,127 +19,138 @@ def get_world_size():
                                                   and torch.distributed.is_initialized()) else 1
 
 
-def _src_permutation_idx(indices):
-    batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-    src_idx = torch.cat([src for (src, _) in indices])
-    return batch_idx, src_idx
-
-
-class ClassificationLoss(nn.Module):
-    """$CQ/losses.py:26-73."""
-
-    def __init__(self, focal_alpha):
-        super().__init__()
-        self.focal_alpha = focal_alpha
-        self.target_classes = None
-        self.src_logits = None
-
-    def forward(self, outputs, targets, indices, num_boxes):
-        outputs["matched_indices"] = indices
-        src_logits = outputs["pred_logits"]
-        dev = src_logits.device
-        target_onehot = torch.zeros_like(src_logits)
-        idx = tuple(t.to(dev) for t in _src_permutation_idx(indices))
-        target_classes_o = torch.cat([t["labels"][J.to(dev)] for t, (_, J) in zip(targets, indices)])
-        self.target_classes = target_classes_o
-        if "topk_indexes" in outputs:
-            topk = outputs["topk_indexes"]
-            self.src_logits = torch.gather(src_logits, 1, topk.expand(-1, -1, src_logits.shape[-1]))[idx]
-            target_onehot[idx[0], topk[idx].squeeze(-1), target_classes_o] = 1
-        else:
-            self.src_logits = src_logits[idx]
-            target_onehot[idx[0], idx[1], target_classes_o] = 1
-        loss_ce = sigmoid_focal_loss(src_logits, target_onehot, alpha=self.focal_alpha, gamma=2.0,
-                                     reduction="sum") / num_boxes
-        return {"loss_ce": loss_ce}
-
-
-class RegressionLoss(nn.Module):
-    """$CQ/losses.py:76-108."""
-
-    def forward(self, outputs, targets, indices, num_boxes):
-        dev = outputs["pred_boxes"].device
-        idx = tuple(t.to(dev) for t in _src_permutation_idx(indices))
-        if "topk_indexes" in outputs:
-            pred_boxes = torch.gather(outputs["pred_boxes"], 1,
-                                      outputs["topk_indexes"].expand(-1, -1, outputs["pred_boxes"].shape[-1]))
-        else:
-            pred_boxes = outputs["pred_boxes"]
-        target_boxes = torch.cat([t["gt_boxes"][i.to(dev)] for t, (_, i) in zip(targets, indices)], dim=0)
-        src_boxes, src_rads = pred_boxes[idx].split(6, dim=-1)
-        target_boxes, target_rads = target_boxes.split(6, dim=-1)
-        loss_bbox = F.l1_loss(src_boxes, target_boxes, reduction="none")
-        loss_rad = F.l1_loss(src_rads, target_rads, reduction="none")
-        # 1 - diag(GIoU matrix) of the reference (:95-100), computed pairwise
-        loss_giou = 1 - paired_box3d_giou(box_cxcyczlwh_to_xyxyxy(src_boxes), box_cxcyczlwh_to_xyxyxy(target_boxes))
-        return {"loss_bbox": loss_bbox.sum() / num_boxes, "loss_giou": loss_giou.sum() / num_boxes,
-                "loss_rad": loss_rad.sum() / num_boxes}
+def _pad_targets(targets, device):
+    """labels [B,G] (0 padded), boxes [B,G,7], counts (host list)."""
+    counts = [int(t["labels"].numel()) for t in targets]
+    g = max(max(counts), 1)
+    labels = torch.zeros(len(targets), g, dtype=torch.int64, device=device)
+    boxes = torch.zeros(len(targets), g, 7, dtype=torch.float32, device=device)
+    for b, t in enumerate(targets):
+        labels[b, : counts[b]] = t["labels"]
+        boxes[b, : counts[b]] = t["gt_boxes"]
+    return labels, boxes, counts
 
 
 class Det3DLoss(nn.Module):
-    """$CQ/losses.py:111-214."""
+    """$CQ/losses.py:111-214 (+ ClassificationLoss :26-73, RegressionLoss :76-108)."""
 
-    def __init__(self, matcher, weight_dict, losses):
+    def __init__(self, matcher, weight_dict, losses, focal_alpha=0.25):
         super().__init__()
         self.matcher, self.weight_dict, self.losses = matcher, weight_dict, losses
-        self.det3d_losses = nn.ModuleDict()
-        self.det3d_enc_losses = nn.ModuleDict()
         for loss in losses:
-            if loss == "boxes":
-                self.det3d_losses[loss] = RegressionLoss()
-                self.det3d_enc_losses[loss + "_enc"] = RegressionLoss()
-            elif loss == "focal_labels":
-                self.det3d_losses[loss] = ClassificationLoss(0.25)
-                self.det3d_enc_losses[loss + "_enc"] = ClassificationLoss(0.25)
-            else:
+            if loss not in ("boxes", "focal_labels"):
                 raise ValueError(f"Only boxes|focal_labels are supported for det3d losses. Found {loss}")
+        self.focal_alpha = focal_alpha
+        self._metric_logits = self._metric_classes = None
 
     def get_target_classes(self):
-        for k in self.det3d_losses.keys():
-            if "labels" in k:
-                return self.det3d_losses[k].src_logits, self.det3d_losses[k].target_classes
+        """(matched logits, target classes) of the LAST matched layer, for the accuracy metric."""
+        return self._metric_logits, self._metric_classes
+
+    # ---- one loss family over stacked layers ------------------------------------------------------------
+    def _layer_losses(self, logits, boxes, sel, tgt_labels, tgt_boxes, num_boxes):
+        """logits [L,B,Q,C], boxes [L,B,Q,7]; sel = (l, b, q, g) int64 index vectors of the matched pairs.
+        Returns {"loss_ce","loss_bbox","loss_giou","loss_rad"} -> [L] vectors."""
+        l_idx, b_idx, q_idx, g_idx = sel
+        n_layers = logits.shape[0]
+        out = {}
+        cls = tgt_labels[b_idx, g_idx]
+        if "focal_labels" in self.losses:
+            onehot = torch.zeros_like(logits)
+            onehot[l_idx, b_idx, q_idx, cls] = 1
+            fl = sigmoid_focal_loss(logits, onehot, alpha=self.focal_alpha, gamma=2.0, reduction="none")
+            out["loss_ce"] = fl.sum(dim=(1, 2, 3)) / num_boxes
+        if "boxes" in self.losses:
+            src = boxes[l_idx, b_idx, q_idx]
+            tgt = tgt_boxes[b_idx, g_idx]
+            l1 = F.l1_loss(src, tgt, reduction="none")
+            giou = 1 - paired_box3d_giou(box_cxcyczlwh_to_xyxyxy(src[:, :6]), box_cxcyczlwh_to_xyxyxy(tgt[:, :6]))
+            per = torch.stack((l1[:, :6].sum(1), giou, l1[:, 6:].sum(1)), dim=1)  # [n, 3]
+            sums = per.new_zeros(n_layers, 3).index_add_(0, l_idx, per) / num_boxes
+            out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
+        return out, cls
 
     def forward(self, outputs, targets, dn_meta=None):
-        dev = next(iter(outputs.values())).device
-        num_boxes = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=dev)
+        dev = outputs["pred_logits"].device
+        n_gt = sum(len(t["labels"]) for t in targets)
         if get_world_size() > 1:
-            torch.distributed.all_reduce(num_boxes)
-        num_boxes = torch.clamp(num_boxes / get_world_size(), min=1).item() if get_world_size() > 1 else max(
-            float(sum(len(t["labels"]) for t in targets)), 1.0)
+            nb = torch.as_tensor([n_gt], dtype=torch.float, device=dev)
+            torch.distributed.all_reduce(nb)
+            num_boxes = torch.clamp(nb / get_world_size(), min=1).item()
+        else:
+            num_boxes = max(float(n_gt), 1.0)
+        tgt_labels, tgt_boxes, counts = _pad_targets(targets, dev)
+
+        # stack the layers: auxiliary outputs first, the final layer last
+        layers = list(outputs.get("aux_outputs", [])) + [outputs]
+        logits = torch.stack([o["pred_logits"] for o in layers])
+        boxes = torch.stack([o["pred_boxes"] for o in layers])
+        topk = outputs.get("topk_indexes")
+        if topk is not None:  # encoder proposals: the matcher and the box loss see the gathered top-k set
+            assert len(layers) == 1
+            m_logits = torch.gather(logits[0], 1, topk.expand(-1, -1, logits.shape[-1]))[None]
+            m_boxes = torch.gather(boxes[0], 1, topk.expand(-1, -1, boxes.shape[-1]))[None]
+        else:
+            m_logits, m_boxes = logits, boxes
+        indices = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L][B] (qi, gi)
+        outputs["matched_indices"] = indices[-1]
+        flat = [[], [], [], []]
+        for li, per_layer in enumerate(indices):
+            for b, (qi, gi) in enumerate(per_layer):
+                flat[0].append(torch.full_like(qi, li))
+                flat[1].append(torch.full_like(qi, b))
+                flat[2].append(qi)
+                flat[3].append(gi)
+        sel = torch.stack([torch.cat(f) for f in flat]).to(dev, non_blocking=True)  # one H2D
+        if topk is not None:
+            # classification targets live on the FULL token set at the positions the top-k picked
+            q_full = topk[sel[1], sel[2], 0]
+            ce, cls = self._layer_losses(logits, boxes, (sel[0], sel[1], q_full, sel[3]), tgt_labels, tgt_boxes,
+                                         num_boxes)
+            bx, _ = self._layer_losses(m_logits, m_boxes, tuple(sel), tgt_labels, tgt_boxes, num_boxes)
+            per_layer = {"loss_ce": ce["loss_ce"], **{k: v for k, v in bx.items() if k != "loss_ce"}}
+            self._metric_logits = m_logits[sel[0], sel[1], sel[2]]
+        else:
+            per_layer, cls = self._layer_losses(logits, boxes, tuple(sel), tgt_labels, tgt_boxes, num_boxes)
+            last = sel[0] == (len(layers) - 1)
+            self._metric_logits = logits[-1][sel[1][last], sel[2][last]]
+            cls = cls[last]
+        self._metric_classes = cls
+
         losses = {}
+        n_aux = len(layers) - 1
+        for k, v in per_layer.items():
+            for i in range(n_aux):
+                losses[k + f"_{i}"] = v[i]
+            losses[k] = v[n_aux]
+
         if dn_meta is not None:
             known = dn_meta["output_known_lbs_bboxes"]
             scalar, pad_size = dn_meta["num_dn_group"], dn_meta["pad_size"]
             assert pad_size % scalar == 0
             single_pad = pad_size // scalar
-            dn_pos_idx = []
-            for tgt in targets:
-                n = len(tgt["labels"])
+            dn_layers = list(known.get("aux_outputs", [])) + [known]
+            dn_logits = torch.stack([o["pred_logits"] for o in dn_layers])
+            dn_boxes = torch.stack([o["pred_boxes"] for o in dn_layers])
+            b_l, q_l, g_l = [], [], []
+            for b, n in enumerate(counts):
                 if n > 0:
                     # quirk kept: arange(0, n - 1) leaves the LAST GT of every scene out of the DN loss (:161)
                     t = torch.arange(0, n - 1).long().unsqueeze(0).repeat(scalar, 1)
-                    tgt_idx = t.flatten()
-                    output_idx = ((torch.arange(scalar) * single_pad).long().unsqueeze(1) + t).flatten()
-                else:
-                    output_idx = tgt_idx = torch.tensor([]).long()
-                dn_pos_idx.append((output_idx, tgt_idx))
-            l_dict = {}
-            for loss in self.losses:
-                l_dict.update(self.det3d_losses[loss](known, targets, dn_pos_idx, num_boxes * scalar))
-            losses.update({k + "_dn": v for k, v in l_dict.items()})
-        if "aux_outputs" in outputs:
-            for i, aux_outputs in enumerate(outputs["aux_outputs"]):
-                indices = self.matcher(aux_outputs, targets)
-                for loss in self.losses:
-                    l_dict = self.det3d_losses[loss](aux_outputs, targets, indices, num_boxes)
-                    losses.update({k + f"_{i}": v for k, v in l_dict.items()})
-                if dn_meta is not None:
-                    aux_known = known["aux_outputs"][i]
-                    l_dict = {}
-                    for loss in self.losses:
-                        l_dict.update(self.det3d_losses[loss](aux_known, targets, dn_pos_idx, num_boxes * scalar))
-                    losses.update({k + f"_dn_{i}": v for k, v in l_dict.items()})
-        indices = self.matcher(outputs, targets)
-        for loss in self.losses:
-            losses.update(self.det3d_losses[loss](outputs, targets, indices, num_boxes))
+                    q_l.append(((torch.arange(scalar) * single_pad).long().unsqueeze(1) + t).flatten())
+                    g_l.append(t.flatten())
+                    b_l.append(torch.full((t.numel(),), b, dtype=torch.int64))
+            if b_l:
+                b_i, q_i, g_i = torch.cat(b_l), torch.cat(q_l), torch.cat(g_l)
+            else:
+                b_i = q_i = g_i = torch.zeros(0, dtype=torch.int64)
+            nl = len(dn_layers)
+            sel_dn = torch.stack([torch.arange(nl).repeat_interleave(b_i.numel()), b_i.repeat(nl), q_i.repeat(nl),
+                                  g_i.repeat(nl)]).to(dev, non_blocking=True)
+            dn_per_layer, _ = self._layer_losses(dn_logits, dn_boxes, tuple(sel_dn), tgt_labels, tgt_boxes,
+                                                 num_boxes * scalar)
+            for k, v in dn_per_layer.items():
+                for i in range(nl - 1):
+                    losses[k + f"_dn_{i}"] = v[i]
+                losses[k + "_dn"] = v[nl - 1]
         return losses

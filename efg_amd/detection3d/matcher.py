@@ -5,7 +5,7 @@ import torch
 from scipy.optimize import linear_sum_assignment
 from torch import nn
 
-from .utils import box_cxcyczlwh_to_xyxyxy, generalized_box3d_iou
+from .utils import box_cxcyczlwh_to_xyxyxy, generalized_box3d_iou, pairwise_box3d_giou
 
 
 class HungarianMatcher3d(nn.Module):
@@ -40,6 +40,37 @@ class HungarianMatcher3d(nn.Module):
             mats.append(self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou +
                         self.cost_rad * cost_rad)
         return mats
+
+    @torch.no_grad()
+    def match_layers(self, logits, boxes, tgt_labels, tgt_boxes, counts):
+        """All decoder layers and scenes at once.  logits [L,B,Q,C], boxes [L,B,Q,7]; padded targets
+        tgt_labels [B,G], tgt_boxes [B,G,7] with `counts[b]` valid columns.  Same cost as `cost_matrices`
+        ($CQ/modules/matcher.py:40-80); ONE device->host transfer, then scipy per (layer, scene).
+        Returns [L][B] (query_idx, gt_idx) int64 CPU tensors."""
+        n_layers, bs, nq = logits.shape[:3]
+        g = tgt_labels.shape[1]
+        out_prob = logits.sigmoid().float()
+        out_bbox, out_rad = boxes.float().split(6, dim=-1)
+        alpha, gamma = 0.25, 2.0
+        neg_cost = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
+        pos_cost = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
+        lab = tgt_labels[None, :, None, :].expand(n_layers, bs, nq, g)
+        cost_class = torch.gather(pos_cost, 3, lab) - torch.gather(neg_cost, 3, lab)
+        tb, tr = tgt_boxes[..., :6].float(), tgt_boxes[..., 6:].float()
+        cost_bbox = (out_bbox[:, :, :, None, :] - tb[None, :, None, :, :]).abs().sum(-1)
+        cost_rad = (out_rad[:, :, :, None, :] - tr[None, :, None, :, :]).abs().sum(-1)
+        cost_giou = -pairwise_box3d_giou(box_cxcyczlwh_to_xyxyxy(out_bbox), box_cxcyczlwh_to_xyxyxy(tb)[None])
+        cost = (self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou +
+                self.cost_rad * cost_rad)
+        host = cost.cpu().numpy()  # the one D2H of this call
+        out = []
+        for li in range(n_layers):
+            per = []
+            for b in range(bs):
+                i, j = linear_sum_assignment(host[li, b, :, : counts[b]])
+                per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+            out.append(per)
+        return out
 
     @torch.no_grad()
     def forward(self, outputs, targets):

@@ -55,6 +55,20 @@ def generalized_box3d_iou(boxes1, boxes2):
     return iou - (vol - union) / vol
 
 
+def pairwise_box3d_giou(boxes1, boxes2):
+    """generalized_box3d_iou with leading batch dims: boxes1 [..., N, 6], boxes2 [..., M, 6] -> [..., N, M]."""
+    boxes1 = torch.nan_to_num(boxes1)[..., :, None, :]
+    boxes2 = torch.nan_to_num(boxes2)[..., None, :, :]
+    vol1 = (boxes1[..., 3] - boxes1[..., 0]) * (boxes1[..., 4] - boxes1[..., 1]) * (boxes1[..., 5] - boxes1[..., 2])
+    vol2 = (boxes2[..., 3] - boxes2[..., 0]) * (boxes2[..., 4] - boxes2[..., 1]) * (boxes2[..., 5] - boxes2[..., 2])
+    lwh = (torch.min(boxes1[..., 3:], boxes2[..., 3:]) - torch.max(boxes1[..., :3], boxes2[..., :3])).clamp(min=0)
+    inter = lwh[..., 0] * lwh[..., 1] * lwh[..., 2]
+    union = vol1 + vol2 - inter
+    whl = (torch.max(boxes1[..., 3:], boxes2[..., 3:]) - torch.min(boxes1[..., :3], boxes2[..., :3])).clamp(min=0)
+    vol = whl[..., 0] * whl[..., 1] * whl[..., 2]
+    return inter / union - (vol - union) / vol
+
+
 def paired_box3d_giou(boxes1, boxes2):
     """Row-wise GIoU (the diagonal of generalized_box3d_iou, without building the matrix)."""
     boxes1 = torch.nan_to_num(boxes1)
