@@ -72,15 +72,16 @@ struct ConvArgs {
   int np;              // round16(cout)
 };
 
-template <int NT>
+template <int NT, int KV = 32>
 __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
-  __shared__ float a_tile[4][2][16 * kAStride];
-  __shared__ int nbr_tile[4][kMaxKvol * 16];
+  // wave-private staging: ONE A tile per wave (the wave itself orders compute -> refill; the prefetch
+  // lives in registers) and the wave's rulebook block; 21 KB per workgroup for KV = 32
+  __shared__ float a_tile[4][16 * kAStride];
+  __shared__ int nbr_tile[4][KV * 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long r0 = ((long long)blockIdx.x * 4 + wv) * 16;
   if (r0 >= a.m_out) return;  // whole wave out of range (waves never sync with each other)
-  float* at0 = a_tile[wv][0];
-  float* at1 = a_tile[wv][1];
+  float* at0 = a_tile[wv];
   int* nb = nbr_tile[wv];
   const int n_tile0 = blockIdx.y * NT;  // first n-tile of this block
 
@@ -111,12 +112,17 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
 
   // gather of (k, chunk) into registers: row j of the wave -> pre[j] (lane = channel)
   auto gather = [&](int k, int ch) {
+    // Branch-free: a predicated load compiles to a branch + its own basic block, and the waitcnt pass then
+    // serialises the 16 loads (one s_waitcnt vmcnt(0) per load).  Clamp the address, load always, select.
     const int c = ch * kCK + lane;
+    const int cc = min(c, a.cin - 1);
+    int rows[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = nb[k * 16 + j];
-      pre[j] = (row >= 0 && c < a.cin) ? a.in[(long long)row * a.cin + c] : 0.0f;
-    }
+    for (int j = 0; j < 16; ++j) rows[j] = nb[k * 16 + j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pre[j] = a.in[(long long)max(rows[j], 0) * a.cin + cc];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pre[j] = (rows[j] >= 0 && c < a.cin) ? pre[j] : 0.0f;
   };
   auto stash = [&](float* at) {
 #pragma unroll
@@ -130,14 +136,19 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
       const float* ap = at + m * kAStride + (c16 - c16_lo) * 16 + kk;
       const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
       const float* bp = a.wp + (((long long)k * a.c16n + c16) * a.np + n_tile0 * 16 + m) * 16 + kk * 4;
+      float4 b[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float4 b = *reinterpret_cast<const float4*>(bp + t * 256);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b.w, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(bp + t * 256);
+      // k-step outer, n-tile inner: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA
+      // issues every 32 cycles but its result is ready after 40)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[t].w, acc[t], 0, 0, 0);
     }
   };
 
@@ -160,8 +171,10 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
       if (more) gather(k_nxt, ch_nxt);  // global loads in flight during the MFMAs below
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      compute((s & 1) ? at1 : at0, k_cur, ch_cur);
-      if (more) stash((s & 1) ? at0 : at1);
+      compute(at0, k_cur, ch_cur);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all fragment reads done before the refill
+      if (more) stash(at0);
       k_cur = k_nxt;
       ch_cur = ch_nxt;
     }
@@ -218,16 +231,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 
   auto process = [&](int head) {
     __syncthreads();  // queue entries visible; previous tile fully consumed
+    const int gco = min(co0 + lane, a.cout - 1), gci = min(ci0 + lane, a.cin - 1);
 #pragma unroll 4
     for (int j = wv; j < 64; j += 4) {
+      // branch-free loads (clamped address, select afterwards): see conv_fwd_kernel::gather
       const int o = q_out[head + j], i = q_in[head + j];
-      float g = 0.f, x = 0.f;
-      if (o >= 0) {
-        if (co0 + lane < a.cout) g = a.go[(long long)o * a.cout + co0 + lane];
-        if (ci0 + lane < a.cin) x = a.in[(long long)i * a.cin + ci0 + lane];
-      }
-      g_tile[j * kWStride + lane] = g;
-      x_tile[j * kWStride + lane] = x;
+      const float g = a.go[(long long)max(o, 0) * a.cout + gco];
+      const float x = a.in[(long long)max(i, 0) * a.cin + gci];
+      g_tile[j * kWStride + lane] = (o >= 0 && co0 + lane < a.cout) ? g : 0.f;
+      x_tile[j * kWStride + lane] = (o >= 0 && ci0 + lane < a.cin) ? x : 0.f;
     }
     __syncthreads();
     // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles; reduction dim = pairs, 4 per MFMA
@@ -343,7 +355,8 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
 template <int NT>
 void launch_fwd(const ConvArgs& a, int nblk_y, hipStream_t stream) {
   const unsigned gx = (unsigned)ceil_div(a.m_out, 64);
-  hipLaunchKernelGGL((conv_fwd_kernel<NT>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
+  if (a.kvol <= 32) hipLaunchKernelGGL((conv_fwd_kernel<NT, 32>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_fwd_kernel<NT, kMaxKvol>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
 }
 
 int run_conv(const float* in, int cin, const float* wp, const float* bias, int cout, int kvol, const int* nbr,
