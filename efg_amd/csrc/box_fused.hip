@@ -10,12 +10,14 @@
 // Same lane mapping as msda.hip (LP = D/4 lanes x float4 per pair); encoder self-attention
 // (queries on the value grid) accumulates grad_value in an fp64 LDS window like msda_bwd_grid_kernel.
 #include "common.h"
+#include <cmath>
 
 namespace efg {
 namespace {
 
 constexpr int kMaxLevels = 8;
 constexpr int kMaxPts = 128;  // L * P upper bound for the fused path (LDS scratch)
+constexpr int kSoftmaxLds = 4096;  // floats: (pairs per workgroup) x (L*P) must fit
 constexpr float kTwoPi = 6.283185307179586f;
 
 struct BoxDims {
@@ -80,11 +82,24 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   const int row_stride = dm.h * dm.d;
   const int np = dm.l * dm.p;
   const float* lg = logits + tt * np;
+  // softmax over the L*P logits of the pair, shared by its LP lanes: each lane exponentiates every LP-th
+  // logit, the weights go through LDS (the redundant form costs 2*L*P expf per lane)
+  __shared__ float a_s[kSoftmaxLds];
+  const int sub = lane & (dm.lp - 1);
+  float* as = a_s + (threadIdx.x >> dm.lp_shift) * np;
   float mx = -INFINITY;
-  for (int e = 0; e < np; ++e) mx = fmaxf(mx, lg[e]);
+  for (int e = sub; e < np; e += dm.lp) mx = fmaxf(mx, lg[e]);
+  for (int dlt = dm.lp >> 1; dlt > 0; dlt >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
   float den = 0.0f;
-  for (int e = 0; e < np; ++e) den += expf(lg[e] - mx);
+  for (int e = sub; e < np; e += dm.lp) {
+    const float ex = expf(lg[e] - mx);
+    as[e] = ex;
+    den += ex;
+  }
+  for (int dlt = dm.lp >> 1; dlt > 0; dlt >>= 1) den += __shfl_xor(den, dlt, 64);
   const float inv = 1.0f / den;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int li = 0; li < dm.l; ++li) {
     const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
@@ -94,7 +109,7 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
       const float gx = kidx[pi * 2] * g.w, gy = kidx[pi * 2 + 1] * g.h;
       const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
       const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
-      const float wgt = expf(lg[li * dm.p + pi] - mx) * inv;
+      const float wgt = as[li * dm.p + pi] * inv;
       const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
       const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
       const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
@@ -102,14 +117,16 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
         const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
         const float hh = 1.f - lh, hw = 1.f - lwf;
-        const float w1 = hh * hw, w2 = hh * lwf, w3 = lh * hw, w4 = lh * lwf;
         const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-        const long long o1 = ((long long)h_low * W + w_low) * row_stride;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v1 = (t_ok && l_ok) ? ld4(v + o1) : z;
-        const float4 v2 = (t_ok && r_ok) ? ld4(v + o1 + row_stride) : z;
-        const float4 v3 = (b_ok && l_ok) ? ld4(v + o1 + (long long)W * row_stride) : z;
-        const float4 v4 = (b_ok && r_ok) ? ld4(v + o1 + (long long)W * row_stride + row_stride) : z;
+        // branch-free corner loads: clamp the address, always load, zero the WEIGHT of an outside corner
+        // (a predicated load becomes a branch and the four loads then wait for each other)
+        const int y0 = max(h_low, 0), y1 = min(h_low + 1, H - 1), x0 = max(w_low, 0), x1 = min(w_low + 1, W - 1);
+        const float4 v1 = ld4(v + ((long long)y0 * W + x0) * row_stride);
+        const float4 v2 = ld4(v + ((long long)y0 * W + x1) * row_stride);
+        const float4 v3 = ld4(v + ((long long)y1 * W + x0) * row_stride);
+        const float4 v4 = ld4(v + ((long long)y1 * W + x1) * row_stride);
+        const float w1 = (t_ok && l_ok) ? hh * hw : 0.f, w2 = (t_ok && r_ok) ? hh * lwf : 0.f;
+        const float w3 = (b_ok && l_ok) ? lh * hw : 0.f, w4 = (b_ok && r_ok) ? lh * lwf : 0.f;
         acc.x = fmaf(bil(w1, w2, w3, w4, v1.x, v2.x, v3.x, v4.x), wgt, acc.x);
         acc.y = fmaf(bil(w1, w2, w3, w4, v1.y, v2.y, v3.y, v4.y), wgt, acc.y);
         acc.z = fmaf(bil(w1, w2, w3, w4, v1.z, v2.z, v3.z, v4.z), wgt, acc.z);
@@ -124,7 +141,7 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
 // One (query, head) pair per LP-lane group.  kWin: queries are the cells of a single-level value map
 // (encoder self-attention); the workgroup then owns an 8x8 query tile of one head and accumulates
 // grad_value for the 16x16 window around it in fp64 LDS (see msda.hip for the measurements).
-template <int D, bool kWin>
+template <int D, bool kWin, int PTS = kMaxPts>
 __global__ void __launch_bounds__(256)
 box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
                const long long* __restrict__ starts, const float* __restrict__ ref, const float* __restrict__ off,
@@ -134,7 +151,8 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   constexpr int LP = D / 4, SLOTS = 256 / LP;
   constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R;
   __shared__ double win[kWin ? WIN * WIN * D : 1];
-  __shared__ float ga_s[SLOTS][kMaxPts];
+  __shared__ float ga_s[SLOTS][PTS];
+  __shared__ float a_s[SLOTS][PTS];  // un-normalised softmax weights of the pair
   const int sub = threadIdx.x % LP, slot = threadIdx.x / LP;
   const int c0 = sub * 4;
   const int rot = (slot + sub) & 3;
@@ -145,15 +163,20 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   if (kWin) {
     Hm = (int)shapes[0];
     Wm = (int)shapes[1];
-    const int tiles_x = (Wm + TQ - 1) / TQ;
-    if ((long long)Hm * Wm != dm.s || (int)blockIdx.x >= ((Hm + TQ - 1) / TQ) * tiles_x) return;
-    ty0 = (blockIdx.x / tiles_x) * TQ;
-    tx0 = (blockIdx.x % tiles_x) * TQ;
-    wy0 = ty0 - R;
-    wx0 = tx0 - R;
+    if ((long long)Hm * Wm != dm.s) return;
     m_fixed = blockIdx.y;
     bi_fixed = blockIdx.z;
     passes = TQ * TQ / SLOTS;
+  }
+  const int tiles_x = kWin ? (Wm + TQ - 1) / TQ : 1;
+  const int ntiles = kWin ? ((Hm + TQ - 1) / TQ) * tiles_x : 1;
+  for (int tile = kWin ? blockIdx.x : 0; tile < ntiles; tile += kWin ? gridDim.x : 1) {
+  if (kWin) {
+    ty0 = (tile / tiles_x) * TQ;
+    tx0 = (tile % tiles_x) * TQ;
+    wy0 = ty0 - R;
+    wx0 = tx0 - R;
+    __syncthreads();  // previous tile's window flushed
     for (int i = threadIdx.x; i < WIN * WIN * D; i += 256) win[i] = 0.0;
     __syncthreads();
   }
@@ -177,11 +200,22 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     const long long bq = t / dm.h;
     const int bi = (int)(bq / dm.lq);
     const float* lg = logits + t * np;
+    float* as = a_s[slot];
     float mx = -INFINITY;
-    for (int e = 0; e < np; ++e) mx = fmaxf(mx, lg[e]);
+    for (int e = sub; e < np; e += LP) mx = fmaxf(mx, lg[e]);
+#pragma unroll
+    for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
     float den = 0.0f;
-    for (int e = 0; e < np; ++e) den += expf(lg[e] - mx);
+    for (int e = sub; e < np; e += LP) {
+      const float ex = expf(lg[e] - mx);
+      as[e] = ex;
+      den += ex;
+    }
+#pragma unroll
+    for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) den += __shfl_xor(den, dlt, 64);
     const float inv = 1.0f / den;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float4 top = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) top = ld4(grad_out + t * dm.d + c0);
     float dot = 0.0f;  // sum_p a_p * ga_p (softmax backward)
@@ -197,7 +231,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
         const float gx = kxn * g.w, gy = kyn * g.h;
         const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
         const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
-        const float wgt = expf(lg[li * dm.p + pi] - mx) * inv;
+        const float wgt = as[li * dm.p + pi] * inv;
         const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
         const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
         const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
@@ -210,13 +244,17 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
           const float4 tv = make_float4(top.x * wgt, top.y * wgt, top.z * wgt, top.w * wgt);
           float4 vv[4];
 #pragma unroll
+          for (int cn = 0; cn < 4; ++cn) {  // branch-free loads: clamped address, select afterwards
+            const int cy = min(max(h_low + (cn >> 1), 0), H - 1), cx = min(max(w_low + (cn & 1), 0), W - 1);
+            vv[cn] = ld4(v + ((long long)cy * W + cx) * row_stride);
+          }
+#pragma unroll
           for (int cn = 0; cn < 4; ++cn) {
             const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
             const bool ok = cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1;
-            vv[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!ok) vv[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
               const long long o = ((long long)cy * W + cx) * row_stride;
-              vv[cn] = ld4(v + o);
               const float gq[4] = {wc[cn] * tv.x, wc[cn] * tv.y, wc[cn] * tv.z, wc[cn] * tv.w};
               const int ly = cy - wy0, lx = cx - wx0;
               if (kWin && (unsigned)ly < (unsigned)WIN && (unsigned)lx < (unsigned)WIN) {
@@ -245,12 +283,9 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
           ghl = (float)H * fmaf(ghw, tv.w, fmaf(ghz, tv.z, fmaf(ghy, tv.y, ghx * tv.x)));
         }
 #pragma unroll
-        for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) {
-          ga += __shfl_xor(ga, dlt, 64);
-          gwl += __shfl_xor(gwl, dlt, 64);
-          ghl += __shfl_xor(ghl, dlt, 64);
-        }
-        // chain rule through grid = centre + R(theta) . (k * size)
+        for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) ga += __shfl_xor(ga, dlt, 64);
+        // chain rule through grid = centre + R(theta) . (k * size); gwl / ghl are this lane's share (its 4
+        // channels) -- the sums over points stay lane-partial and are reduced across the LP lanes once
         dcx += gwl;
         dcy += ghl;
         dw += kxn * (gwl * g.cs + ghl * g.sn);
@@ -258,6 +293,14 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
         dth += gwl * (-(gx * g.sn) - gy * g.cs) + ghl * (gx * g.cs - gy * g.sn);
         dot = fmaf(wgt, ga, dot);
         if (sub == 0) ga_s[slot][li * dm.p + pi] = ga;
+      }
+#pragma unroll
+      for (int dlt = LP >> 1; dlt > 0; dlt >>= 1) {
+        dcx += __shfl_xor(dcx, dlt, 64);
+        dcy += __shfl_xor(dcy, dlt, 64);
+        dw += __shfl_xor(dw, dlt, 64);
+        dh += __shfl_xor(dh, dlt, 64);
+        dth += __shfl_xor(dth, dlt, 64);
       }
       if (qok && sub == 0) {
         float* go = grad_off + (t * dm.l + li) * dm.v;
@@ -272,10 +315,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // softmax backward: d logit_p = a_p * (ga_p - sum_j a_j ga_j); the LP lanes of the pair share the work
     if (qok) {
-      for (int e = sub; e < np; e += LP) {
-        const float a = expf(lg[e] - mx) * inv;
-        grad_logits[t * np + e] = a * (ga_s[slot][e] - dot);
-      }
+      for (int e = sub; e < np; e += LP) grad_logits[t * np + e] = as[e] * inv * (ga_s[slot][e] - dot);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -292,6 +332,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
       }
     }
   }
+  }  // tile loop
 }
 
 int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) {
@@ -304,6 +345,8 @@ int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) 
     lp <<= 1;
     ++sh;
   }
+  EFG_CHECK_ARG((256 / lp) * l * p <= kSoftmaxLds, "box_attn_fused: (256/(d/4)) * L*P = %d exceeds the LDS scratch (%d)",
+                (256 / lp) * l * p, kSoftmaxLds);
   *dm = BoxDims{b, s, h, d, l, lq, p, v, lp, sh};
   return EFG_OK;
 }
@@ -340,10 +383,18 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
   const long long total = (long long)b * lq * h;
   if (total == 0) return EFG_OK;
   if (l == 1 && s == lq && s >= 1024 && h <= 65535 && b <= 65535) {
-    const unsigned tiles_ub = (unsigned)(s / 64 + (s + 1) / 8 + 2);  // covers every H x W = S (see msda.hip)
-    hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_ub, h, b), dim3(256), 0, (hipStream_t)stream, value,
-                       (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
-                       kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
+    // encoder self-attention (queries on the value map): fp64 LDS window per 8x8 query tile.  H, W are
+    // device-side, so the launch is sized for a square map and the kernel strides over the tiles.
+    const int side = (int)std::ceil(std::sqrt((double)s));
+    const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
+    if (l * p <= 32)
+      hipLaunchKernelGGL((box_bwd_kernel<32, true, 32>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
+                         value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
+                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
+    else
+      hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
+                         value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
+                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
   } else {
     hipLaunchKernelGGL((box_bwd_kernel<32, false>), dim3((unsigned)ceil_div(total, 32)), dim3(256), 0,
                        (hipStream_t)stream, value, (const long long*)shapes, (const long long*)level_start,

@@ -14,6 +14,7 @@
 // across the LP lanes with DPP shuffles (no LDS, no serial thread-0 sum) and accumulates
 // grad_value with hardware fp32 atomics (global_atomic_add_f32).
 #include "common.h"
+#include <cmath>
 
 namespace efg {
 namespace {
@@ -104,11 +105,18 @@ msda_kernel(const float* __restrict__ value, const long long* __restrict__ shape
         const long long o2 = o1 + row_stride;
         const long long o3 = o1 + (long long)W * row_stride;
         const long long o4 = o3 + row_stride;
+        // branch-free corner loads (clamped address, select afterwards): a predicated load becomes a branch
+        // and the four loads then wait for each other
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v1 = (t_ok && l_ok) ? ld4(v + o1) : z;
-        const float4 v2 = (t_ok && r_ok) ? ld4(v + o2) : z;
-        const float4 v3 = (b_ok && l_ok) ? ld4(v + o3) : z;
-        const float4 v4 = (b_ok && r_ok) ? ld4(v + o4) : z;
+        const int y0 = max(h_low, 0), y1 = min(h_high, H - 1), x0 = max(w_low, 0), x1 = min(w_high, W - 1);
+        const float4 u1 = ld4(v + ((long long)y0 * W + x0) * row_stride);
+        const float4 u2 = ld4(v + ((long long)y0 * W + x1) * row_stride);
+        const float4 u3 = ld4(v + ((long long)y1 * W + x0) * row_stride);
+        const float4 u4 = ld4(v + ((long long)y1 * W + x1) * row_stride);
+        const float4 v1 = (t_ok && l_ok) ? u1 : z;
+        const float4 v2 = (t_ok && r_ok) ? u2 : z;
+        const float4 v3 = (b_ok && l_ok) ? u3 : z;
+        const float4 v4 = (b_ok && r_ok) ? u4 : z;
         float4 val;
         val.x = bil(w1, w2, w3, w4, v1.x, v2.x, v3.x, v4.x);
         val.y = bil(w1, w2, w3, w4, v1.y, v2.y, v3.y, v4.y);
@@ -185,16 +193,20 @@ msda_bwd_grid_kernel(const float* __restrict__ value, const float* __restrict__ 
   // the map shape lives on the device (int64 [1,2]); the grid is an upper bound over all H x W = S
   const int Hm = (int)shapes[0], Wm = (int)shapes[1];
   if ((long long)Hm * Wm != s_total) return;  // host dispatch guarantees this; defensive
-  if ((int)blockIdx.x >= ((Hm + TQ - 1) / TQ) * ((Wm + TQ - 1) / TQ)) return;
+  const int ntiles = ((Hm + TQ - 1) / TQ) * ((Wm + TQ - 1) / TQ);
+  // the launch is sized for a square map and strides over the tiles: every H x W = S is covered without
+  // a host read-back and without thousands of empty (64 KB LDS) workgroups
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   constexpr int SLOTS = 256 / LP;            // (query, head) pairs in flight per pass
   constexpr int PASSES = TQ * TQ / SLOTS;
   // fp64 accumulators: ds_add_f64 is native on gfx950 (3.1 lane-ops/clk/CU measured) while ds_add_f32
   // runs at 0.33 -- a 10x slower path (scripts/ubench/lds_atomics.hip)
   __shared__ double win[WIN * WIN * D];
   const int tiles_x = (Wm + TQ - 1) / TQ;
-  const int ty0 = (blockIdx.x / tiles_x) * TQ, tx0 = (blockIdx.x % tiles_x) * TQ;
+  const int ty0 = (tile / tiles_x) * TQ, tx0 = (tile % tiles_x) * TQ;
   const int wy0 = ty0 - R, wx0 = tx0 - R;
   const int m = blockIdx.y, bi = blockIdx.z;
+  __syncthreads();  // previous tile's window flushed
   const int lane = threadIdx.x & 63;
   const int sub = threadIdx.x % LP;          // float4 group of this lane
   const int slot = threadIdx.x / LP;
@@ -230,13 +242,17 @@ msda_bwd_grid_kernel(const float* __restrict__ value, const float* __restrict__ 
         const float4 tv = make_float4(top.x * wgt, top.y * wgt, top.z * wgt, top.w * wgt);
         float4 vv[4];
 #pragma unroll
+        for (int cn = 0; cn < 4; ++cn) {  // branch-free loads: clamped address, select afterwards
+          const int cy = min(max(h_low + (cn >> 1), 0), Hm - 1), cx = min(max(w_low + (cn & 1), 0), Wm - 1);
+          vv[cn] = ld4(v + ((long long)cy * Wm + cx) * row_stride);
+        }
+#pragma unroll
         for (int cn = 0; cn < 4; ++cn) {
           const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
           const bool ok = cy >= 0 && cy <= Hm - 1 && cx >= 0 && cx <= Wm - 1;
-          vv[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!ok) vv[cn] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ok) {
             const long long o = ((long long)cy * Wm + cx) * row_stride;
-            vv[cn] = ld4(v + o);
             const float g[4] = {wc[cn] * tv.x, wc[cn] * tv.y, wc[cn] * tv.z, wc[cn] * tv.w};
             const int ly = cy - wy0, lx = cx - wx0;
             if ((unsigned)ly < (unsigned)WIN && (unsigned)lx < (unsigned)WIN) {
@@ -290,6 +306,7 @@ msda_bwd_grid_kernel(const float* __restrict__ value, const float* __restrict__ 
         unsafeAtomicAdd(grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * nh + m) * D + ch, g);
     }
   }
+  }  // tile loop
 }
 
 int check_dims(int b, int s, int h, int d, int l, int lq, int p, MsdaDims* dm) {
@@ -336,10 +353,10 @@ extern "C" int efg_msda_backward_f32(const float* value, const int64_t* shapes, 
   if (total == 0) return EFG_OK;
   if (l == 1 && d == 32 && s == lq && s >= 1024 && h <= 65535 && b <= 65535) {
     // queries on the value grid (encoder self-attention): LDS-window accumulation.  H and W are
-    // device-side (int64), so the launch covers the largest tile count any H x W = S can have
-    // (<= S/64 + (S+1)/8 + 2) and surplus workgroups exit at once: no host sync.
-    const unsigned tiles_ub = (unsigned)(s / 64 + (s + 1) / 8 + 2);
-    hipLaunchKernelGGL((msda_bwd_grid_kernel<32>), dim3(tiles_ub, h, b), dim3(256), 0, (hipStream_t)stream, value, loc,
+    // device-side (int64): the launch is sized for a square map and the kernel strides over the tiles.
+    const int side = (int)std::ceil(std::sqrt((double)s));
+    const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
+    hipLaunchKernelGGL((msda_bwd_grid_kernel<32>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream, value, loc,
                        attn, grad_out, (const long long*)shapes, b, h, (long long)s, p, grad_value, grad_loc,
                        grad_attn);
     EFG_LAUNCH_CHECK();

@@ -124,6 +124,9 @@ class Transformer(nn.Module):
     def _create_ref_windows(self, tensor_list):
         """Fixed anchors per BEV token: (x, y, z=0.5, l=w=0.025, h=0.5, angle=0) (:36-58)."""
         device = tensor_list[0].device
+        key = (tuple(tuple(t.shape[0:1]) + tuple(t.shape[2:]) for t in tensor_list), device)
+        if getattr(self, "_ref_cache_key", None) == key:  # constants of the BEV shape: build once
+            return self._ref_cache
         ref_windows = []
         for tensor in tensor_list:
             B, _, H, W = tensor.shape
@@ -136,7 +139,8 @@ class Transformer(nn.Module):
             ref_wh = torch.ones_like(ref_xy) * 0.025
             ph = torch.zeros_like(ref_xy)[..., :1]
             ref_windows.append(torch.cat((ref_xy, ph + 0.5, ref_wh, ph + 0.5, ph), -1).expand(B, -1, -1))
-        return torch.cat(ref_windows, dim=1)
+        self._ref_cache_key, self._ref_cache = key, torch.cat(ref_windows, dim=1).contiguous()
+        return self._ref_cache
 
     def _get_enc_proposals(self, enc_embed, ref_windows):
         """top-k (unsorted, :65) proposals of the 1-class proposal head, detached (:60-81)."""

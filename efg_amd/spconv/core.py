@@ -79,7 +79,7 @@ def _conv_forward(features, w, bias, rb):
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-    with _prof.timed(_fwd_kernel_name(cout, rb.m_out), lambda: _conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cout, rb.m_out), _Cost(rb, cin, cout, "fwd")):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
                                            L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
     return out
@@ -93,7 +93,7 @@ def _conv_dgrad(grad_out, w, rb):
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     rnbr = rb.rnbr
-    with _prof.timed(_fwd_kernel_name(cin, rb.m_in), lambda: _conv_cost(rb, cin, cout)):
+    with _prof.timed(_fwd_kernel_name(cin, rb.m_in), _Cost(rb, cin, cout, "dgrad")):
         L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
                                          rb.m_in, L.ptr(grad_in), L.stream()))
     return grad_in
@@ -105,7 +105,7 @@ def _conv_wgrad(features, grad_out, rb):
     ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
-    with _prof.timed("conv_wgrad_kernel+wgrad_reduce_kernel", lambda: _conv_cost(rb, cin, cout)):
+    with _prof.timed("conv_wgrad_kernel+wgrad_reduce_kernel", _Cost(rb, cin, cout, "wgrad")):
         L.check(lib.efg_spconv_wgrad_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
                                          L.ptr(rb.nbr), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
     return grad_w
@@ -123,6 +123,18 @@ def _fwd_kernel_name(n_out_channels, n_rows):
     while nt < ntiles and nt < 16 and ntiles % nt != 0:
         nt <<= 1
     return "conv_fwd_kernel<%d>" % nt
+
+
+class _Cost:
+    """Deferred algorithmic cost of one launch (evaluated after the run) + a label for detailed listings."""
+
+    def __init__(self, rb, cin, cout, kind):
+        self.rb, self.cin, self.cout = rb, cin, cout
+        self.meta = "%s m_in=%d m_out=%d cin=%d cout=%d kvol=%d %s" % (kind, rb.m_in, rb.m_out, cin, cout, rb.kvol,
+                                                                      "subm" if rb.subm else "strided")
+
+    def __call__(self):
+        return _conv_cost(self.rb, self.cin, self.cout)
 
 
 def _conv_cost(rb, cin, cout):

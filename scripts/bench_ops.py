@@ -51,6 +51,39 @@ def bench_msda():
         print("msda %-8s fwd %8.1f us (%6.1f GB/s alg)   bwd %8.1f us" % (name, tf, fwd_bytes / tf / 1e3, tb))
 
 
+def bench_box():
+    """Fused Box3dAttention sampling at the encoder / decoder shapes (csrc/box_fused.hip)."""
+    from efg_amd.operators.box_attention_func import BoxAttnFusedFunction
+
+    g = torch.Generator().manual_seed(0)
+    s, h, d, p = 188 * 188, 8, 32, 25
+    shapes = torch.tensor([[188, 188]], device=dev)
+    start = torch.zeros(1, dtype=torch.int64, device=dev)
+    k = torch.linspace(-2, 2, 5) / 5
+    ky, kx = torch.meshgrid(k, k, indexing="ij")
+    kidx = torch.stack([kx, ky], -1).view(-1, 2).to(dev)
+    for name, b, lq, v in [("encoder", 2, s, 4), ("decoder", 2, 1240, 5)]:
+        value = torch.randn(b, s, h, d, generator=g).to(dev).requires_grad_(True)
+        if name == "encoder":
+            ys, xs = torch.meshgrid(torch.arange(188.0), torch.arange(188.0), indexing="ij")
+            ref = torch.zeros(b, s, 7)
+            ref[..., 0], ref[..., 1] = ((xs + 0.5) / 188).reshape(-1), ((ys + 0.5) / 188).reshape(-1)
+            ref[..., 3] = ref[..., 4] = 0.025
+        else:
+            ref = torch.rand(b, lq, 7, generator=g)
+            ref[..., 3:5] = ref[..., 3:5] * 0.05 + 0.01
+        ref = ref.to(dev)
+        off = torch.rand(b, lq, h * v, generator=g).to(dev).requires_grad_(True)
+        logits = torch.randn(b, lq, h * p, generator=g).to(dev).requires_grad_(True)
+        go = torch.randn(b, lq, h * d, generator=g).to(dev)
+        out = BoxAttnFusedFunction.apply(value, shapes, start, ref, off, logits, kidx, v)
+        tf = timeit(lambda: BoxAttnFusedFunction.apply(value, shapes, start, ref, off, logits, kidx, v))
+        tb = timeit(lambda: torch.autograd.grad(out, (value, off, logits), go, retain_graph=True))
+        alg = 4 * (b * s * h * d + b * lq * (7 + h * (v + p)) + b * lq * h * d)
+        print("box fused %-8s fwd %8.1f us (%6.1f GB/s alg)   bwd %8.1f us (incl. zero-fill of grad_value)" % (
+            name, tf, alg / tf / 1e3, tb))
+
+
 def bench_spconv():
     import efg_amd.spconv as spconv
     from efg_amd import _prof
@@ -77,6 +110,13 @@ def bench_spconv():
     fwd_bwd()
     torch.cuda.synchronize()
     _prof.enable(False)
+    if "--detail" in sys.argv:
+        import efg_amd.spconv.core as core
+        for name, recs in sorted(_prof._records.items()):
+            for (s_, e_, cost) in recs:
+                b, f = cost()
+                meta = getattr(cost, "meta", "")
+                print("    %-40s %8.1f us  %7.2f GFLOP  %6.1f TF/s  %s" % (name, s_.elapsed_time(e_) * 1e3, f / 1e9, f / s_.elapsed_time(e_) / 1e9, meta))
     for k, v in sorted(_prof.summary().items()):
         print("  %-14s launches %3d total %8.2f ms  %7.1f GB/s alg  %6.2f TFLOP/s" % (
             k, v["launches"], v["total_ms"], v["bytes"] / v["total_ms"] / 1e6, v["flops"] / v["total_ms"] / 1e9))
