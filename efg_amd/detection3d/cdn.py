@@ -4,7 +4,8 @@ import torch
 from torch.nn import functional as F
 
 
-def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, label_enc, generator=None):
+def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, label_enc, generator=None,
+                    with_mask=True):
     if not training:
         return None, None, None, None
     targets, dn_number, label_noise_ratio, box_noise_scale = dn_args
@@ -64,8 +65,8 @@ def prepare_for_cdn(dn_args, training, num_queries, num_classes, hidden_dim, lab
         map_known = torch.cat([within + single_pad * i for i in range(2 * dn_number)]).long()
         input_query_label[(known_bid.long(), map_known)] = input_label_embed
         input_query_bbox[(known_bid.long(), map_known)] = known_bbox_expand
-    return input_query_label, input_query_bbox, dn_attn_mask(pad_size, single_pad, dn_number, num_queries, dev), {
-        "pad_size": pad_size, "num_dn_group": dn_number}
+    mask = dn_attn_mask(pad_size, single_pad, dn_number, num_queries, dev) if with_mask else None
+    return input_query_label, input_query_bbox, mask, {"pad_size": pad_size, "num_dn_group": dn_number}
 
 
 def dn_attn_mask(pad_size, single_pad, dn_number, num_queries, device):

@@ -81,7 +81,9 @@ class TransformerDecoderLayer(nn.Module):
             query_pos = self.pos_embed_layer(ref_windows)
             q = k = _with_pos(query, query_pos)
         q, k, v = q.transpose(0, 1), k.transpose(0, 1), query.transpose(0, 1)
-        query2 = self.self_attn(q, k, v, attn_mask=attn_mask)[0].transpose(0, 1)
+        # need_weights=False: same output, skips materialising the head-averaged attention map the reference
+        # computes and discards ($CQ/transformer.py:295)
+        query2 = self.self_attn(q, k, v, attn_mask=attn_mask, need_weights=False)[0].transpose(0, 1)
         query = self.norm1(query + self.dropout1(query2))
         query2 = self.multihead_attn(_with_pos(query, query_pos), memory, memory_shape, None, memory_start_idx, None,
                                      ref_windows[..., :7])[0]

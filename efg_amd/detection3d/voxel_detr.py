@@ -15,6 +15,7 @@ import copy
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 from torch.autograd.profiler import record_function
 
@@ -23,7 +24,7 @@ from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import voxelize_batch
 from .box_coder import VoxelBoxCoder3D
-from .cdn import dn_post_process, prepare_for_cdn
+from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
 from .heads import Det3DHead
 from .position_encoding import build_position_encoding
 from .transformer import Transformer
@@ -100,6 +101,7 @@ class VoxelDETR(nn.Module):
         for p in self.transformer.decoder_gt.parameters():
             p.requires_grad = False
         self.box_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range, device=self.device)
+        self._host_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range)
         cc = config.model.contrastive
         self.eqco, self.tau, self.contras_loss_coeff = cc.eqco, cc.tau, cc.loss_coeff
         self.projector = nn.Sequential(nn.Linear(10, cc.dim), nn.ReLU(), nn.Linear(cc.dim, cc.dim))
@@ -132,16 +134,18 @@ class VoxelDETR(nn.Module):
         with record_function("efg::voxelize"):
             voxels, coords, num_points_per_voxel, input_shape, voxel_mean = self._inputs(batched_inputs)
         if self.training:
-            targets = []
+            # annotations arrive as host arrays: normalise them on the host (box_coder.encode is ~25 tiny
+            # kernels and one sync per scene on the device) and upload the encoded targets
+            targets, host_targets = [], []
             for bi in batched_inputs:
                 ann = bi[1]["annotations"]
-                tgt = {k: torch.as_tensor(np.asarray(ann[k])).to(self.device)
-                       for k in ["gt_boxes", "difficulty", "num_points_in_gt", "labels"] if k in ann}
-                tgt["gt_boxes"] = tgt["gt_boxes"].float().clone()
-                tgt["labels"] = tgt["labels"].long().clone()
-                targets.append(self.box_coder.encode(tgt))
+                tgt = {"gt_boxes": torch.as_tensor(np.asarray(ann["gt_boxes"])).float().clone(),
+                       "labels": torch.as_tensor(np.asarray(ann["labels"])).long().clone()}
+                tgt = self._host_coder.encode(tgt)
+                host_targets.append(tgt)
+                targets.append({k: v.to(self.device, non_blocking=True) for k, v in tgt.items()})
         else:
-            targets = None
+            targets = host_targets = None
         with record_function("efg::backbone+fpn"):
             feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
             features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
@@ -149,10 +153,16 @@ class VoxelDETR(nn.Module):
         dn = self.config.model.dn
         if self.training and dn.enabled and dn.dn_number > 0:
             with record_function("efg::cdn"):
-                input_query_label, input_query_bbox, attn_mask, dn_meta = prepare_for_cdn(
-                    dn_args=(targets, dn.dn_number, dn.dn_label_noise_ratio, dn.dn_box_noise_scale),
+                # the denoising queries are a few hundred numbers derived from host annotations: build them on
+                # the host (CPU generator -> device-independent noise) and upload three small tensors
+                input_query_label, input_query_bbox, _, dn_meta = prepare_for_cdn(
+                    dn_args=(host_targets, dn.dn_number, dn.dn_label_noise_ratio, dn.dn_box_noise_scale),
                     training=self.training, num_queries=self.num_queries, num_classes=self.num_classes,
-                    hidden_dim=self.hidden_dim, label_enc=None, generator=self.noise_generator)
+                    hidden_dim=self.hidden_dim, label_enc=None, generator=self.noise_generator, with_mask=False)
+                input_query_label = input_query_label.to(self.device, non_blocking=True)
+                input_query_bbox = input_query_bbox.to(self.device, non_blocking=True)
+                attn_mask = dn_attn_mask(dn_meta["pad_size"], dn_meta["pad_size"] // (2 * dn.dn_number),
+                                         dn.dn_number, self.num_queries, self.device)
         else:
             input_query_bbox = input_query_label = attn_mask = dn_meta = None
         with record_function("efg::transformer"):
@@ -197,8 +207,9 @@ class VoxelDETR(nn.Module):
 
     def _contrastive_losses(self, outputs_class, outputs_coord, matched, targets, dn_meta):
         """voxel_detr.py:223-254 in batched form.  For decoder layer li and scene bi, every matched
-        (query p, gt g) contributes mean over the G positive-noised GT copies r = g + max_gt*pi of
-        log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau."""
+        (query p, gt g) contributes the mean over the G positive-noised GT copies r = g + max_gt*pi of
+        log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau.  All layers and
+        scenes are evaluated together (the reference runs a Python loop per layer, scene and pair)."""
         out = {}
         per_gt = [t["gt_boxes"].shape[0] for t in targets]
         max_gt, num_gts = max(per_gt), sum(per_gt)
@@ -206,25 +217,28 @@ class VoxelDETR(nn.Module):
             return out
         nq, groups = self.num_queries, dn_meta["num_dn_group"]
         dev = outputs_class.device
-        pis = torch.arange(1, groups + 1, device=dev) * max_gt
-        for li in range(self.config.model.transformer.dec_layers):
-            projs = torch.cat((outputs_class[li], outputs_coord[li]), dim=-1)
-            gt_projs = self.projector(projs[:, nq:].detach())
-            pred_projs = self.predictor(self.projector(projs[:, :nq]))
-            total = projs.new_zeros(())
-            for bi, (qi, gi) in enumerate(matched):
-                if qi.numel() == 0:
-                    continue
-                qi, gi = qi.to(dev), gi.to(dev)
-                rows = (gi[:, None] + pis[None, :]).reshape(-1)                      # [n*G]
-                sim = self.similarity_f(gt_projs[bi][rows].unsqueeze(1), pred_projs[bi].unsqueeze(0)) / self.tau
-                sim = sim.view(qi.numel(), groups, nq)                               # [n, G, Q]
-                neg_mask = torch.ones(nq, dtype=torch.bool, device=dev)
-                neg_mask[qi] = False
-                pos = sim.gather(2, qi[:, None, None].expand(-1, groups, 1))         # [n, G, 1]
-                neg = (torch.exp(sim) * neg_mask).sum(dim=-1, keepdim=True)
-                total = total + (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(1, 2)).sum()
-            out[f"loss_contrastive_dec_{li}"] = self.contras_loss_coeff * total / num_gts
+        n_layers = self.config.model.transformer.dec_layers
+        # index vectors of all matched pairs of the batch (host -> one upload)
+        b_idx = torch.cat([torch.full_like(qi, bi) for bi, (qi, _) in enumerate(matched)])
+        q_idx = torch.cat([qi for qi, _ in matched])
+        g_idx = torch.cat([gi for _, gi in matched])
+        sel = torch.stack([b_idx, q_idx, g_idx]).to(dev, non_blocking=True)
+        b_idx, q_idx, g_idx = sel[0], sel[1], sel[2]
+        n = int(b_idx.numel())
+        neg_mask = torch.ones(len(targets), nq, dtype=torch.bool, device=dev)
+        neg_mask[b_idx, q_idx] = False                                                   # unmatched queries per scene
+        rows = g_idx[:, None] + (torch.arange(1, groups + 1, device=dev) * max_gt)[None, :]  # [n, G]
+        projs = torch.cat((outputs_class[:n_layers], outputs_coord[:n_layers]), dim=-1)     # [L, B, Q+gt, 10]
+        gt_projs = self.projector(projs[:, :, nq:].detach())                                 # [L, B, gt, C]
+        pred_projs = self.predictor(self.projector(projs[:, :, :nq]))                        # [L, B, Q, C]
+        gsel = F.normalize(gt_projs[:, b_idx[:, None], rows], dim=-1, eps=1e-8)              # [L, n, G, C]
+        pn = F.normalize(pred_projs, dim=-1, eps=1e-8)[:, b_idx]                             # [L, n, Q, C]
+        sim = torch.matmul(gsel, pn.transpose(-1, -2)) / self.tau                            # [L, n, G, Q]
+        pos = sim.gather(3, q_idx[None, :, None, None].expand(n_layers, n, groups, 1))
+        neg = (torch.exp(sim) * neg_mask[b_idx][None, :, None, :]).sum(dim=-1, keepdim=True)
+        per_layer = (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(2, 3)).sum(dim=1)      # [L]
+        for li in range(n_layers):
+            out[f"loss_contrastive_dec_{li}"] = self.contras_loss_coeff * per_layer[li] / num_gts
         return out
 
     def _inference(self, outputs_class, outputs_coord):

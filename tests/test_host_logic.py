@@ -103,3 +103,43 @@ def test_synthetic_scene_is_deterministic_and_in_range():
     assert p.shape == (30000, 5) and p.dtype == np.float32
     assert (p[:, 0] >= PC_RANGE[0]).all() and (p[:, 0] < PC_RANGE[3]).all() and (p[:, 2] >= PC_RANGE[2]).all()
     assert make_scene(5, n_points=9000, n_sweeps=4)[0].shape[1] == 6
+
+
+def test_batched_contrastive_loss_matches_reference_loop():
+    """Our batched evaluation vs a literal restatement of the Python loops at $CQ/voxel_detr.py:223-254."""
+    from efg_amd.engine import Trainer
+
+    tr = Trainer(device="cpu", overrides={"model.transformer.num_queries": 30, "model.transformer.enc_layers": 1},
+                 seed=0, ddp=False)
+    m = tr.model
+    g = torch.Generator().manual_seed(0)
+    nq, groups, n_layers = 30, 3, 3
+    per_gt = [4, 2]
+    max_gt = max(per_gt)
+    tot = nq + (groups + 1) * max_gt
+    oc = torch.randn(n_layers, 2, tot, 3, generator=g)
+    ob = torch.rand(n_layers, 2, tot, 7, generator=g)
+    targets = [{"gt_boxes": torch.rand(n, 7)} for n in per_gt]
+    matched = [(torch.tensor([5, 17, 2, 9]), torch.tensor([0, 1, 2, 3])), (torch.tensor([11, 0]), torch.tensor([1, 0]))]
+    got = m._contrastive_losses(oc, ob, matched, targets, {"num_dn_group": groups})
+    sim_f = torch.nn.CosineSimilarity(dim=2)
+    num_gts = sum(per_gt)
+    for li in range(n_layers):
+        loss = 0.0
+        projs = torch.cat((oc[li], ob[li]), dim=-1)
+        gt_projs = m.projector(projs[:, nq:].detach())
+        pred_projs = m.predictor(m.projector(projs[:, :nq]))
+        pos_idxs = list(range(1, groups + 1))
+        for bi, idx in enumerate(matched):
+            sim = sim_f(gt_projs[bi].unsqueeze(1), pred_projs[bi].unsqueeze(0)) / m.tau
+            pairs = torch.stack(idx, dim=-1)
+            neg_mask = projs.new_ones(nq).bool()
+            neg_mask[pairs[:, 0]] = False
+            for pair in pairs:
+                pos_mask = torch.tensor([int(pair[1] + max_gt * pi) for pi in pos_idxs])
+                pos_pair = sim[pos_mask, pair[0]].view(-1, 1)
+                neg_pairs = sim[:, neg_mask][pos_mask]
+                loss = loss + (torch.log(torch.exp(pos_pair) + torch.exp(neg_pairs).sum(dim=-1, keepdim=True))
+                               - pos_pair).mean()
+        ref = m.contras_loss_coeff * loss / num_gts
+        assert float(got[f"loss_contrastive_dec_{li}"]) == pytest.approx(float(ref), rel=1e-5)
