@@ -11,7 +11,8 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libefg_hip.so")
 _lib = None
 
-c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+c_void_p, c_int, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t,
+                                               ctypes.c_float)
 
 # name -> (restype, argtypes); pointers are passed as c_void_p
 _SIGS = {
@@ -57,6 +58,9 @@ _SIGS = {
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_box_attn_fused_forward_f32": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p, c_void_p]),
     "efg_box_attn_fused_backward_f32": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p] * 4),
+    "efg_boxes_bev_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "efg_nms_workspace_bytes": (c_size_t, [c_int]),
+    "efg_nms_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

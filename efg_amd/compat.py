@@ -16,7 +16,7 @@ def install(force=False):
     from .modeling import backbones, common, readers
     from .modeling.backbones import fpn, sparse_net
     from .modeling.readers import voxel_reader
-    from .operators import box_attention_func, ms_deform_attn, scatter_points, voxelize
+    from .operators import box_attention_func, iou3d_nms, ms_deform_attn, scatter_points, voxelize
 
     table = {
         "efg.operators": operators,
@@ -24,6 +24,7 @@ def install(force=False):
         "efg.operators.scatter_points": scatter_points,
         "efg.operators.box_attention_func": box_attention_func,
         "efg.operators.ms_deform_attn": ms_deform_attn,
+        "efg.operators.iou3d_nms": iou3d_nms,
         "efg.modeling": modeling,
         "efg.modeling.operators": operators,
         "efg.modeling.common": common,

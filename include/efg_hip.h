@@ -200,6 +200,25 @@ int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, c
                                     int l, int lq, int p, int v, float* grad_value, float* grad_offsets,
                                     float* grad_logits, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Rotated BEV overlap / IoU and NMS.  Replaces
+ * efg::boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu
+ * (efg/operators/src/iou3d_nms/iou3d_nms.h:7-16, iou3d_nms.cpp:41-160) and the torch composition
+ * boxes_iou3d_gpu (efg/operators/iou3d_nms.py:54-87).
+ *   boxes f32 [n,7] = (x, y, z, dx, dy, dz, heading), device memory.
+ * ---------------------------------------------------------------------------------------- */
+/* out f32 [na,nb], fully written.  mode 0: BEV overlap area, 1: BEV IoU, 2: 3-D IoU. */
+int efg_boxes_bev_f32(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out,
+                      void* stream);
+size_t efg_nms_workspace_bytes(int n);
+/* boxes_sorted: already ordered by descending score (the reference sorts in Python, iou3d_nms.py:98-104).
+ * Greedy suppression of every later box whose IoU with a kept box is > thresh (rotated != 0: rotated BEV
+ * IoU, 0: axis-aligned "normal" IoU).  keep i64 [n] (device) receives the kept row numbers in ascending
+ * order, *num_keep (device int32) their count -- the reference returns the count as the host int
+ * num_to_keep and fills a CPU LongTensor; here nothing leaves the GPU until the caller asks. */
+int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int rotated, int64_t* keep, int* num_keep,
+                void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

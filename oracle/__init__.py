@@ -43,6 +43,7 @@ def lib():
         _LIB.oracle_hard_voxelize.restype = ctypes.c_int
         _LIB.oracle_scatter_forward.restype = ctypes.c_int64
         _LIB.oracle_spconv_out_indices.restype = ctypes.c_int64
+        _LIB.oracle_nms.restype = ctypes.c_int
     return _LIB
 
 
@@ -248,3 +249,23 @@ def msda_backward(value, shapes, level_start, loc, attn, grad_out):
                                _p(attn, _f32p), _p(grad_out, _f32p), b, s, h, d, l, lq, p, _p(gv, _f32p),
                                _p(gl, _f32p), _p(ga, _f32p))
     return gv, gl, ga
+
+
+# ------------------------------------------------------------------------------------------------
+# next row n1: rotated BEV IoU / NMS
+# ------------------------------------------------------------------------------------------------
+def boxes_bev(boxes_a, boxes_b, mode="iou"):
+    """[N,7] x [M,7] (x,y,z,dx,dy,dz,heading) -> [N,M] BEV overlap area ("overlap") or IoU ("iou")."""
+    a, b = _f(boxes_a), _f(boxes_b)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().oracle_boxes_bev(_p(a, _f32p), a.shape[0], _p(b, _f32p), b.shape[0], 1 if mode == "iou" else 0,
+                           _p(out, _f32p))
+    return out
+
+
+def nms(boxes_sorted, thresh, rotated=True):
+    """Greedy NMS over boxes already sorted by descending score -> kept indices (int64)."""
+    b = _f(boxes_sorted)
+    keep = np.zeros((max(b.shape[0], 1),), np.int64)
+    n = lib().oracle_nms(_p(b, _f32p), b.shape[0], ctypes.c_float(thresh), 1 if rotated else 0, _p(keep, _i64p))
+    return keep[:n]

@@ -506,3 +506,129 @@ void oracle_msda_backward(const float* value, const int64_t* shapes, const int64
   for (int64_t e = 0; e < (int64_t)b * s * h * d; ++e) grad_value[e] = (float)gv[e];
   free(gv);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row n1: rotated BEV overlap / IoU and NMS  (efg/operators/src/iou3d_nms/
+ * iou3d_nms_kernel.cu:34-239 box_overlap / iou_bev, :270-309 nms_kernel, :312-322 iou_normal,
+ * iou3d_nms.cpp:82-128 sequential suppression).  PARITY UNPINNED: the reference's CPU twin
+ * iou3d_cpu.cpp includes <cuda.h> / <cuda_runtime_api.h>, which this image lacks, so it cannot be
+ * built here and the reference has no tests; restated from the device functions and cross-checked
+ * against an independent polygon-clipping IoU in tests/test_oracle_iou3d.py.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float x, y; } pt_t;
+static const float kIouEps = 1e-8f;
+
+static float cross3(pt_t p1, pt_t p2, pt_t p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+static float cross2(pt_t a, pt_t b) { return a.x * b.y - a.y * b.x; }
+
+static int rect_cross(pt_t p1, pt_t p2, pt_t q1, pt_t q2) {
+  return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+         fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+static int in_box2d(const float* box, pt_t p) { /* :54-64, MARGIN 1e-2 */
+  const float MARGIN = 1e-2f;
+  const float c = cosf(-box[6]), s = sinf(-box[6]);
+  const float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s);
+  const float ry = (p.x - box[0]) * s + (p.y - box[1]) * c;
+  return fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN;
+}
+
+static int seg_intersection(pt_t p1, pt_t p0, pt_t q1, pt_t q0, pt_t* ans) { /* :66-97 */
+  if (!rect_cross(p0, p1, q0, q1)) return 0;
+  const float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  const float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > kIouEps) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+static void box_corners(const float* b, pt_t c[5]) { /* :127-158 */
+  const float hx = b[3] / 2, hy = b[4] / 2, cs = cosf(b[6]), sn = sinf(b[6]);
+  const float xs[4] = {b[0] - hx, b[0] + hx, b[0] + hx, b[0] - hx};
+  const float ys[4] = {b[1] - hy, b[1] - hy, b[1] + hy, b[1] + hy};
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (xs[k] - b[0]) * cs + (ys[k] - b[1]) * (-sn) + b[0];
+    c[k].y = (xs[k] - b[0]) * sn + (ys[k] - b[1]) * cs + b[1];
+  }
+  c[4] = c[0];
+}
+
+float oracle_box_overlap(const float* box_a, const float* box_b) { /* :111-239 */
+  pt_t ca[5], cb[5], pts[16], center = {0.f, 0.f};
+  box_corners(box_a, ca);
+  box_corners(box_b, cb);
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+        center.x += pts[cnt].x; center.y += pts[cnt].y; ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (in_box2d(box_a, cb[k])) { center.x += cb[k].x; center.y += cb[k].y; pts[cnt++] = cb[k]; }
+    if (in_box2d(box_b, ca[k])) { center.x += ca[k].x; center.y += ca[k].y; pts[cnt++] = ca[k]; }
+  }
+  if (cnt == 0) return 0.0f; /* reference: 0/0 centre, empty area loop -> 0 */
+  center.x /= cnt; center.y /= cnt;
+  for (int j = 0; j < cnt - 1; ++j) /* bubble sort by angle, descending (:207-215) */
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (atan2f(pts[i].y - center.y, pts[i].x - center.x) > atan2f(pts[i + 1].y - center.y, pts[i + 1].x - center.x)) {
+        pt_t t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+      }
+  float area = 0;
+  for (int k = 0; k < cnt - 1; ++k) {
+    pt_t a = {pts[k].x - pts[0].x, pts[k].y - pts[0].y}, b = {pts[k + 1].x - pts[0].x, pts[k + 1].y - pts[0].y};
+    area += cross2(a, b);
+  }
+  return fabsf(area) / 2.0f;
+}
+
+float oracle_iou_bev(const float* a, const float* b) { /* :241-248 */
+  const float sa = a[3] * a[4], sb = b[3] * b[4], so = oracle_box_overlap(a, b);
+  return so / fmaxf(sa + sb - so, kIouEps);
+}
+
+static float iou_normal(const float* a, const float* b) { /* :312-322 */
+  const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  const float inter = fmaxf(right - left, 0.f) * fmaxf(bottom - top, 0.f);
+  return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, kIouEps);
+}
+
+/* mode 0: overlap area, 1: IoU.  out [na, nb] */
+void oracle_boxes_bev(const float* a, int na, const float* b, int nb, int mode, float* out) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      out[(int64_t)i * nb + j] = mode ? oracle_iou_bev(a + i * 7, b + j * 7) : oracle_box_overlap(a + i * 7, b + j * 7);
+}
+
+/* boxes already sorted by score (descending); greedy suppression exactly as nms_kernel + the host
+ * loop of iou3d_nms.cpp:104-117: box j > i is removed when IoU(i, j) > thresh and i is kept.
+ * rotated = 1: iou_bev, 0: iou_normal.  Returns the number kept; keep[] holds their indices. */
+int oracle_nms(const float* boxes, int n, float thresh, int rotated, int64_t* keep) {
+  unsigned char* removed = (unsigned char*)calloc((size_t)n + 1, 1);
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (removed[i]) continue;
+    keep[kept++] = i;
+    for (int j = i + 1; j < n; ++j)
+      if (!removed[j]) {
+        const float v = rotated ? oracle_iou_bev(boxes + i * 7, boxes + j * 7) : iou_normal(boxes + i * 7, boxes + j * 7);
+        if (v > thresh) removed[j] = 1;
+      }
+  }
+  free(removed);
+  return kept;
+}

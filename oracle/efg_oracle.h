@@ -66,6 +66,12 @@ void oracle_msda_backward(const float* value, const int64_t* shapes, const int64
                           int h, int d, int l, int lq, int p, float* grad_value, float* grad_loc,
                           float* grad_attn /* all pre-zeroed */);
 
+/* ---- next row n1: rotated BEV IoU / NMS (efg/operators/src/iou3d_nms/iou3d_nms_kernel.cu) ---- */
+float oracle_box_overlap(const float* box_a, const float* box_b);
+float oracle_iou_bev(const float* box_a, const float* box_b);
+void oracle_boxes_bev(const float* a, int na, const float* b, int nb, int mode, float* out);
+int oracle_nms(const float* boxes, int n, float thresh, int rotated, int64_t* keep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,37 @@ def bench_voxelize():
             nb, n, f, m, t, alg / t / 1e3))
 
 
+def bench_iou3d():
+    """Rotated BEV IoU / NMS at CenterPoint-style post-processing sizes (pre_maxsize 4096)."""
+    from efg_amd import _lib
+    from efg_amd.operators import iou3d_nms
+
+    rng = np.random.default_rng(0)
+    for n, extent in [(1000, 75.0), (4096, 75.0), (4096, 20.0)]:
+        b = np.zeros((n, 7), np.float32)
+        b[:, 0:2] = rng.uniform(-extent, extent, (n, 2))
+        b[:, 3] = rng.uniform(1.5, 5.0, n)
+        b[:, 4] = rng.uniform(0.6, 3.0, n)
+        b[:, 5] = 1.5
+        b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+        t_b = torch.from_numpy(b).to(dev)
+        scores = torch.rand(n, device=dev)
+        t_iou = timeit(lambda: iou3d_nms.boxes_iou_bev(t_b, t_b))
+        frac = float((iou3d_nms.boxes_iou_bev(t_b, t_b) > 0).float().mean())
+        order = scores.sort(0, descending=True)[1]
+        bs = t_b[order].contiguous()
+        keep = torch.empty(n, dtype=torch.int64, device=dev)
+        num = torch.empty(1, dtype=torch.int32, device=dev)
+        wsb = _lib.lib().efg_nms_workspace_bytes(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        t_nms = timeit(lambda: _lib.check(_lib.lib().efg_nms_f32(_lib.ptr(bs), n, 0.7, 1, _lib.ptr(keep), _lib.ptr(num),
+                                                                 _lib.ptr(ws), wsb, _lib.stream())))
+        t_full = timeit(lambda: iou3d_nms.nms_gpu(t_b, scores, 0.7))
+        print("iou3d n=%d extent=%.0f: boxes_iou_bev %8.1f us (%.2f Gpair/s, %.2f%% overlapping, %5.1f GB/s out)  "
+              "nms kernels %8.1f us  nms_gpu incl. sort+sync %8.1f us  kept %d" % (
+                  n, extent, t_iou, n * n / t_iou / 1e3, 100 * frac, 4 * n * n / t_iou / 1e3, t_nms, t_full, int(num)))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
     for w in which:
