@@ -49,11 +49,31 @@ def synthetic_batch(seed_base, scenes, n_points=180000, n_sweeps=1, device=None,
     return batch
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+
+
+def use_tuned_gemms(path=TUNED_GEMMS):
+    """Select the hipBLASLt / rocBLAS solutions recorded by scripts/tune_gemm.py for the step's dense fp32 GEMM
+    shapes (PyTorch TunableOp, tuning itself OFF: unknown shapes keep the library default).  Pure algorithm
+    selection -- same fp32 arithmetic; entries are validated against the ROCm / hipBLASLt build and ignored on
+    mismatch.  EFG_TUNED_GEMMS=0 disables it."""
+    if os.environ.get("EFG_TUNED_GEMMS", "1") == "0" or not os.path.exists(path):
+        return False
+    import torch.cuda.tunable as tunable
+
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.set_filename(path)
+    return True
+
+
 class Trainer:
     def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
         if device is not None:
             cfg.model.device = str(device)
+        if str(cfg.model.device).startswith("cuda"):
+            use_tuned_gemms()
         torch.manual_seed(seed)
         self.cfg = cfg
         self.model = VoxelDETR(cfg)

@@ -1,0 +1,50 @@
+"""Tune the dense fp32 GEMMs of the train step with PyTorch TunableOp (hipBLASLt / rocBLAS solution search).
+
+Run on the GPU box:  python scripts/tune_gemm.py [out.csv]
+Runs a few train steps with tuning enabled (every new GEMM shape is benchmarked over the library's solutions
+once), writes the chosen solutions to a CSV, then reports the step time with tuning frozen.  The CSV is plumbing
+(library algorithm selection) -- it changes no arithmetic type; entries are validated against the ROCm /
+hipBLASLt versions at load time and ignored when they do not match."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tunableop_results.csv")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+
+import torch.cuda.tunable as tunable
+from efg_amd.engine import Trainer, synthetic_batch
+
+dev = torch.device("cuda:0")
+tr = Trainer(device=dev, seed=0)
+pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
+
+
+def steps(n, tag):
+    ts = []
+    for s in range(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        tr.step(pool[s % 2])
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    print(tag, " ".join("%.1f" % x for x in ts), flush=True)
+    return ts
+
+
+steps(4, "untuned:")
+tunable.enable(True)
+tunable.tuning_enable(True)
+tunable.set_filename(out)
+tunable.set_max_tuning_duration(30)
+tunable.set_max_tuning_iterations(20)
+t0 = time.perf_counter()
+steps(3, "tuning:")
+print("tuning took %.1f s, %d entries" % (time.perf_counter() - t0, len(tunable.get_results())), flush=True)
+tunable.write_file(out)
+tunable.tuning_enable(False)
+steps(8, "tuned:")
+print("validators:", tunable.get_validators())
