@@ -74,9 +74,11 @@ class Det3DLoss(nn.Module):
         dev = outputs["pred_logits"].device
         n_gt = sum(len(t["labels"]) for t in targets)
         if get_world_size() > 1:
-            nb = torch.as_tensor([n_gt], dtype=torch.float, device=dev)
+            # kept on the device (0-dim tensor): the reference reads it back with .item() (losses.py:131-135),
+            # which would drain the stream once per step for a value that is only ever a divisor
+            nb = torch.tensor([float(n_gt)]).to(dev, non_blocking=True)
             torch.distributed.all_reduce(nb)
-            num_boxes = torch.clamp(nb / get_world_size(), min=1).item()
+            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
         else:
             num_boxes = max(float(n_gt), 1.0)
         tgt_labels, tgt_boxes, counts = _pad_targets(targets, dev)

@@ -98,10 +98,21 @@ def sigmoid_focal_loss(logits, targets, alpha=-1.0, gamma=2.0, reduction="none")
     return loss
 
 
+_SHAPES = {}
+
+
+def _shapes_on_device(shapes, device):
+    """int64 [N,2] level shapes on `device`, built once per distinct shape set: torch.tensor(list, device=...)
+    is a SYNCHRONOUS upload -- it waits for everything queued on the stream (the previous step's backward)."""
+    key = (shapes, str(device))
+    if key not in _SHAPES:
+        _SHAPES[key] = torch.tensor(shapes, dtype=torch.int64).to(device)
+    return _SHAPES[key]
+
+
 def flatten_with_shape(tensor_list):
     """[(B,C,Hi,Wi)] -> ((B, sum Hi*Wi, C), int64 [N,2] shapes) ($CQ/modules/utils.py:277-314)."""
-    shapes = torch.tensor([[t.shape[2], t.shape[3]] for t in tensor_list], dtype=torch.int64,
-                          device=tensor_list[0].device)
+    shapes = _shapes_on_device(tuple((t.shape[2], t.shape[3]) for t in tensor_list), tensor_list[0].device)
     flat = torch.cat([t.flatten(2).permute(0, 2, 1) for t in tensor_list], dim=1)
     return flat, shapes
 

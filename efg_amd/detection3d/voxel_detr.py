@@ -12,6 +12,7 @@ OUR side of the operator boundary and none changing a result:
   * the contrastive loss's Python double loop (:234-253) is evaluated in batched tensor form.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -23,6 +24,7 @@ from ..modeling.backbones.fpn import build_resnet_fpn_backbone
 from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import voxelize_batch
+from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
 from .heads import Det3DHead
@@ -64,6 +66,7 @@ class VoxelDETR(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.device = torch.device(config.model.device)
+        self._geo_stream = None
         self.hidden_dim = config.model.hidden_dim
         self.aux_loss = config.model.aux_loss
         self.num_classes = len(config.dataset.classes)
@@ -125,9 +128,36 @@ class VoxelDETR(nn.Module):
         mode = "train" if self.training else "val"
         vc = self._vox_cfg[mode]
         pts = [torch.as_tensor(s["points"], dtype=torch.float32).to(self.device, non_blocking=True) for s in samples]
-        out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
-        return (out["voxels"], out["coordinates"], out["num_points_per_voxel"], self.grid_size,
-                out["voxel_mean"][:, : self.input_dim].contiguous())
+        geo = self._geometry_stream()
+        if geo is None:
+            out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
+            mean = out["voxel_mean"][:, : self.input_dim].contiguous()
+        else:
+            # voxelization sizes every downstream tensor (one count readback): run it on the geometry stream so
+            # the readback does not wait for the previous step's backward still queued on the main stream
+            main = torch.cuda.current_stream()
+            events = [s.get("ready_event") for s in samples]
+            if all(e is not None for e in events):
+                for e in events:
+                    geo.wait_event(e)  # the caller's promise: the points are complete once this event fires
+            else:
+                geo.wait_stream(main)  # unknown provenance: order after everything queued so far
+            with torch.cuda.stream(geo):
+                out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
+                mean = out["voxel_mean"][:, : self.input_dim].contiguous()
+            main.wait_stream(geo)
+            for t in (out["voxels"], out["coordinates"], out["num_points_per_voxel"], mean):
+                t.record_stream(main)
+        return out["voxels"], out["coordinates"], out["num_points_per_voxel"], self.grid_size, mean
+
+    def _geometry_stream(self):
+        """High-priority side stream for voxelization + sparse-conv geometry (spconv/core.py `geometry_stream`);
+        None on CPU or with EFG_GEOMETRY_STREAM=0."""
+        if self.device.type != "cuda" or os.environ.get("EFG_GEOMETRY_STREAM", "1") == "0":
+            return None
+        if self._geo_stream is None:
+            self._geo_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._geo_stream
 
     def forward(self, batched_inputs):
         batch_size = len(batched_inputs)
@@ -147,7 +177,8 @@ class VoxelDETR(nn.Module):
         else:
             targets = host_targets = None
         with record_function("efg::backbone+fpn"):
-            feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
+            with spconv_core.geometry_stream(self._geometry_stream()):
+                feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
             features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
         pos_encodings = [fp[1] for fp in feats_pos]
         dn = self.config.model.dn

@@ -45,7 +45,13 @@ def synthetic_batch(seed_base, scenes, n_points=180000, n_sweeps=1, device=None,
             pts = pts.to(device)
         ann = {"gt_boxes": boxes, "labels": labels, "difficulty": np.zeros(len(labels), np.int64),
                "num_points_in_gt": np.full(len(labels), 50, np.int64)}
-        batch.append(({"points": pts}, {"annotations": ann}))
+        sample = {"points": pts}
+        if pts.is_cuda:
+            # "the points are complete once this event fires": lets the model start voxelization on its geometry
+            # stream without ordering it after unrelated work queued on the main stream (voxel_detr.py:_inputs)
+            sample["ready_event"] = torch.cuda.Event()
+            sample["ready_event"].record(torch.cuda.current_stream(pts.device))
+        batch.append((sample, {"annotations": ann}))
     return batch
 
 

@@ -182,6 +182,58 @@ def _from_dense(grad_dense, x):
     return g
 
 
+# ---- geometry stream ------------------------------------------------------------------------------------
+# Sparse-conv geometry (site discovery, neighbour tables) depends only on voxel coordinates, never on
+# features or weights, but sizes every downstream tensor: each strided level reads its site count back to
+# the host.  On the main stream that read waits for everything queued before it -- in a training loop the
+# whole backward of the previous step -- so the host cannot run ahead.  Inside a `geometry_stream(s)` scope
+# the geometry launches (and their count readbacks) go to the side stream `s` instead: the readback only
+# waits for the few geometry kernels, the main stream gets a device-side dependency, and tensors that cross
+# streams are handed to the caching allocator with record_stream.  Outside a scope nothing changes.
+_GEO = None
+
+
+class geometry_stream:
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        global _GEO
+        self.prev, _GEO = _GEO, self.stream
+        return self
+
+    def __exit__(self, *exc):
+        global _GEO
+        _GEO = self.prev
+        return False
+
+
+class _on_geometry_stream:
+    """`with _on_geometry_stream() as main:` -- main is None when no scope is active."""
+
+    def __enter__(self):
+        self.main = None
+        if _GEO is not None:
+            self.main = torch.cuda.current_stream()
+            self.ctx = torch.cuda.stream(_GEO)
+            self.ctx.__enter__()
+        return self.main
+
+    def __exit__(self, *exc):
+        if self.main is not None:
+            self.ctx.__exit__(*exc)
+            self.main.wait_stream(_GEO)  # device-side dependency, the host does not block
+        return False
+
+
+def _hand_over(main, *tensors):
+    """Tensors allocated on the geometry stream that main-stream kernels will read."""
+    if main is not None:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(main)
+
+
 class Rulebook:
     """Output-stationary neighbour table of one convolution geometry."""
 
@@ -428,7 +480,10 @@ class SparseConvolution(SparseModule):
             if key is not None and key in x.indice_dict:
                 return x.indice_dict[key], None
             m = x.indices.shape[0]
-            nbr = _build_nbr(x.site_index(), x.indices, m, ks, (1, 1, 1), pad)
+            with _on_geometry_stream() as main:
+                si = x.site_index()
+                nbr = _build_nbr(si, x.indices, m, ks, (1, 1, 1), pad)
+                _hand_over(main, nbr, si.index, si.perm)
             rb = Rulebook(nbr, m, m, nbr.shape[0], True)
             if key is not None:
                 x.indice_dict[key] = rb
@@ -437,9 +492,12 @@ class SparseConvolution(SparseModule):
         key = ("conv", ks, st, pad)
         if key in x._conv_cache:  # main and shortcut convs of a block share one geometry
             return x._conv_cache[key]
-        out_indices, out_site_index, oshape_py = _downsample_geometry(x, ks, st, pad)
-        m_out = out_indices.shape[0]
-        nbr = _build_nbr(x.site_index(), out_indices, m_out, ks, st, pad)
+        with _on_geometry_stream() as main:
+            si = x.site_index()
+            out_indices, out_site_index, oshape_py = _downsample_geometry(x, ks, st, pad)
+            m_out = out_indices.shape[0]
+            nbr = _build_nbr(si, out_indices, m_out, ks, st, pad)
+            _hand_over(main, nbr, out_indices, out_site_index.index, si.index, si.perm)
         rb = Rulebook(nbr, x.indices.shape[0], m_out, nbr.shape[0], False)
         geom = (out_indices, out_site_index, oshape_py)
         x._conv_cache[key] = (rb, geom)
