@@ -18,7 +18,6 @@ namespace {
 constexpr int kMaxLevels = 8;
 constexpr int kMaxPts = 128;  // L * P upper bound for the fused path (LDS scratch)
 constexpr int kSoftmaxLds = 4096;  // floats: (pairs per workgroup) x (L*P) must fit
-constexpr float kTwoPi = 6.283185307179586f;
 
 struct BoxDims {
   int b, s, h, d, l, lq, p, v;  // v = 4 (no rotation) or 5

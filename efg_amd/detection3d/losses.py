@@ -19,8 +19,24 @@ def get_world_size():
                                                   and torch.distributed.is_initialized()) else 1
 
 
+class PaddedTargets(list):
+    """The per-scene target dicts (a plain list, as the reference passes them) that also carries the padded batch
+    form built once on the host: labels [B,G] (0 padded), boxes [B,G,7], counts (host list).  Every dict's
+    tensors are views of the padded ones."""
+
+    def __init__(self, labels, boxes, counts):
+        super().__init__({"labels": labels[b, :n], "gt_boxes": boxes[b, :n]} for b, n in enumerate(counts))
+        self.labels, self.boxes, self.counts = labels, boxes, list(counts)
+
+    def class_agnostic(self):
+        """Same boxes, every label 0 (the encoder proposal loss, voxel_detr.py:200-202)."""
+        return PaddedTargets(torch.zeros_like(self.labels), self.boxes, self.counts)
+
+
 def _pad_targets(targets, device):
     """labels [B,G] (0 padded), boxes [B,G,7], counts (host list)."""
+    if isinstance(targets, PaddedTargets):
+        return targets.labels, targets.boxes, targets.counts
     counts = [int(t["labels"].numel()) for t in targets]
     g = max(max(counts), 1)
     labels = torch.zeros(len(targets), g, dtype=torch.int64, device=device)
@@ -57,7 +73,8 @@ class Det3DLoss(nn.Module):
         cls = tgt_labels[b_idx, g_idx]
         if "focal_labels" in self.losses:
             onehot = torch.zeros_like(logits)
-            onehot[l_idx, b_idx, q_idx, cls] = 1
+            # (a Python scalar on the right-hand side would be uploaded synchronously)
+            onehot.index_put_((l_idx, b_idx, q_idx, cls), logits.new_ones(()))
             fl = sigmoid_focal_loss(logits, onehot, alpha=self.focal_alpha, gamma=2.0, reduction="none")
             out["loss_ce"] = fl.sum(dim=(1, 2, 3)) / num_boxes
         if "boxes" in self.losses:
@@ -94,29 +111,29 @@ class Det3DLoss(nn.Module):
             m_boxes = torch.gather(boxes[0], 1, topk.expand(-1, -1, boxes.shape[-1]))[None]
         else:
             m_logits, m_boxes = logits, boxes
-        indices = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L][B] (qi, gi)
-        outputs["matched_indices"] = indices[-1]
-        flat = [[], [], [], []]
-        for li, per_layer in enumerate(indices):
-            for b, (qi, gi) in enumerate(per_layer):
-                flat[0].append(torch.full_like(qi, li))
-                flat[1].append(torch.full_like(qi, b))
-                flat[2].append(qi)
-                flat[3].append(gi)
-        sel = torch.stack([torch.cat(f) for f in flat]).to(dev, non_blocking=True)  # one H2D
+        q_of_g = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L,B,G] on dev
+        outputs["matched_query_of_gt"] = q_of_g[-1]
+        # (layer, scene, gt) of every matched pair is known from the GT counts alone: built on the host, one
+        # asynchronous upload; the matched query comes from the device-side assignment
+        n_layers = len(layers)
+        b_l = torch.cat([torch.full((n,), b, dtype=torch.int64) for b, n in enumerate(counts)])
+        g_l = torch.cat([torch.arange(n, dtype=torch.int64) for n in counts])
+        static = torch.stack([torch.arange(n_layers).repeat_interleave(n_gt), b_l.repeat(n_layers),
+                              g_l.repeat(n_layers)]).to(dev, non_blocking=True)
+        sel = (static[0], static[1], q_of_g[static[0], static[1], static[2]], static[2])
         if topk is not None:
             # classification targets live on the FULL token set at the positions the top-k picked
             q_full = topk[sel[1], sel[2], 0]
             ce, cls = self._layer_losses(logits, boxes, (sel[0], sel[1], q_full, sel[3]), tgt_labels, tgt_boxes,
                                          num_boxes)
-            bx, _ = self._layer_losses(m_logits, m_boxes, tuple(sel), tgt_labels, tgt_boxes, num_boxes)
+            bx, _ = self._layer_losses(m_logits, m_boxes, sel, tgt_labels, tgt_boxes, num_boxes)
             per_layer = {"loss_ce": ce["loss_ce"], **{k: v for k, v in bx.items() if k != "loss_ce"}}
             self._metric_logits = m_logits[sel[0], sel[1], sel[2]]
         else:
-            per_layer, cls = self._layer_losses(logits, boxes, tuple(sel), tgt_labels, tgt_boxes, num_boxes)
-            last = sel[0] == (len(layers) - 1)
-            self._metric_logits = logits[-1][sel[1][last], sel[2][last]]
-            cls = cls[last]
+            per_layer, cls = self._layer_losses(logits, boxes, sel, tgt_labels, tgt_boxes, num_boxes)
+            # pairs are ordered layer-major: the last layer's are the final n_gt entries
+            self._metric_logits = logits[-1][sel[1][-n_gt:], sel[2][-n_gt:]] if n_gt else logits[-1][:0, 0]
+            cls = cls[-n_gt:] if n_gt else cls[:0]
         self._metric_classes = cls
 
         losses = {}

@@ -1,10 +1,12 @@
-"""Hungarian matching of queries to GT boxes ($CQ/modules/matcher.py:9-96).  The cost matrices are
-built on the GPU for the whole batch and cross to the host ONCE per call (the reference moves one
-matrix per scene); the assignment itself is scipy's linear_sum_assignment, as in the reference."""
+"""Hungarian matching of queries to GT boxes ($CQ/modules/matcher.py:9-96).  The cost matrices are built on
+the GPU for all layers and scenes at once and -- in the training step (`match_layers`) -- assigned there too
+(efg_lsap_f32 reproduces scipy's linear_sum_assignment exactly); the reference moves one matrix per scene to the
+host and calls scipy.  `forward` keeps the reference's call format (one transfer, scipy)."""
 import torch
 from scipy.optimize import linear_sum_assignment
 from torch import nn
 
+from ..operators.assignment import linear_sum_assignment_batched
 from .utils import box_cxcyczlwh_to_xyxyxy, generalized_box3d_iou, pairwise_box3d_giou
 
 
@@ -45,8 +47,10 @@ class HungarianMatcher3d(nn.Module):
     def match_layers(self, logits, boxes, tgt_labels, tgt_boxes, counts):
         """All decoder layers and scenes at once.  logits [L,B,Q,C], boxes [L,B,Q,7]; padded targets
         tgt_labels [B,G], tgt_boxes [B,G,7] with `counts[b]` valid columns.  Same cost as `cost_matrices`
-        ($CQ/modules/matcher.py:40-80); ONE device->host transfer, then scipy per (layer, scene).
-        Returns [L][B] (query_idx, gt_idx) int64 CPU tensors."""
+        ($CQ/modules/matcher.py:40-80).  Returns query_of_gt int64 [L,B,G] on the inputs' device: the query
+        matched to GT column g (-1 in padded columns) -- the reference's (row_ind, col_ind) pairs of
+        (layer l, scene b) are {(query_of_gt[l,b,g], g)}.  On the GPU the assignment is efg_lsap_f32 (no
+        host transfer); on CPU tensors it is scipy, as in the reference."""
         n_layers, bs, nq = logits.shape[:3]
         g = tgt_labels.shape[1]
         out_prob = logits.sigmoid().float()
@@ -62,15 +66,19 @@ class HungarianMatcher3d(nn.Module):
         cost_giou = -pairwise_box3d_giou(box_cxcyczlwh_to_xyxyxy(out_bbox), box_cxcyczlwh_to_xyxyxy(tb)[None])
         cost = (self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou +
                 self.cost_rad * cost_rad)
-        host = cost.cpu().numpy()  # the one D2H of this call
-        out = []
+        if cost.is_cuda:
+            # the assignment stays on the device (csrc/matcher.hip: scipy's algorithm, arithmetic and
+            # tie-breaking): the step never waits for a cost matrix to reach the host
+            ng = torch.tensor(list(counts) * n_layers, dtype=torch.int32).to(cost.device, non_blocking=True)
+            q_of_g = linear_sum_assignment_batched(cost.view(n_layers * bs, nq, g), ng)
+            return q_of_g.view(n_layers, bs, g)
+        host = cost.numpy()
+        q_of_g = torch.full((n_layers, bs, g), -1, dtype=torch.int64)
         for li in range(n_layers):
-            per = []
             for b in range(bs):
                 i, j = linear_sum_assignment(host[li, b, :, : counts[b]])
-                per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
-            out.append(per)
-        return out
+                q_of_g[li, b, torch.as_tensor(j, dtype=torch.int64)] = torch.as_tensor(i, dtype=torch.int64)
+        return q_of_g
 
     @torch.no_grad()
     def forward(self, outputs, targets):

@@ -9,6 +9,7 @@ from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
 from .box_attention import Box3dAttention
+from .losses import PaddedTargets
 from .utils import MLP, flatten_with_shape, get_clones
 
 
@@ -183,11 +184,18 @@ class Transformer(nn.Module):
             batch_size = len(targets)
             per_gt_num = [tgt["gt_boxes"].shape[0] for tgt in targets]
             max_gt_num = max(per_gt_num)
-            gt_with_score = memory.new_zeros(batch_size, max_gt_num, 10)
-            for bi in range(batch_size):
-                gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
-                gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
-                                                                    num_classes=self.num_classes)
+            if isinstance(targets, PaddedTargets):  # batched: padded rows are zeroed by the validity mask
+                valid = (torch.arange(max_gt_num)[None, :] < torch.tensor(per_gt_num)[:, None]).to(
+                    memory.device, non_blocking=True)
+                gt_with_score = torch.cat((targets.boxes[:, :max_gt_num],
+                                           F.one_hot(targets.labels[:, :max_gt_num], num_classes=self.num_classes)
+                                           .to(memory.dtype)), dim=-1) * valid[..., None]
+            else:
+                gt_with_score = memory.new_zeros(batch_size, max_gt_num, 10)
+                for bi in range(batch_size):
+                    gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
+                    gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
+                                                                        num_classes=self.num_classes)
             with torch.no_grad(), record_function("efg::gt_decoder"):
                 self._momentum_update_gt_decoder()
                 if noised_gt_box is not None:

@@ -28,6 +28,7 @@ from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
 from .heads import Det3DHead
+from .losses import PaddedTargets
 from .position_encoding import build_position_encoding
 from .transformer import Transformer
 
@@ -166,14 +167,23 @@ class VoxelDETR(nn.Module):
         if self.training:
             # annotations arrive as host arrays: normalise them on the host (box_coder.encode is ~25 tiny
             # kernels and one sync per scene on the device) and upload the encoded targets
-            targets, host_targets = [], []
+            host_targets = []
             for bi in batched_inputs:
                 ann = bi[1]["annotations"]
                 tgt = {"gt_boxes": torch.as_tensor(np.asarray(ann["gt_boxes"])).float().clone(),
                        "labels": torch.as_tensor(np.asarray(ann["labels"])).long().clone()}
-                tgt = self._host_coder.encode(tgt)
-                host_targets.append(tgt)
-                targets.append({k: v.to(self.device, non_blocking=True) for k, v in tgt.items()})
+                host_targets.append(self._host_coder.encode(tgt))
+            # padded batch form, built on the host and uploaded once (two small asynchronous copies); the per-scene
+            # dicts the transformer / losses index are views of it
+            counts = [int(t["labels"].numel()) for t in host_targets]
+            g = max(max(counts), 1)
+            labels = torch.zeros(batch_size, g, dtype=torch.int64)
+            boxes = torch.zeros(batch_size, g, 7, dtype=torch.float32)
+            for b, t in enumerate(host_targets):
+                labels[b, : counts[b]] = t["labels"]
+                boxes[b, : counts[b]] = t["gt_boxes"]
+            targets = PaddedTargets(labels.to(self.device, non_blocking=True),
+                                    boxes.to(self.device, non_blocking=True), counts)
         else:
             targets = host_targets = None
         with record_function("efg::backbone+fpn"):
@@ -220,9 +230,10 @@ class VoxelDETR(nn.Module):
         losses = {}
         # encoder proposal losses (class-agnostic), voxel_detr.py:198-209
         enc_class, enc_coords = self.transformer.proposal_head(src_embed, src_ref_windows)
-        bin_targets = copy.deepcopy(targets)
-        for tgt in bin_targets:
-            tgt["labels"].fill_(0)
+        bin_targets = targets.class_agnostic() if isinstance(targets, PaddedTargets) else copy.deepcopy(targets)
+        if not isinstance(targets, PaddedTargets):
+            for tgt in bin_targets:
+                tgt["labels"].fill_(0)
         enc_outputs = {"topk_indexes": src_indexes, "pred_logits": enc_class, "pred_boxes": enc_coords}
         enc_losses = self.transformer.proposal_head.compute_losses(enc_outputs, bin_targets)
         losses.update({k + "_enc": v for k, v in enc_losses.items()})
@@ -232,15 +243,16 @@ class VoxelDETR(nn.Module):
         with record_function("efg::losses.decoder"):
             losses.update(head.compute_losses(outputs, targets, dn_meta))
         with record_function("efg::losses.contrastive"):
-            losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_indices"], targets,
-                                                   dn_meta))
+            losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
+                                                   targets, dn_meta))
         return losses
 
-    def _contrastive_losses(self, outputs_class, outputs_coord, matched, targets, dn_meta):
+    def _contrastive_losses(self, outputs_class, outputs_coord, query_of_gt, targets, dn_meta):
         """voxel_detr.py:223-254 in batched form.  For decoder layer li and scene bi, every matched
         (query p, gt g) contributes the mean over the G positive-noised GT copies r = g + max_gt*pi of
         log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau.  All layers and
-        scenes are evaluated together (the reference runs a Python loop per layer, scene and pair)."""
+        scenes are evaluated together (the reference runs a Python loop per layer, scene and pair).
+        query_of_gt: int64 [B, G] on the device, the last layer's assignment (matcher.match_layers)."""
         out = {}
         per_gt = [t["gt_boxes"].shape[0] for t in targets]
         max_gt, num_gts = max(per_gt), sum(per_gt)
@@ -249,15 +261,16 @@ class VoxelDETR(nn.Module):
         nq, groups = self.num_queries, dn_meta["num_dn_group"]
         dev = outputs_class.device
         n_layers = self.config.model.transformer.dec_layers
-        # index vectors of all matched pairs of the batch (host -> one upload)
-        b_idx = torch.cat([torch.full_like(qi, bi) for bi, (qi, _) in enumerate(matched)])
-        q_idx = torch.cat([qi for qi, _ in matched])
-        g_idx = torch.cat([gi for _, gi in matched])
-        sel = torch.stack([b_idx, q_idx, g_idx]).to(dev, non_blocking=True)
-        b_idx, q_idx, g_idx = sel[0], sel[1], sel[2]
-        n = int(b_idx.numel())
+        # (scene, gt) of all matched pairs follow from the GT counts (host -> one asynchronous upload); the
+        # matched query stays on the device
+        static = torch.stack([torch.cat([torch.full((n,), bi, dtype=torch.int64) for bi, n in enumerate(per_gt)]),
+                              torch.cat([torch.arange(n, dtype=torch.int64) for n in per_gt])]).to(
+                                  dev, non_blocking=True)
+        b_idx, g_idx = static[0], static[1]
+        q_idx = query_of_gt[b_idx, g_idx]
+        n = num_gts
         neg_mask = torch.ones(len(targets), nq, dtype=torch.bool, device=dev)
-        neg_mask[b_idx, q_idx] = False                                                   # unmatched queries per scene
+        neg_mask.index_put_((b_idx, q_idx), torch.zeros((), dtype=torch.bool, device=dev))  # unmatched queries
         rows = g_idx[:, None] + (torch.arange(1, groups + 1, device=dev) * max_gt)[None, :]  # [n, G]
         projs = torch.cat((outputs_class[:n_layers], outputs_coord[:n_layers]), dim=-1)     # [L, B, Q+gt, 10]
         gt_projs = self.projector(projs[:, :, nq:].detach())                                 # [L, B, gt, C]

@@ -219,6 +219,19 @@ size_t efg_nms_workspace_bytes(int n);
 int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int rotated, int64_t* keep, int* num_keep,
                 void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the
+ * device->host transfer + scipy.optimize.linear_sum_assignment(C[b]) of $CQ/modules/matcher.py:86-91.
+ *   cost f32 [p, nq, g_stride]: p independent problems (layers x scenes), nq queries (rows) x GT
+ *        boxes (columns); problem i uses its first ng[i] columns.  ng i32 [p], device memory.
+ *   query_of_gt i64 [p, g_stride]: the query assigned to each GT column, -1 for padded columns (and
+ *        for unassigned GTs when ng[i] > nq).  The reference's (row_ind, col_ind) pairs are
+ *        {(query_of_gt[g], g)}; the assignment equals scipy's for every input, ties included.
+ *   status i32 [p] or NULL: 0 ok, 1 infeasible / non-finite costs (scipy raises ValueError there).
+ * ---------------------------------------------------------------------------------------- */
+int efg_lsap_f32(const float* cost, int n_problems, int nq, int g_stride, const int32_t* ng,
+                 int64_t* query_of_gt, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

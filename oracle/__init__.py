@@ -44,6 +44,7 @@ def lib():
         _LIB.oracle_scatter_forward.restype = ctypes.c_int64
         _LIB.oracle_spconv_out_indices.restype = ctypes.c_int64
         _LIB.oracle_nms.restype = ctypes.c_int
+        _LIB.oracle_lsap.restype = ctypes.c_int
     return _LIB
 
 
@@ -269,3 +270,18 @@ def nms(boxes_sorted, thresh, rotated=True):
     keep = np.zeros((max(b.shape[0], 1),), np.int64)
     n = lib().oracle_nms(_p(b, _f32p), b.shape[0], ctypes.c_float(thresh), 1 if rotated else 0, _p(keep, _i64p))
     return keep[:n]
+
+
+# ------------------------------------------------------------------------------------------------
+# next row "GPU matcher": linear sum assignment
+# ------------------------------------------------------------------------------------------------
+def lsap(cost, ng=None):
+    """cost [nq, g_stride] float32, first `ng` columns valid -> query_of_gt int64 [ng] (-1 = unmatched)."""
+    c = _f(cost)
+    nq, gs = c.shape
+    ng = gs if ng is None else int(ng)
+    out = np.full((max(ng, 1),), -1, np.int64)
+    rc = lib().oracle_lsap(_p(c, _f32p), nq, gs, ng, _p(out, _i64p))
+    if rc != 0:
+        raise ValueError("cost matrix is infeasible")
+    return out[:ng]

@@ -632,3 +632,90 @@ int oracle_nms(const float* boxes, int n, float thresh, int rotated, int64_t* ke
   free(removed);
   return kept;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * "next" row (GPU matcher): linear sum assignment.  The reference calls
+ * scipy.optimize.linear_sum_assignment ($CQ/modules/matcher.py:1,89) -- a third-party dependency
+ * (scipy, not pinned by the reference; 1.15.3 in this image) whose implementation is the
+ * rectangular shortest-augmenting-path algorithm of D. F. Crouse, "On implementing 2D rectangular
+ * assignment algorithms", IEEE TAES 52(4), 2016 (scipy/optimize/rectangular_lsap).  Restated here
+ * including its tie-breaking (candidate columns are scanned in the order of the `remaining` list,
+ * which starts REVERSED and is compacted by moving the last element into the freed slot).
+ * PINNED against scipy itself in tests/test_oracle_lsap.py (random, tie-heavy integer and constant
+ * matrices, both orientations).
+ *   cost: row-major [nq][g_stride] floats, first ng columns valid.  The assignment runs with the
+ *   smaller side as rows (scipy transposes when nq > ng) in fp64, same operation order.
+ *   query_of_gt[g] = matched query, or -1 (only when ng > nq).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_lsap(const float* cost, int nq, int g_stride, int ng, int64_t* query_of_gt) {
+  for (int g = 0; g < ng; ++g) query_of_gt[g] = -1;
+  if (nq == 0 || ng == 0) return 0;
+  const int transposed = nq > ng; /* rows = GT, cols = queries */
+  const int nr = transposed ? ng : nq, nc = transposed ? nq : ng;
+#define COST(i, j) ((double)(transposed ? cost[(size_t)(j) * g_stride + (i)] : cost[(size_t)(i) * g_stride + (j)]))
+  double* u = (double*)calloc(nr, sizeof(double));
+  double* v = (double*)calloc(nc, sizeof(double));
+  double* spc = (double*)malloc(sizeof(double) * nc);
+  int* path = (int*)malloc(sizeof(int) * nc);
+  int* col4row = (int*)malloc(sizeof(int) * nr);
+  int* row4col = (int*)malloc(sizeof(int) * nc);
+  int* remaining = (int*)malloc(sizeof(int) * nc);
+  unsigned char* SR = (unsigned char*)malloc(nr);
+  unsigned char* SC = (unsigned char*)malloc(nc);
+  for (int i = 0; i < nr; ++i) col4row[i] = -1;
+  for (int j = 0; j < nc; ++j) row4col[j] = -1;
+  int ok = 1;
+  for (int cur = 0; cur < nr && ok; ++cur) {
+    double min_val = 0;
+    int i = cur, num_remaining = nc, sink = -1;
+    for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+    memset(SR, 0, nr);
+    memset(SC, 0, nc);
+    for (int j = 0; j < nc; ++j) spc[j] = INFINITY;
+    while (sink == -1) {
+      int index = -1;
+      double lowest = INFINITY;
+      SR[i] = 1;
+      for (int it = 0; it < num_remaining; ++it) {
+        const int j = remaining[it];
+        const double r = min_val + COST(i, j) - u[i] - v[j];
+        if (r < spc[j]) {
+          path[j] = i;
+          spc[j] = r;
+        }
+        if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) {
+          lowest = spc[j];
+          index = it;
+        }
+      }
+      min_val = lowest;
+      if (min_val == INFINITY) { ok = 0; break; } /* infeasible */
+      const int j = remaining[index];
+      if (row4col[j] == -1) sink = j; else i = row4col[j];
+      SC[j] = 1;
+      remaining[index] = remaining[--num_remaining];
+    }
+    if (!ok) break;
+    u[cur] += min_val;
+    for (int r = 0; r < nr; ++r)
+      if (SR[r] && r != cur) u[r] += min_val - spc[col4row[r]];
+    for (int j = 0; j < nc; ++j)
+      if (SC[j]) v[j] -= min_val - spc[j];
+    int j = sink;
+    for (;;) {
+      const int r = path[j];
+      row4col[j] = r;
+      const int t = col4row[r];
+      col4row[r] = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+#undef COST
+  if (ok) {
+    if (transposed) for (int g = 0; g < nr; ++g) query_of_gt[g] = col4row[g];
+    else for (int q = 0; q < nr; ++q) query_of_gt[col4row[q]] = q;
+  }
+  free(u); free(v); free(spc); free(path); free(col4row); free(row4col); free(remaining); free(SR); free(SC);
+  return ok ? 0 : -1;
+}

@@ -72,6 +72,9 @@ float oracle_iou_bev(const float* box_a, const float* box_b);
 void oracle_boxes_bev(const float* a, int na, const float* b, int nb, int mode, float* out);
 int oracle_nms(const float* boxes, int n, float thresh, int rotated, int64_t* keep);
 
+/* ---- next row "GPU matcher": scipy.optimize.linear_sum_assignment ($CQ/modules/matcher.py:89) ---- */
+int oracle_lsap(const float* cost, int nq, int g_stride, int ng, int64_t* query_of_gt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,7 +121,10 @@ def test_batched_contrastive_loss_matches_reference_loop():
     ob = torch.rand(n_layers, 2, tot, 7, generator=g)
     targets = [{"gt_boxes": torch.rand(n, 7)} for n in per_gt]
     matched = [(torch.tensor([5, 17, 2, 9]), torch.tensor([0, 1, 2, 3])), (torch.tensor([11, 0]), torch.tensor([1, 0]))]
-    got = m._contrastive_losses(oc, ob, matched, targets, {"num_dn_group": groups})
+    q_of_g = torch.full((2, max_gt), -1, dtype=torch.int64)
+    for bi, (qi, gi) in enumerate(matched):
+        q_of_g[bi, gi] = qi
+    got = m._contrastive_losses(oc, ob, q_of_g, targets, {"num_dn_group": groups})
     sim_f = torch.nn.CosineSimilarity(dim=2)
     num_gts = sum(per_gt)
     for li in range(n_layers):
