@@ -7,8 +7,9 @@
 //   ref window [7], box offsets [V = 4|5], attention logits [L*P], the P x 2 kernel lattice,
 // and rebuilds centre / size / rotation / softmax in registers.  Backward returns gradients w.r.t. the
 // value map, the raw box offsets and the raw logits (softmax and geometry backward fused in).
-// Same lane mapping as msda.hip (LP = D/4 lanes x float4 per pair); encoder self-attention
-// (queries on the value grid) accumulates grad_value in an fp64 LDS window like msda_bwd_grid_kernel.
+// Same lane mapping as msda.hip (LP = D/4 lanes x float4 per pair).  Encoder self-attention (queries on the
+// value grid, L*P <= 32) has its own backward in GEMM form, box_bwd_tile_kernel below; larger point counts
+// accumulate grad_value in an fp64 LDS window like msda_bwd_grid_kernel.
 #include "common.h"
 #include <cmath>
 
@@ -334,6 +335,316 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   }  // tile loop
 }
 
+// ---- encoder backward in GEMM form ---------------------------------------------------------------
+// Encoder self-attention: the queries ARE the cells of the (single-level) value map, so an 8x8 query tile only
+// touches the 16x16 window of cells around it.  Per (tile, head, scene) the whole backward then factors into two
+// small dense products plus SCALAR scatter / gather work -- no per-channel atomics and no per-point channel
+// gathers (the previous kernel issued 3200 fp64 LDS atomics and 100 float4 gathers per (query, head)):
+//
+//   G [64 q  x 256 cells] = GO [64 x 32] . V^T [32 x 256]        (MFMA)   "what each cell's value says to q"
+//       grad_attn(q, p)   = sum_corners wc * G[q][cell]                    4 scalar LDS reads per point
+//       grad_loc (q, p)   = bilinear differences of the same 4 scalars
+//   W [256 cells x 64 q]  += attn * wc   at the 4 corner cells             plain LDS read-modify-write: column q
+//                                                                          is private to its 4 corner lanes
+//   GV[256 cells x 32]    = W [256 x 64] . GO [64 x 32]           (MFMA)   -> one global atomic per touched
+//                                                                          (cell, channel) of the window
+//
+// G and W share one LDS buffer (pass A reads G, pass B rebuilds the geometry and fills W).  Sampling points
+// that leave the window (boxes grown past R = 4 cells) take a per-channel global path, as before.
+namespace bt {
+constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R, NQ = TQ * TQ, NC = WIN * WIN, D = 32;
+constexpr int VS = 36;    // row stride of V / GO tiles (floats, 16-byte aligned rows)
+constexpr int GS = 260;   // G[q][cell]
+constexpr int WS = 68;    // W[cell][q]
+constexpr int PMAX = 32;  // L * P of the fused encoder path
+constexpr int kThreads = 512;
+constexpr int kGW = (NQ * GS > NC * WS) ? NQ * GS : NC * WS;
+constexpr size_t kLdsBytes = sizeof(float) * (NC * VS + NQ * VS + kGW + 2 * NQ * PMAX + 2 * PMAX);
+}  // namespace bt
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ BoxGeo make_box_v(const float rf[5], const float of[5], int v) {
+  BoxGeo g;
+  g.rw = rf[2];
+  g.rh = rf[3];
+  g.cx = rf[0] + of[0] / 8.0f * g.rw;
+  g.cy = rf[1] + of[1] / 8.0f * g.rh;
+  const float w = g.rw + of[2] / 8.0f * g.rw, h = g.rh + of[3] / 8.0f * g.rh;
+  g.w_on = w > 0.0f;
+  g.h_on = h > 0.0f;
+  g.w = g.w_on ? w : 0.0f;
+  g.h = g.h_on ? h : 0.0f;
+  const float ang = (v == 5) ? (rf[4] + of[4] / 16.0f) * 2.0f * 3.14159274f : rf[4];
+  g.cs = cosf(ang);
+  g.sn = sinf(ang);
+  return g;
+}
+
+__global__ void __launch_bounds__(bt::kThreads)
+box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
+                    const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ logits,
+                    const float* __restrict__ kidx, const float* __restrict__ grad_out, BoxDims dm,
+                    float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits) {
+  using namespace bt;
+  extern __shared__ float lds[];
+  float* Vs = lds;                     // [NC][VS]
+  float* GOs = Vs + NC * VS;           // [NQ][VS]
+  float* GW = GOs + NQ * VS;           // G [NQ][GS]  |  W [NC][WS]
+  float* a_s = GW + kGW;               // [NQ][PMAX] un-normalised softmax weights
+  float* ga_s = a_s + NQ * PMAX;       // [NQ][PMAX]
+  float* k_s = ga_s + NQ * PMAX;       // [PMAX][2] the k x k lattice (read at every point: keep it out of global)
+  const int Hm = (int)shapes[0], Wm = (int)shapes[1];
+  if ((long long)Hm * Wm != dm.s) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2 * dm.p) k_s[tid] = kidx[tid];
+  const int slot = tid >> 3, sub = tid & 7, corner = sub & 3, half = sub >> 2;
+  const int m = blockIdx.y, bi = blockIdx.z;
+  const int np = dm.p;  // single level
+  const int tiles_x = (Wm + TQ - 1) / TQ;
+  const int ntiles = ((Hm + TQ - 1) / TQ) * tiles_x;
+  const long long S = dm.s;
+  constexpr int VPT = NC * (D / 4) / kThreads;  // float4 of the value window per thread (4)
+  constexpr int EPT = PMAX / 2;                 // points per lane (one half of the lattice)
+
+  // Everything a work item reads from global memory, fetched one item ahead: with 132 KB of LDS there is one
+  // workgroup per CU and all of its waves sit in the same phase, so nothing else would hide the latency.
+  struct Pre {
+    float4 v[VPT];
+    float4 go;
+    float lg[4], rf[5], of[5];
+  } pre;
+  auto fetch = [&](int tile) {
+    const int ty0 = (tile / tiles_x) * TQ, tx0 = (tile % tiles_x) * TQ;
+#pragma unroll
+    for (int it = 0; it < VPT; ++it) {
+      const int idx = tid + it * kThreads;
+      const int cell = idx >> 3, c4 = (idx & 7) * 4;
+      const int cy = min(max(ty0 - R + cell / WIN, 0), Hm - 1), cx = min(max(tx0 - R + cell % WIN, 0), Wm - 1);
+      pre.v[it] = ld4(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + c4);
+    }
+    const int qy = min(ty0 + slot / TQ, Hm - 1), qx = min(tx0 + slot % TQ, Wm - 1);
+    const long long bq = (long long)bi * dm.lq + (long long)qy * Wm + qx, t = bq * dm.h + m;
+    pre.go = ld4(grad_out + t * D + sub * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre.lg[k] = logits[t * np + min(sub + 8 * k, np - 1)];
+    const float* r = ref + bq * 7;
+    pre.rf[0] = r[0];
+    pre.rf[1] = r[1];
+    pre.rf[2] = r[3];
+    pre.rf[3] = r[4];
+    pre.rf[4] = r[6];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pre.of[k] = off[t * dm.v + min(k, dm.v - 1)];
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty0 = (tile / tiles_x) * TQ, tx0 = (tile % tiles_x) * TQ;
+    const int wy0 = ty0 - R, wx0 = tx0 - R;
+    __syncthreads();  // previous item's GEMM-2 is done with GOs / W
+    // ---- S0: registers -> LDS ------------------------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < VPT; ++it) {
+      const int idx = tid + it * kThreads;
+      const int cell = idx >> 3, c4 = (idx & 7) * 4;
+      const int cy = wy0 + cell / WIN, cx = wx0 + cell % WIN;
+      const bool in = cy >= 0 && cy < Hm && cx >= 0 && cx < Wm;
+      *reinterpret_cast<float4*>(Vs + cell * VS + c4) = in ? pre.v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int qy = ty0 + slot / TQ, qx = tx0 + slot % TQ;
+    const bool qok = qy < Hm && qx < Wm;
+    const long long t = qok ? (((long long)bi * dm.lq + (long long)qy * Wm + qx) * dm.h + m) : 0;
+    *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? pre.go : make_float4(0.f, 0.f, 0.f, 0.f);
+    // softmax statistics of the pair (8 lanes share the work)
+    float* as = a_s + slot * PMAX;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) mx = fmaxf(mx, pre.lg[k]);
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) {
+        const float ex = expf(pre.lg[k] - mx);
+        as[sub + 8 * k] = ex;
+        den += ex;
+      }
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) den += __shfl_xor(den, dlt, 64);
+    const float inv = 1.0f / den;
+    const BoxGeo g = make_box_v(pre.rf, pre.of, dm.v);
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight during the phases below
+
+    // ---- S1: G = GO . V^T ----------------------------------------------------------------------------------
+    {
+      const int mb = wave >> 1, nb0 = (wave & 1) * 8;
+      const int r16 = lane & 15, kk = lane >> 4;
+      float a[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) a[ks] = GOs[(16 * mb + r16) * VS + 4 * ks + kk];
+#pragma unroll
+      for (int nbi = 0; nbi < 8; nbi += 2) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* b0 = Vs + (16 * (nb0 + nbi) + r16) * VS + kk;
+        const float* b1 = b0 + 16 * VS;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b0[4 * ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b1[4 * ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* gp = GW + (16 * mb + 4 * kk + r) * GS + 16 * (nb0 + nbi) + r16;
+          gp[0] = acc0[r];
+          gp[16] = acc1[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- S2 (pass A): this lane = (query, corner, half of the lattice).  Gradients wrt the attention weights
+    // and the sampling locations come from 4 scalars of G per point; the (cell, weight) of the lane's corner is
+    // kept in registers for pass B.
+    float dcx = 0.f, dcy = 0.f, dw = 0.f, dh = 0.f, dth = 0.f, dot = 0.f;
+    int e_cell[EPT];    // window cell (>= 0), -1: nothing to add, -2: outside the window (global path)
+    float e_w[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int pi = half + 2 * k;
+      e_cell[k] = -1;
+      e_w[k] = 0.f;
+      if (qok && pi < np) {
+        const float kxn = k_s[pi * 2], kyn = k_s[pi * 2 + 1];
+        const float gx = kxn * g.w, gy = kyn * g.h;
+        const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
+        const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
+        const float wgt = as[pi] * inv;
+        const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)Hm), 0.5f);
+        const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)Wm), 0.5f);
+        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lwf;
+        const int cy = h_low + (corner >> 1), cx = w_low + (corner & 1);
+        const bool ok = inside && cy >= 0 && cy <= Hm - 1 && cx >= 0 && cx <= Wm - 1;
+        const int ly = cy - wy0, lx = cx - wx0;
+        const bool in_win = (unsigned)ly < (unsigned)WIN && (unsigned)lx < (unsigned)WIN;
+        float gval = 0.f;
+        if (ok) {
+          e_w[k] = wgt * (((corner >> 1) ? lh : hh) * ((corner & 1) ? lwf : hw));
+          if (in_win) {
+            e_cell[k] = ly * WIN + lx;
+            gval = GW[slot * GS + e_cell[k]];
+          } else {  // the box has grown out of the window: dot product against the global value row
+            e_cell[k] = -2;
+            const float* vr = value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D;
+            for (int c = 0; c < D; ++c) gval = fmaf(GOs[slot * VS + c], vr[c], gval);
+          }
+        }
+        const float g0 = quad_bcast<0>(gval), g1 = quad_bcast<1>(gval), g2 = quad_bcast<2>(gval), g3 = quad_bcast<3>(gval);
+        const float ga = fmaf(lh * lwf, g3, fmaf(lh * hw, g2, fmaf(hh * lwf, g1, hh * hw * g0)));
+        const float gwl = (float)Wm * wgt * fmaf(hh, g1 - g0, lh * (g3 - g2));
+        const float ghl = (float)Hm * wgt * fmaf(hw, g2 - g0, lwf * (g3 - g1));
+        dcx += gwl;
+        dcy += ghl;
+        dw += kxn * (gwl * g.cs + ghl * g.sn);
+        dh += kyn * (ghl * g.cs - gwl * g.sn);
+        dth += gwl * (-(gx * g.sn) - gy * g.cs) + ghl * (gx * g.cs - gy * g.sn);
+        dot = fmaf(wgt, ga, dot);
+        if (corner == 0) ga_s[slot * PMAX + pi] = ga;
+      }
+    }
+    // the two halves (even / odd points) of a pair sit 4 lanes apart
+    dcx += __shfl_xor(dcx, 4, 64);
+    dcy += __shfl_xor(dcy, 4, 64);
+    dw += __shfl_xor(dw, 4, 64);
+    dh += __shfl_xor(dh, 4, 64);
+    dth += __shfl_xor(dth, 4, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (qok && sub == 0) {
+      float* go = grad_off + t * dm.v;
+      go[0] = dcx * g.rw / 8.0f;
+      go[1] = dcy * g.rh / 8.0f;
+      go[2] = g.w_on ? dw * g.rw / 8.0f : 0.0f;
+      go[3] = g.h_on ? dh * g.rh / 8.0f : 0.0f;
+      if (dm.v == 5) go[4] = dth * (2.0f * 3.14159274f / 16.0f);
+    }
+    __syncthreads();  // G fully consumed; ga_s complete
+    if (qok)
+      for (int e = sub; e < np; e += 8) grad_logits[t * np + e] = as[e] * inv * (ga_s[slot * PMAX + e] - dot);
+
+    // ---- S3 / S4 (pass B): W[cell][q] = sum of attn * bilinear weight ---------------------------------------
+    for (int i = tid; i < NC * WS / 4; i += kThreads) reinterpret_cast<float4*>(GW)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // Column `slot` of W belongs to the 8 lanes of the query.  At one step the 4 corner lanes of a half hit 4
+    // distinct cells, so a plain read-modify-write is safe; the two halves take turns (their points may share
+    // a cell), and the LDS pipe keeps consecutive steps of a wave in order.
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (half == hsel && e_cell[k] >= 0) GW[e_cell[k] * WS + slot] += e_w[k];
+        asm volatile("" ::: "memory");
+      }
+    }
+    // rare: corners outside the window go straight to global memory, channel by channel
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (e_cell[k] == -2) {
+        const int pi = half + 2 * k;
+        const float kxn = k_s[pi * 2], kyn = k_s[pi * 2 + 1];
+        const float gx = kxn * g.w, gy = kyn * g.h;
+        const float h_im = __fsub_rn(__fmul_rn(g.cy + (gx * g.sn + gy * g.cs), (float)Hm), 0.5f);
+        const float w_im = __fsub_rn(__fmul_rn(g.cx + (gx * g.cs + gy * (-g.sn)), (float)Wm), 0.5f);
+        const int cy = (int)floorf(h_im) + (corner >> 1), cx = (int)floorf(w_im) + (corner & 1);
+        float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D;
+        for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
+      }
+    }
+    __syncthreads();
+
+    // ---- S5: GV = W . GO, flushed with one atomic per touched (cell, channel) -------------------------------
+    {
+      const int r16 = lane & 15, kk = lane >> 4;
+      f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+      const float* a0p = GW + (16 * (2 * wave) + r16) * WS + kk;
+      const float* a1p = a0p + 16 * WS;
+      const float* bp = GOs + kk * VS + r16;
+#pragma unroll
+      for (int ks = 0; ks < NQ / 4; ++ks) {
+        const float a0 = a0p[4 * ks], a1 = a1p[4 * ks];
+        const float b0 = bp[4 * ks * VS], b1 = bp[4 * ks * VS + 16];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cell = 16 * (2 * wave + i) + 4 * kk + r;
+          const int cy = wy0 + cell / WIN, cx = wx0 + cell % WIN;
+          if (cy >= 0 && cy < Hm && cx >= 0 && cx < Wm) {
+            float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
+            if (acc[i][0][r] != 0.0f) unsafeAtomicAdd(gv, acc[i][0][r]);
+            if (acc[i][1][r] != 0.0f) unsafeAtomicAdd(gv + 16, acc[i][1][r]);
+          }
+        }
+    }
+  }  // tile loop
+}
+
 int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) {
   EFG_CHECK_ARG(b >= 0 && s >= 0 && h >= 1 && l >= 1 && lq >= 0 && p >= 1, "box_attn_fused: bad dimensions");
   EFG_CHECK_ARG(v == 4 || v == 5, "box_attn_fused: offsets must have 4 or 5 variables, got %d", v);
@@ -386,10 +697,17 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     // device-side, so the launch is sized for a square map and the kernel strides over the tiles.
     const int side = (int)std::ceil(std::sqrt((double)s));
     const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
-    if (l * p <= 32)
-      hipLaunchKernelGGL((box_bwd_kernel<32, true, 32>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
-                         value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
+    if (l * p <= bt::PMAX) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        EFG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(box_bwd_tile_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::kLdsBytes));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes,
+                         (hipStream_t)stream, value, (const long long*)shapes, ref_windows, offsets, logits,
                          kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
+    }
     else
       hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
                          value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,

@@ -137,7 +137,7 @@ class BoxAttnFusedFunction(Function):
         cost = lambda: (4 * (2 * b * s * h * d + 2 * b * lq * (h * l * (ctx.num_var + p)) + 2 * b * lq * h * d),  # noqa: E731
                         30 * b * lq * h * l * p * d)
         grid = (l == 1 and s == lq and s >= 1024)
-        name = ("box_bwd_kernel<32, true, 32>" if l * p <= 32 else "box_bwd_kernel<32, true, 128>") if grid \
+        name = ("box_bwd_tile_kernel" if l * p <= 32 else "box_bwd_kernel<32, true, 128>") if grid \
             else "box_bwd_kernel<32, false, 128>"
         with _prof.timed(name, cost):
             L.check(L.lib().efg_box_attn_fused_backward_f32(L.ptr(value), L.ptr(shapes.contiguous()),

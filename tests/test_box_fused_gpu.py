@@ -36,7 +36,8 @@ def _run(m, fused, query, value, shapes, start, ref):
         baf.FUSED_ENABLED = old
 
 
-@pytest.mark.parametrize("case", ["encoder_grid", "decoder_rot", "decoder_norot_small"])
+@pytest.mark.parametrize("case", ["encoder_grid", "encoder_grid_rot", "encoder_grid_big", "decoder_rot",
+                                  "decoder_norot_small"])
 def test_fused_matches_reference_sequence(dev, case):
     g = torch.Generator().manual_seed(1)
     H, W = 40, 36
@@ -44,13 +45,17 @@ def test_fused_matches_reference_sequence(dev, case):
     shapes = torch.tensor([[H, W]], device=dev)
     start = torch.zeros(1, dtype=torch.int64, device=dev)
     value = torch.randn(2, S, 256, generator=g).to(dev)
-    if case == "encoder_grid":   # queries are the map cells, no rotation -> LDS-window backward
-        rot, lq = False, S
+    if case.startswith("encoder_grid"):   # queries are the map cells -> tile (GEMM-form) backward
+        rot, lq = case.endswith("rot"), S
         ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
         ref = torch.zeros(2, S, 7)
         ref[..., 0], ref[..., 1] = (xs / W).reshape(-1), (ys / H).reshape(-1)
         ref[..., 2] = ref[..., 5] = 0.5
         ref[..., 3] = ref[..., 4] = 0.08
+        if case.endswith("big"):   # 14-cell boxes: most sampling points leave the 16x16 window (global path)
+            ref[..., 3] = ref[..., 4] = 0.4
+        if rot:
+            ref[..., 6] = torch.rand(2, S, generator=g)
     else:
         rot, lq = (case == "decoder_rot"), 77
         ref = torch.rand(2, lq, 7, generator=g)
