@@ -39,7 +39,12 @@ def _pmc_traffic(kernel):
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            kernels = json.load(f)["kernels"]
+        if kernel not in kernels and "+" in kernel:  # "a+b": a label that times two kernels together
+            parts = kernel.split("+")
+            if all(k in kernels for k in parts):
+                return sum(kernels[k]["hbm_bytes_per_launch"] for k in parts)
+        return kernels[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 

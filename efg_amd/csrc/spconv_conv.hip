@@ -79,11 +79,24 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   __shared__ float a_tile[4][16 * kAStride];
   __shared__ int nbr_tile[4][KV * 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long r0 = ((long long)blockIdx.x * 4 + wv) * 16;
+  // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) by linear id;
+  // rows are in canonical spatial order, so the 27 gathers of a row block hit rows that neighbouring row blocks
+  // also read.  With the hardware order those neighbours sit on 8 different L2s (measured: 8x the algorithmic
+  // bytes fetched past L2); renumbering gives every XCD one contiguous range of row blocks.
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
+    if (per > 0 && lin < (per << 3)) {
+      const unsigned nl = (lin & 7) * per + (lin >> 3);
+      bx = nl % gridDim.x;
+      by = nl / gridDim.x;
+    }
+  }
+  const long long r0 = ((long long)bx * 4 + wv) * 16;
   if (r0 >= a.m_out) return;  // whole wave out of range (waves never sync with each other)
   float* at0 = a_tile[wv];
   int* nb = nbr_tile[wv];
-  const int n_tile0 = blockIdx.y * NT;  // first n-tile of this block
+  const int n_tile0 = by * NT;  // first n-tile of this block
 
   // stage the wave's rulebook block and find the active offsets
   for (int e = lane; e < a.kvol * 16; e += 64) {

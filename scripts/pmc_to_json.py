@@ -13,6 +13,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     with open("%s/%s.summary.csv" % (src, ctr)) as f:
         for row in csv.DictReader(f):
             name = row["kernel"].replace("efg::", "").replace(";", ",")
+            # bench.py labels: conv_fwd_kernel<NT> (the KV = 32 template argument is fixed)
+            if name.startswith("conv_fwd_kernel<") and name.endswith(", 32>"):
+                name = name[: -len(", 32>")] + ">"
             vals.setdefault(name, {})[ctr] = float(row["mean_" + ctr])
             vals[name]["launches_" + ctr] = int(row["launches"])
 out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
