@@ -11,6 +11,7 @@
 // value grid, L*P <= 32) has its own backward in GEMM form, box_bwd_tile_kernel below; larger point counts
 // accumulate grad_value in an fp64 LDS window like msda_bwd_grid_kernel.
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 
 namespace efg {
@@ -147,7 +148,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
                const long long* __restrict__ starts, const float* __restrict__ ref, const float* __restrict__ off,
                const float* __restrict__ logits, const float* __restrict__ kidx, const float* __restrict__ grad_out,
                BoxDims dm, float* __restrict__ grad_value, float* __restrict__ grad_off,
-               float* __restrict__ grad_logits) {
+               float* __restrict__ grad_logits, int* __restrict__ cursor, int2* __restrict__ entries) {
   constexpr int LP = D / 4, SLOTS = 256 / LP;
   constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R;
   __shared__ double win[kWin ? WIN * WIN * D : 1];
@@ -263,6 +264,14 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
                 for (int j = 0; j < 4; ++j) {
                   const int jj = (j + rot) & 3;
                   atomicAdd(wp + jj, (double)gq[jj]);
+                }
+              } else if (cursor) {
+                // binned path: one (row of grad_out, weight) entry per corner instead of D float atomics; the
+                // entries are summed per (cell, head) by box_bin_reduce_kernel
+                if (sub == 0) {
+                  const long long bin = ((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m;
+                  const int slot_e = atomicAdd(cursor + bin, 1);
+                  entries[slot_e] = make_int2((int)t, __float_as_int(wc[cn] * wgt));
                 }
               } else {
 #pragma unroll
@@ -645,6 +654,144 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   }  // tile loop
 }
 
+// ---- binned grad_value (decoder) -------------------------------------------------------------------------
+// Decoder queries sample anywhere, so their grad_value contributions cannot be tiled; as float atomics they are
+// D atomics per (query, head, point, corner), and on MI355X device-scope atomics are executed past the per-XCD
+// L2s (1.0 GB of atomic traffic and 0.75 ms per launch for 2 x 1240 queries).  Instead every corner emits ONE
+// 8-byte entry (grad_out row, weight) into the bin of its (scene, cell, head) row:
+//   count (1 int atomic per corner) -> exclusive scan -> main kernel writes entries at atomically allocated
+//   slots -> one 8-lane group per non-empty bin sums weight * grad_out[row] and owns the output row.
+__global__ void __launch_bounds__(256)
+box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __restrict__ starts,
+                     const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ kidx,
+                     BoxDims dm, int* __restrict__ counts) {
+  // one thread per (query, head, level, point): the same location arithmetic as box_bwd_kernel
+  const long long total = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int pi = (int)(e % dm.p);
+  const int li = (int)((e / dm.p) % dm.l);
+  const long long t = e / ((long long)dm.p * dm.l);
+  const int m = (int)(t % dm.h);
+  const long long bq = t / dm.h;
+  const int bi = (int)(bq / dm.lq);
+  const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
+  const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
+  const float gx = kidx[pi * 2] * g.w, gy = kidx[pi * 2 + 1] * g.h;
+  const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
+  const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
+  const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
+  const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
+  if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) return;
+  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+#pragma unroll
+  for (int cn = 0; cn < 4; ++cn) {
+    const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
+    if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1)
+      atomicAdd(counts + (((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m), 1);
+  }
+}
+
+constexpr int kScanTile = 1024;  // elements per workgroup of the 3-kernel exclusive scan
+
+__global__ void __launch_bounds__(256) scan_tiles_kernel(int* __restrict__ data, long long n, int* __restrict__ totals) {
+  __shared__ int sm[17];
+  const long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * 4;
+  int v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? data[base + j] : 0;
+  int tot;
+  const int pre = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], sm, &tot);
+  int run = pre;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (base + j < n) data[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) scan_totals_kernel(int* __restrict__ totals, int nblk) {
+  __shared__ int sm[17];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? totals[i] : 0;
+    int tot;
+    const int pre = block_exclusive_scan(v, sm, &tot);
+    const int carry = carry_s;
+    if (i < nblk) totals[i] = carry + pre;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+}
+
+// offsets[i] += totals[tile]; cursor[i] = offsets[i]
+__global__ void __launch_bounds__(256) scan_apply_kernel(int* __restrict__ offsets, long long n,
+                                                         const int* __restrict__ totals, int* __restrict__ cursor) {
+  const long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * 4;
+  const int add = totals[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n) {
+      const int o = offsets[base + j] + add;
+      offsets[base + j] = o;
+      cursor[base + j] = o;
+    }
+}
+
+// grad_value row `bin` += sum over its entries of weight * grad_out[row]; 8 lanes x float4 per bin.  After the
+// main kernel cursor[bin] is the END of the bin, offsets[bin] its start.
+__global__ void __launch_bounds__(256)
+box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ cursor, const int2* __restrict__ entries,
+                      const float* __restrict__ grad_out, long long nbins, float* __restrict__ grad_value) {
+  const int c4 = (threadIdx.x & 7) * 4;
+  for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
+    const int s = offsets[bin], e = cursor[bin];
+    if (s == e) continue;
+    float4 acc = ld4(grad_value + bin * 32 + c4);
+    for (int i = s; i < e; ++i) {
+      const int2 en = entries[i];
+      const float w = __int_as_float(en.y);
+      const float4 g = ld4(grad_out + (long long)en.x * 32 + c4);
+      acc.x = fmaf(w, g.x, acc.x);
+      acc.y = fmaf(w, g.y, acc.y);
+      acc.z = fmaf(w, g.z, acc.z);
+      acc.w = fmaf(w, g.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(grad_value + bin * 32 + c4) = acc;
+  }
+}
+
+struct BinPlan {
+  long long nbins, nentries;
+  int ntiles;
+  size_t off_offsets, off_cursor, off_totals, off_entries, bytes;
+};
+
+BinPlan bin_plan(int b, int s, int h, int l, int lq, int p) {
+  BinPlan pl;
+  pl.nbins = (long long)b * s * h;
+  pl.nentries = (long long)b * lq * h * l * p * 4;
+  pl.ntiles = (int)ceil_div(pl.nbins, kScanTile);
+  size_t o = 0;
+  pl.off_offsets = o;
+  o += align_up(sizeof(int) * (size_t)pl.nbins, 256);
+  pl.off_cursor = o;
+  o += align_up(sizeof(int) * (size_t)pl.nbins, 256);
+  pl.off_totals = o;
+  o += align_up(sizeof(int) * (size_t)pl.ntiles, 256);
+  pl.off_entries = o;
+  o += align_up(sizeof(int2) * (size_t)pl.nentries, 256);
+  pl.bytes = o;
+  return pl;
+}
+
+constexpr long long kBinMinEntries = 200000;  // below this the extra launches cost more than the atomics
+
 int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) {
   EFG_CHECK_ARG(b >= 0 && s >= 0 && h >= 1 && l >= 1 && lq >= 0 && p >= 1, "box_attn_fused: bad dimensions");
   EFG_CHECK_ARG(v == 4 || v == 5, "box_attn_fused: offsets must have 4 or 5 variables, got %d", v);
@@ -682,11 +829,17 @@ extern "C" int efg_box_attn_fused_forward_f32(const float* value, const int64_t*
   return EFG_OK;
 }
 
+extern "C" size_t efg_box_attn_fused_backward_workspace_bytes(int b, int s, int h, int l, int lq, int p) {
+  if (b < 0 || s < 0 || h < 1 || l < 1 || lq < 0 || p < 1) return 0;
+  return bin_plan(b, s, h, l, lq, p).bytes;
+}
+
 extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                                                const float* ref_windows, const float* offsets, const float* logits,
                                                const float* kernel_indices, const float* grad_out, int b, int s, int h,
                                                int d, int l, int lq, int p, int v, float* grad_value,
-                                               float* grad_offsets, float* grad_logits, void* stream) {
+                                               float* grad_offsets, float* grad_logits, void* ws, size_t ws_bytes,
+                                               void* stream) {
   BoxDims dm;
   if (int rc = check(b, s, h, d, l, lq, p, v, &dm)) return rc;
   EFG_CHECK_ARG(d == 32, "box_attn_fused backward: head dim 32 only (got %d); use the unfused op", d);
@@ -711,12 +864,41 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     else
       hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
                          value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
-                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
+                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, nullptr, nullptr);
   } else {
-    hipLaunchKernelGGL((box_bwd_kernel<32, false>), dim3((unsigned)ceil_div(total, 32)), dim3(256), 0,
-                       (hipStream_t)stream, value, (const long long*)shapes, (const long long*)level_start,
-                       ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value, grad_offsets,
-                       grad_logits);
+    const BinPlan pl = bin_plan(b, s, h, l, lq, p);
+    hipStream_t st = (hipStream_t)stream;
+    const bool binned = ws != nullptr && pl.nentries >= kBinMinEntries && pl.nentries < (1ll << 31) &&
+                        pl.nbins < (1ll << 31);
+    int* cursor = nullptr;
+    int2* entries = nullptr;
+    int* offs = nullptr;
+    if (binned) {
+      EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
+      char* base = static_cast<char*>(ws);
+      offs = reinterpret_cast<int*>(base + pl.off_offsets);
+      cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+      int* totals = reinterpret_cast<int*>(base + pl.off_totals);
+      entries = reinterpret_cast<int2*>(base + pl.off_entries);
+      EFG_HIP_TRY(hipMemsetAsync(offs, 0, sizeof(int) * (size_t)pl.nbins, st));
+      const long long npts = (long long)b * lq * h * l * p;
+      hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st,
+                         (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, kernel_indices,
+                         dm, offs);
+      hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals);
+      hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
+      hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals, cursor);
+      EFG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((box_bwd_kernel<32, false>), dim3((unsigned)ceil_div(total, 32)), dim3(256), 0, st, value,
+                       (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
+                       kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, cursor, entries);
+    if (binned) {
+      EFG_LAUNCH_CHECK();
+      const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
+      hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out,
+                         pl.nbins, grad_value);
+    }
   }
   EFG_LAUNCH_CHECK();
   return EFG_OK;

@@ -139,10 +139,15 @@ class BoxAttnFusedFunction(Function):
         grid = (l == 1 and s == lq and s >= 1024)
         name = ("box_bwd_tile_kernel" if l * p <= 32 else "box_bwd_kernel<32, true, 128>") if grid \
             else "box_bwd_kernel<32, false, 128>"
+        ws, ws_bytes = None, 0
+        if not grid:  # free-position queries: scratch for the binned grad_value reduction (csrc/box_fused.hip)
+            ws_bytes = L.lib().efg_box_attn_fused_backward_workspace_bytes(b, s, h, l, lq, p)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
         with _prof.timed(name, cost):
             L.check(L.lib().efg_box_attn_fused_backward_f32(L.ptr(value), L.ptr(shapes.contiguous()),
                                                             L.ptr(start.contiguous()), L.ptr(ref), L.ptr(offsets),
                                                             L.ptr(logits), L.ptr(kidx), L.ptr(grad_output), b, s, h,
                                                             d, l, lq, p, ctx.num_var, L.ptr(grad_value),
-                                                            L.ptr(grad_off), L.ptr(grad_logits), L.stream()))
+                                                            L.ptr(grad_off), L.ptr(grad_logits), L.ptr(ws), ws_bytes,
+                                                            L.stream()))
         return grad_value, None, None, None, grad_off, grad_logits, None, None

@@ -194,11 +194,15 @@ int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, co
                                    const float* ref_windows, const float* offsets, const float* logits,
                                    const float* kernel_indices, int b, int s, int h, int d, int l, int lq, int p,
                                    int v, float* out, void* stream);
+/* ws (optional, may be NULL): scratch of efg_box_attn_fused_backward_workspace_bytes(...) bytes.  With it, large
+ * free-position (decoder) launches sum their grad_value contributions through sorted 8-byte entries instead of
+ * d float atomics per corner; without it, or for small launches, atomics are used.  Same results either way. */
+size_t efg_box_attn_fused_backward_workspace_bytes(int b, int s, int h, int l, int lq, int p);
 int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                                     const float* ref_windows, const float* offsets, const float* logits,
                                     const float* kernel_indices, const float* grad_out, int b, int s, int h, int d,
                                     int l, int lq, int p, int v, float* grad_value, float* grad_offsets,
-                                    float* grad_logits, void* stream);
+                                    float* grad_logits, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rotated BEV overlap / IoU and NMS.  Replaces

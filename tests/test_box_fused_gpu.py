@@ -37,7 +37,7 @@ def _run(m, fused, query, value, shapes, start, ref):
 
 
 @pytest.mark.parametrize("case", ["encoder_grid", "encoder_grid_rot", "encoder_grid_big", "decoder_rot",
-                                  "decoder_norot_small"])
+                                  "decoder_rot_many", "decoder_norot_small"])
 def test_fused_matches_reference_sequence(dev, case):
     g = torch.Generator().manual_seed(1)
     H, W = 40, 36
@@ -57,7 +57,7 @@ def test_fused_matches_reference_sequence(dev, case):
         if rot:
             ref[..., 6] = torch.rand(2, S, generator=g)
     else:
-        rot, lq = (case == "decoder_rot"), 77
+        rot, lq = case.startswith("decoder_rot"), (400 if case.endswith("many") else 77)  # many: binned grad_value
         ref = torch.rand(2, lq, 7, generator=g)
         ref[..., 3:5] = ref[..., 3:5] * 0.2 + 0.02
         if case == "decoder_norot_small":
