@@ -8,6 +8,7 @@ from torch import nn
 from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
+from ..operators.layernorm import add_layer_norm
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
 from .utils import MLP, flatten_with_shape, get_clones
@@ -35,9 +36,9 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, src_shape, src_start_idx, ref_windows):
         src2 = self.self_attn(_with_pos(src, pos), src, src_shape, None, src_start_idx, None, ref_windows)[0]
-        src = self.norm1(src + self.dropout1(src2))
+        src = add_layer_norm(src, self.dropout1(src2), self.norm1)
         src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout2(src2))
+        return add_layer_norm(src, self.dropout2(src2), self.norm2)
 
 
 class TransformerEncoder(nn.Module):
@@ -85,12 +86,12 @@ class TransformerDecoderLayer(nn.Module):
         # need_weights=False: same output, skips materialising the head-averaged attention map the reference
         # computes and discards ($CQ/transformer.py:295)
         query2 = self.self_attn(q, k, v, attn_mask=attn_mask, need_weights=False)[0].transpose(0, 1)
-        query = self.norm1(query + self.dropout1(query2))
+        query = add_layer_norm(query, self.dropout1(query2), self.norm1)
         query2 = self.multihead_attn(_with_pos(query, query_pos), memory, memory_shape, None, memory_start_idx, None,
                                      ref_windows[..., :7])[0]
-        query = self.norm2(query + self.dropout2(query2))
+        query = add_layer_norm(query, self.dropout2(query2), self.norm2)
         query2 = self.linear2(self.dropout(self.activation(self.linear1(query))))
-        return self.norm3(query + self.dropout3(query2))
+        return add_layer_norm(query, self.dropout3(query2), self.norm3)
 
 
 class TransformerDecoder(nn.Module):

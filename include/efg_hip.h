@@ -236,6 +236,21 @@ int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int rotated, int
 int efg_lsap_f32(const float* cost, int n_problems, int nq, int g_stride, const int32_t* ng,
                  int64_t* query_of_gt, int32_t* status, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused residual-add + LayerNorm (the post-norm steps of $CQ/transformer.py:231-243,296-317, which the
+ * reference runs as torch add + nn.LayerNorm).  Rows of c floats (c % 4 == 0, c <= 1024).
+ *   forward : z = x + residual (residual may be NULL: z = x and z_out is not written), y = LN(z) * gamma + beta,
+ *             mean / rstd [rows] saved for backward.
+ *   backward: dz (the gradient of x AND of residual), dgamma, dbeta [c]; deterministic two-stage reduction.
+ * ---------------------------------------------------------------------------------------- */
+int efg_add_layernorm_forward_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  float eps, int64_t rows, int c, float* z_out, float* y, float* mean, float* rstd,
+                                  void* stream);
+size_t efg_add_layernorm_backward_workspace_bytes(int64_t rows, int c);
+int efg_add_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd,
+                                   const float* gamma, int64_t rows, int c, float* dz, float* dgamma, float* dbeta,
+                                   void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
