@@ -63,6 +63,7 @@ def use_tuned_gemms(path=TUNED_GEMMS):
     shapes (PyTorch TunableOp, tuning itself OFF: unknown shapes keep the library default).  Pure algorithm
     selection -- same fp32 arithmetic; entries are validated against the ROCm / hipBLASLt build and ignored on
     mismatch.  EFG_TUNED_GEMMS=0 disables it."""
+    path = os.environ.get("EFG_TUNED_GEMMS_FILE", path)
     if os.environ.get("EFG_TUNED_GEMMS", "1") == "0" or not os.path.exists(path):
         return False
     import torch.cuda.tunable as tunable

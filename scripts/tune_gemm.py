@@ -1,6 +1,8 @@
 """Tune the dense fp32 GEMMs of the train step with PyTorch TunableOp (hipBLASLt / rocBLAS solution search).
 
-Run on the GPU box:  python scripts/tune_gemm.py [out.csv]
+Run on the GPU box:  EFG_TUNE_ROTATE_MB=1024 EFG_TUNED_GEMMS=0 python scripts/tune_gemm.py [out.csv]
+(the committed efg_amd/tuned/gemm_gfx950.csv was produced this way: operands rotate through 1 GB so every
+candidate is timed with cold caches, which is how the 72 MB activations reach these GEMMs inside the step)
 Runs a few train steps with tuning enabled (every new GEMM shape is benchmarked over the library's solutions
 once), writes the chosen solutions to a CSV, then reports the step time with tuning frozen.  The CSV is plumbing
 (library algorithm selection) -- it changes no arithmetic type; entries are validated against the ROCm /
@@ -35,12 +37,15 @@ def steps(n, tag):
     return ts
 
 
+tunable.enable(False)
 steps(4, "untuned:")
 tunable.enable(True)
 tunable.tuning_enable(True)
 tunable.set_filename(out)
 tunable.set_max_tuning_duration(30)
 tunable.set_max_tuning_iterations(20)
+if os.environ.get("EFG_TUNE_ROTATE_MB"):  # cold-cache timing: rotate operands through a buffer larger than L2 + MALL
+    tunable.set_rotating_buffer_size(int(os.environ["EFG_TUNE_ROTATE_MB"]))
 t0 = time.perf_counter()
 steps(3, "tuning:")
 print("tuning took %.1f s, %d entries" % (time.perf_counter() - t0, len(tunable.get_results())), flush=True)
