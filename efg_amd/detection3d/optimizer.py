@@ -15,4 +15,6 @@ def build_adamw_multi(cfg, model):
     groups = [{"params": backbone, "lr": lr_backbone}, {"params": rest},
               {"params": deform, "lr": lr * cfg.solver.deform_lr_multi}]
     oc["betas"] = tuple(oc["betas"])
+    if all(p.is_cuda for g in groups for p in g["params"]):
+        oc.setdefault("fused", True)  # one multi-tensor kernel per group instead of ~40 foreach launches; same update
     return torch.optim.AdamW(groups, **oc)

@@ -99,7 +99,8 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         with record_function("efg::forward"):
             loss_dict = self.wrapped(batch)
-            losses = sum(v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad)
+            # one stack + sum instead of 31 chained scalar adds (and as many backward nodes)
+            losses = torch.stack([v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad]).sum()
         with record_function("efg::backward"):
             losses.backward()
         with record_function("efg::optimizer"):
