@@ -64,6 +64,10 @@ _SIGS = {
     "efg_add_layernorm_forward_f32": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int] + [c_void_p] * 5),
     "efg_add_layernorm_backward_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "efg_add_layernorm_backward_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "efg_points_transform_filter_workspace_bytes": (c_size_t, [c_int64]),
+    "efg_points_transform_filter_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_size_t, c_void_p]),
+    "efg_points_gather_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "efg_lsap_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_nms_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

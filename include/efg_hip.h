@@ -251,6 +251,28 @@ int efg_add_layernorm_backward_f32(const float* dy, const float* z, const float*
                                    const float* gamma, int64_t rows, int c, float* dz, float* dgamma, float* dbeta,
                                    void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Point-cloud augmentation + range filter (the step before the path):
+ * the per-point work of RandomFlip3D / GlobalRotation / GlobalScaling / GlobalTranslation / FilterByRange /
+ * PointShuffle (efg/data/augmentations/extend_3d.py:108-236,286-315) on device clouds.  The random draws stay
+ * with the caller (the host mirror draws them with the reference's numpy calls).
+ * ---------------------------------------------------------------------------------------- */
+enum { EFG_PT_NEG_Y = 0, /* "flip along x axis": y = -y */
+       EFG_PT_NEG_X = 1, /* "flip along y axis": x = -x */
+       EFG_PT_ROT_Z = 2, /* a = cos, b = sin: (x, y) <- (x*a + y*(-b), x*b + y*a) */
+       EFG_PT_SCALE = 3, /* x, y, z *= a */
+       EFG_PT_TRANSLATE = 4 /* x += a, y += b, z += c */ };
+typedef struct { int kind; float a, b, c; } efg_point_op;
+size_t efg_points_transform_filter_workspace_bytes(int64_t n);
+/* points f32 [n,f] (x, y, z, features...) -> out [<= n, f]: ops applied in order (<= 8), then -- when range_host
+ * (6 floats: min xyz, max xyz, bounds inclusive) is not NULL -- rows outside the range are dropped, order
+ * preserved (== points[mask]).  *count (device int32) receives the number of rows written. */
+int efg_points_transform_filter_f32(const float* points, int64_t n, int f, const efg_point_op* ops_host, int n_ops,
+                                    const float* range_host, float* out, int32_t* count, void* ws, size_t ws_bytes,
+                                    void* stream);
+/* out[i] = points[index[i]] (row gather; index i64 [m] on the device) -- PointShuffle with a given permutation */
+int efg_points_gather_f32(const float* points, const int64_t* index, int64_t m, int f, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

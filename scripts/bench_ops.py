@@ -190,6 +190,33 @@ def bench_iou3d():
                   n, extent, t_iou, n * n / t_iou / 1e3, 100 * frac, 4 * n * n / t_iou / 1e3, t_nms, t_full, int(num)))
 
 
+def bench_augment():
+    """Device augmentation chain (flip + rotate + scale + range filter, then shuffle gather) per 180k-point scene."""
+    from efg_amd.data import gpu_pipeline as gp
+    from efg_amd.data.synthetic import PC_RANGE, make_scene
+
+    for n, sw in [(180000, 1), (720000, 4)]:
+        pts = torch.from_numpy(make_scene(7, n_points=n, n_sweeps=sw)[0]).to(dev)
+        f = pts.shape[1]
+
+        def fused():
+            dp = gp.DevicePoints(pts)
+            dp.queue(gp.NEG_Y)
+            dp.queue(gp.ROT_Z, 0.9, 0.43589)
+            dp.queue(gp.SCALE, 1.05)
+            return dp, dp.materialize(PC_RANGE)
+
+        t = timeit(lambda: fused())
+        dp, m = fused()
+        idx = torch.randperm(m, device=dev)
+        out = torch.empty_like(dp.tensor)
+        from efg_amd import _lib as L
+        tg = timeit(lambda: L.check(L.lib().efg_points_gather_f32(L.ptr(dp.tensor), L.ptr(idx), m, f, L.ptr(out),
+                                                                   L.stream())))
+        print("augment %d pts x %d feats: transform+filter %7.1f us (incl. count read-back; %5.1f GB/s alg)  "
+              "shuffle gather %7.1f us  kept %d" % (n, f, t, 2 * 4 * f * n / t / 1e3, tg, m))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
     for w in which:

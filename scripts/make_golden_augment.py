@@ -1,0 +1,82 @@
+"""Generate tests/golden/augment_*.npz from the REFERENCE augmentation classes (build container only).
+
+The reference module efg/data/augmentations/extend_3d.py is imported IN PLACE from /root/reference behind stub
+modules for packages this image lacks (cv2, numba, pycocotools, torchvision, ...: none of them is used by the five
+processors exercised here).  Only input / output VECTORS and the numpy seed are stored -- no reference source."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+from efg_amd.data.synthetic import PC_RANGE, make_scene  # noqa: E402
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Stub(self.__name__ + "." + n)
+
+    def __call__(self, *a, **k):
+        return None
+
+
+def load_reference_processors():
+    for name in ["cv2", "numba", "PIL", "PIL.Image", "portalocker", "tabulate", "termcolor", "omegaconf", "pycocotools",
+                 "pycocotools.mask", "shapely", "shapely.geometry", "torchvision", "torchvision.ops",
+                 "torchvision.ops.boxes", "torchvision.transforms", "fvcore", "fvcore.transforms",
+                 "fvcore.transforms.transform", "fvcore.common", "fvcore.common.file_io"]:
+        sys.modules.setdefault(name, _Stub(name))
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    sys.modules["numba"].jit = jit
+    sys.modules["numba"].njit = jit
+    efg = types.ModuleType("efg")
+    efg.__path__ = [REF + "/efg"]
+    efg._C = _Stub("efg._C")
+    sys.modules["efg"], sys.modules["efg._C"] = efg, efg._C
+    for pkg in ["efg.data", "efg.data.augmentations", "efg.data.samplers", "efg.data.utils", "efg.geometry", "efg.utils"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [REF + "/" + pkg.replace(".", "/")]
+        sys.modules[pkg] = m
+    return importlib.import_module("efg.data.augmentations.extend_3d")
+
+
+def main():
+    ref = load_reference_processors()
+    rng = np.random.default_rng(11)
+    for name, seed, n_points, with_vel in [("a", 5, 6000, False), ("b", 17, 20000, False), ("c", 23, 3000, True)]:
+        pts, boxes, labels = make_scene(4000 + seed, n_points=n_points)
+        pts = pts.astype(np.float32)
+        pts[:, :3] *= 1.15                      # push some points across the range boundary
+        boxes = boxes.astype(np.float32)
+        boxes[:, :2] *= 1.3                     # ... and some boxes
+        if with_vel:                            # 9-column boxes (x y z dx dy dz vx vy heading)
+            vel = rng.normal(size=(boxes.shape[0], 2)).astype(np.float32)
+            boxes = np.concatenate([boxes[:, :6], vel, boxes[:, 6:7]], axis=1)
+        info = {"annotations": {"gt_boxes": boxes.copy(), "labels": labels.copy()}}
+        chain = [ref.RandomFlip3D(p=0.5), ref.GlobalRotation(rotation=0.78539816),
+                 ref.GlobalScaling(min_scale=0.8, max_scale=1.2), ref.FilterByRange(pc_range=list(PC_RANGE)),
+                 ref.PointShuffle(p=1.0)]
+        np.random.seed(seed)
+        out_pts, out_info = pts.copy(), info
+        for proc in chain:
+            out_pts, out_info = proc(out_pts, out_info)
+        np.savez_compressed(os.path.join(OUT, "augment_%s.npz" % name), seed=seed, points=pts, boxes=boxes,
+                            labels=labels, pc_range=np.asarray(PC_RANGE, np.float32), out_points=out_pts,
+                            out_boxes=out_info["annotations"]["gt_boxes"], out_labels=out_info["annotations"]["labels"])
+        print(name, pts.shape, "->", out_pts.shape, boxes.shape, "->", out_info["annotations"]["gt_boxes"].shape)
+
+
+if __name__ == "__main__":
+    main()
