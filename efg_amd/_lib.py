@@ -68,6 +68,13 @@ _SIGS = {
     "efg_points_transform_filter_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_size_t, c_void_p]),
     "efg_points_gather_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "efg_match_cost_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float] * 6 + [c_void_p, c_void_p]),
+    "efg_focal_loss_forward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_void_p,
+                                           c_void_p]),
+    "efg_focal_loss_backward_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_float, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
+    "efg_box_loss_forward_f32": (c_int, [c_void_p] * 6 + [c_int64] + [c_int] * 4 + [c_void_p] * 3),
+    "efg_box_loss_backward_f32": (c_int, [c_void_p] * 6 + [c_int64] + [c_int] * 4 + [c_void_p] * 4),
     "efg_lsap_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_nms_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

@@ -11,6 +11,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from ..operators.det_loss import BoxLossLayers, FocalLossLayers, device_scalar
 from .utils import box_cxcyczlwh_to_xyxyxy, paired_box3d_giou, sigmoid_focal_loss
 
 
@@ -71,6 +72,17 @@ class Det3DLoss(nn.Module):
         n_layers = logits.shape[0]
         out = {}
         cls = tgt_labels[b_idx, g_idx]
+        if logits.is_cuda:
+            # one kernel per loss family and direction (csrc/det_loss.hip) instead of ~40 elementwise launches each
+            denom = device_scalar(num_boxes, logits.device)
+            if "focal_labels" in self.losses:
+                tcls = torch.full(logits.shape[:-1], -1, dtype=torch.int32, device=logits.device)
+                tcls.index_put_((l_idx, b_idx, q_idx), cls.to(torch.int32))
+                out["loss_ce"] = FocalLossLayers.apply(logits, tcls, denom, self.focal_alpha, 2.0)
+            if "boxes" in self.losses:
+                sums = BoxLossLayers.apply(boxes, tgt_boxes, l_idx, b_idx, q_idx, g_idx, denom)
+                out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
+            return out, cls
         if "focal_labels" in self.losses:
             onehot = torch.zeros_like(logits)
             # (a Python scalar on the right-hand side would be uploaded synchronously)

@@ -7,6 +7,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from ..operators.assignment import linear_sum_assignment_batched
+from ..operators.det_loss import match_cost
 from .utils import box_cxcyczlwh_to_xyxyxy, generalized_box3d_iou, pairwise_box3d_giou
 
 
@@ -53,6 +54,11 @@ class HungarianMatcher3d(nn.Module):
         host transfer); on CPU tensors it is scipy, as in the reference."""
         n_layers, bs, nq = logits.shape[:3]
         g = tgt_labels.shape[1]
+        if logits.is_cuda:  # cost in one kernel (csrc/det_loss.hip), assignment on the device (csrc/matcher.hip)
+            cost = match_cost(logits, boxes, tgt_labels, tgt_boxes, self.cost_class, self.cost_bbox, self.cost_giou,
+                              self.cost_rad)
+            ng = torch.tensor(list(counts) * n_layers, dtype=torch.int32).to(cost.device, non_blocking=True)
+            return linear_sum_assignment_batched(cost, ng).view(n_layers, bs, g)
         out_prob = logits.sigmoid().float()
         out_bbox, out_rad = boxes.float().split(6, dim=-1)
         alpha, gamma = 0.25, 2.0
@@ -66,12 +72,6 @@ class HungarianMatcher3d(nn.Module):
         cost_giou = -pairwise_box3d_giou(box_cxcyczlwh_to_xyxyxy(out_bbox), box_cxcyczlwh_to_xyxyxy(tb)[None])
         cost = (self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou +
                 self.cost_rad * cost_rad)
-        if cost.is_cuda:
-            # the assignment stays on the device (csrc/matcher.hip: scipy's algorithm, arithmetic and
-            # tie-breaking): the step never waits for a cost matrix to reach the host
-            ng = torch.tensor(list(counts) * n_layers, dtype=torch.int32).to(cost.device, non_blocking=True)
-            q_of_g = linear_sum_assignment_batched(cost.view(n_layers * bs, nq, g), ng)
-            return q_of_g.view(n_layers, bs, g)
         host = cost.numpy()
         q_of_g = torch.full((n_layers, bs, g), -1, dtype=torch.int64)
         for li in range(n_layers):

@@ -273,6 +273,33 @@ int efg_points_transform_filter_f32(const float* points, int64_t n, int f, const
 /* out[i] = points[index[i]] (row gather; index i64 [m] on the device) -- PointShuffle with a given permutation */
 int efg_points_gather_f32(const float* points, const int64_t* index, int64_t m, int f, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused detection losses ($CQ/modules/matcher.py:40-80, $CQ/losses.py:26-108), all layers and scenes per launch.
+ *   logits f32 [layers, b, q, c]; boxes f32 [layers, b, q, 7] (cx cy cz l w h rad, normalised);
+ *   tgt_labels i64 [b, g], tgt_boxes f32 [b, g, 7] (zero padded); denom: device float (num_boxes).
+ * ---------------------------------------------------------------------------------------- */
+/* cost f32 [p = layers*b, q, g] = w_bbox*L1(6) + w_class*(focal pos - neg cost at the GT label) + w_giou*(-GIoU3D)
+ * + w_rad*|d rad|  (no gradient; feeds efg_lsap_f32) */
+int efg_match_cost_f32(const float* logits, const float* boxes, const int64_t* tgt_labels, const float* tgt_boxes,
+                       int p, int b, int q, int c, int g, float w_class, float w_bbox, float w_giou, float w_rad,
+                       float alpha, float gamma, float* cost, void* stream);
+/* out[l] = sum over the n = b*q rows and c classes of sigmoid_focal_loss(logit, class == target_class[l, row]) / denom;
+ * target_class i32 [layers, n], -1 = background row */
+int efg_focal_loss_forward_f32(const float* logits, const int32_t* target_class, int layers, int64_t n, int c,
+                               float alpha, float gamma, const float* denom, float* out, void* stream);
+int efg_focal_loss_backward_f32(const float* logits, const int32_t* target_class, int layers, int64_t n, int c,
+                                float alpha, float gamma, const float* denom, const float* grad_out,
+                                float* grad_logits, void* stream);
+/* matched pair i: prediction boxes[l_idx[i], b_idx[i], q_idx[i]] vs tgt_boxes[b_idx[i], g_idx[i]];
+ * out f32 [layers, 3] = (sum L1 of x y z l w h, sum (1 - GIoU3D), sum |d rad|) / denom.
+ * backward: grad_boxes [layers, b, q, 7] must be zero-filled; a prediction is matched at most once. */
+int efg_box_loss_forward_f32(const float* boxes, const float* tgt_boxes, const int64_t* l_idx, const int64_t* b_idx,
+                             const int64_t* q_idx, const int64_t* g_idx, int64_t n, int layers, int b, int q, int g,
+                             const float* denom, float* out, void* stream);
+int efg_box_loss_backward_f32(const float* boxes, const float* tgt_boxes, const int64_t* l_idx, const int64_t* b_idx,
+                              const int64_t* q_idx, const int64_t* g_idx, int64_t n, int layers, int b, int q, int g,
+                              const float* denom, const float* grad_out, float* grad_boxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
