@@ -21,6 +21,8 @@
 // 64-pair tiles, G^T x gathered-X on the same MFMA, partials to a workspace, deterministic reduce.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace efg {
 namespace {
 
@@ -72,13 +74,19 @@ struct ConvArgs {
   int np;              // round16(cout)
 };
 
-template <int NT, int KV = 32>
+// KS: the kernel offsets of a 16-row tile are split over KS waves of the workgroup (split-K).  A wave walks its
+// offsets one after the other -- gather, stash, MFMA -- so its run time is a serial chain of gather latencies, and a
+// level only has a few waves per SIMD to overlap them (PMC: 34 % MFMA busy, 45 % of wave cycles waiting).  Splitting
+// the offsets multiplies the waves and divides the chain; the partial accumulators meet in LDS.
+template <int NT, int KV = 32, int KS = 1>
 __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   // wave-private staging: ONE A tile per wave (the wave itself orders compute -> refill; the prefetch
   // lives in registers) and the wave's rulebook block; 21 KB per workgroup for KV = 32
   __shared__ float a_tile[4][16 * kAStride];
   __shared__ int nbr_tile[4][KV * 16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int TILES = 4 / KS;          // row tiles per workgroup
+  const int tile = wv / KS, part = wv % KS;
   // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) by linear id;
   // rows are in canonical spatial order, so the 27 gathers of a row block hit rows that neighbouring row blocks
   // also read.  With the hardware order those neighbours sit on 8 different L2s (measured: 8x the algorithmic
@@ -92,8 +100,9 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
       by = nl / gridDim.x;
     }
   }
-  const long long r0 = ((long long)bx * 4 + wv) * 16;
-  if (r0 >= a.m_out) return;  // whole wave out of range (waves never sync with each other)
+  const long long r0 = ((long long)bx * TILES + tile) * 16;
+  const bool tile_ok = r0 < a.m_out;
+  if (KS == 1 && !tile_ok) return;  // whole wave out of range (with KS == 1 waves never sync with each other)
   float* at0 = a_tile[wv];
   int* nb = nbr_tile[wv];
   const int n_tile0 = by * NT;  // first n-tile of this block
@@ -106,9 +115,16 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   unsigned long long active = 0;
-  for (int k = 0; k < a.kvol; ++k) {
-    const int v = (lane < 16) ? nb[k * 16 + lane] : -1;
-    if (__ballot(v >= 0)) active |= 1ull << k;
+  {
+    int seen = 0;
+    for (int k = 0; k < a.kvol; ++k) {
+      const int v = (lane < 16) ? nb[k * 16 + lane] : -1;
+      if (__ballot(v >= 0)) {
+        if (seen % KS == part) active |= 1ull << k;  // this wave's share of the tile's active offsets
+        ++seen;
+      }
+    }
+    if (!tile_ok) active = 0;
   }
 
   f32x4 acc[NT];
@@ -116,7 +132,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   for (int t = 0; t < NT; ++t) {
     float b = 0.0f;
     const int co = (n_tile0 + t) * 16 + (lane & 15);
-    if (a.bias && co < a.cout) b = a.bias[co];
+    if (a.bias && co < a.cout && part == 0) b = a.bias[co];
     acc[t] = f32x4{b, b, b, b};
   }
 
@@ -193,6 +209,31 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
     }
   }
 
+  if (KS > 1) {
+    // partial accumulators of the tile's other waves: through the (now idle) A tiles, 16 x 16 floats per n-tile
+    __syncthreads();  // every wave is done with its A tile
+    float* red = a_tile[wv];
+    for (int t0 = 0; t0 < NT; t0 += 4) {  // 4 n-tiles (1024 floats) fit one A tile (16 x 66 floats)
+      if (part != 0) {
+#pragma unroll
+        for (int t = t0; t < NT && t < t0 + 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((t - t0) * 4 + r) * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (part == 0) {
+        for (int p = 1; p < KS; ++p) {
+          const float* o = a_tile[wv + p];
+#pragma unroll
+          for (int t = t0; t < NT && t < t0 + 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += o[((t - t0) * 4 + r) * 64 + lane];
+        }
+      }
+      __syncthreads();
+    }
+    if (part != 0 || !tile_ok) return;
+  }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -366,7 +407,15 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
 }
 
 template <int NT>
-void launch_fwd(const ConvArgs& a, int nblk_y, hipStream_t stream) {
+void launch_fwd(const ConvArgs& a, int nblk_y, int ks, hipStream_t stream) {
+  if (a.kvol <= 32 && ks == 2) {
+    hipLaunchKernelGGL((conv_fwd_kernel<NT, 32, 2>), dim3((unsigned)ceil_div(a.m_out, 32), nblk_y), dim3(256), 0, stream, a);
+    return;
+  }
+  if (a.kvol <= 32 && ks == 4) {
+    hipLaunchKernelGGL((conv_fwd_kernel<NT, 32, 4>), dim3((unsigned)ceil_div(a.m_out, 16), nblk_y), dim3(256), 0, stream, a);
+    return;
+  }
   const unsigned gx = (unsigned)ceil_div(a.m_out, 64);
   if (a.kvol <= 32) hipLaunchKernelGGL((conv_fwd_kernel<NT, 32>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_fwd_kernel<NT, kMaxKvol>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
@@ -399,12 +448,16 @@ int run_conv(const float* in, int cin, const float* wp, const float* bias, int c
   if (nt > ntiles) nt = ntiles >= 16 ? 16 : ntiles >= 8 ? 8 : ntiles >= 4 ? 4 : ntiles >= 2 ? 2 : 1;
   while (nt < ntiles && nt < 16 && (ntiles % nt) != 0) nt <<= 1;  // keep grid.y exact where possible
   const int ny = (ntiles + nt - 1) / nt;
+  // split-K over the 4 waves of a workgroup for the 3x3x3 kernels with 2-4 n-tiles per wave (measured -10 %);
+  // 16-channel outputs (NT = 1) and the 3-offset z-collapsing heads gain nothing.  EFG_CONV_KS overrides (1 | 2 | 4).
+  static const int ks_env = getenv("EFG_CONV_KS") ? atoi(getenv("EFG_CONV_KS")) : 4;
+  const int ks = (kvol >= 8) ? ks_env : 1;
   switch (nt) {
-    case 16: launch_fwd<16>(a, ny, stream); break;
-    case 8: launch_fwd<8>(a, ny, stream); break;
-    case 4: launch_fwd<4>(a, ny, stream); break;
-    case 2: launch_fwd<2>(a, ny, stream); break;
-    default: launch_fwd<1>(a, ny, stream); break;
+    case 16: launch_fwd<16>(a, ny, 1, stream); break;
+    case 8: launch_fwd<8>(a, ny, 1, stream); break;
+    case 4: launch_fwd<4>(a, ny, ks, stream); break;
+    case 2: launch_fwd<2>(a, ny, ks, stream); break;
+    default: launch_fwd<1>(a, ny, 1, stream); break;
   }
   EFG_LAUNCH_CHECK();
   return EFG_OK;
