@@ -217,6 +217,15 @@ def bench_augment():
               "shuffle gather %7.1f us  kept %d" % (n, f, t, 2 * 4 * f * n / t / 1e3, tg, m))
 
 
+def bench_copy():
+    """Practical HBM ceiling: a device-to-device copy."""
+    for mb in (72, 290, 1024, 4096):
+        a = torch.empty(mb * 1024 * 1024 // 4, device=dev)
+        b = torch.empty_like(a)
+        t = timeit(lambda: b.copy_(a))
+        print("copy %5d MB: %8.1f us  %6.2f TB/s (read + write)" % (mb, t, 2 * a.numel() * 4 / t / 1e6))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
     for w in which:
