@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   // wave-private staging: ONE A tile per wave (the wave itself orders compute -> refill; the prefetch
   // lives in registers) and the wave's rulebook block; 21 KB per workgroup for KV = 32
   __shared__ float a_tile[4][16 * kAStride];
-  __shared__ int nbr_tile[4][KV * 16];
+  __shared__ int nbr_tile[4 / KS][KV * 16];  // one rulebook block per row tile (shared by its KS waves)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   constexpr int TILES = 4 / KS;          // row tiles per workgroup
   const int tile = wv / KS, part = wv % KS;
@@ -104,16 +104,17 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   const bool tile_ok = r0 < a.m_out;
   if (KS == 1 && !tile_ok) return;  // whole wave out of range (with KS == 1 waves never sync with each other)
   float* at0 = a_tile[wv];
-  int* nb = nbr_tile[wv];
+  int* nb = nbr_tile[wv / KS];
   const int n_tile0 = by * NT;  // first n-tile of this block
 
   // stage the wave's rulebook block and find the active offsets
-  for (int e = lane; e < a.kvol * 16; e += 64) {
+  for (int e = lane + 64 * part; e < a.kvol * 16; e += 64 * KS) {
     const int k = e >> 4, j = e & 15;
     nb[e] = (r0 + j < a.m_out) ? a.nbr[(long long)k * a.m_out + r0 + j] : -1;
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (KS > 1) __syncthreads();  // the tile's waves each staged a share of the block
   unsigned long long active = 0;
   {
     int seen = 0;
@@ -149,7 +150,12 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) rows[j] = nb[k * 16 + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) pre[j] = a.in[(long long)max(rows[j], 0) * a.cin + cc];
+    for (int j = 0; j < 16; ++j) {
+      // 32-bit byte offset from the (scalar) base: one v_mad + the saddr load form instead of 64-bit VALU address
+      // arithmetic per load (run_conv checks that the input is smaller than 4 GB)
+      const unsigned off = ((unsigned)max(rows[j], 0) * (unsigned)a.cin + (unsigned)cc) * 4u;
+      pre[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + off);
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) pre[j] = (rows[j] >= 0 && c < a.cin) ? pre[j] : 0.0f;
   };
@@ -164,10 +170,13 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
     for (int c16 = c16_lo; c16 < c16_hi; ++c16) {
       const float* ap = at + m * kAStride + (c16 - c16_lo) * 16 + kk;
       const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-      const float* bp = a.wp + (((long long)k * a.c16n + c16) * a.np + n_tile0 * 16 + m) * 16 + kk * 4;
+      // 32-bit byte offset into the packed weights (a few MB): saddr + voffset loads
+      const unsigned boff = ((((unsigned)k * (unsigned)a.c16n + (unsigned)c16) * (unsigned)a.np + (unsigned)(n_tile0 * 16 + m)) * 16u +
+                             (unsigned)(kk * 4)) * 4u;
       float4 b[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(bp + t * 256);
+      for (int t = 0; t < NT; ++t)
+        b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff + (unsigned)t * 1024u);
       // k-step outer, n-tile inner: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA
       // issues every 32 cycles but its result is ready after 40)
 #pragma unroll
@@ -421,11 +430,13 @@ void launch_fwd(const ConvArgs& a, int nblk_y, int ks, hipStream_t stream) {
   else hipLaunchKernelGGL((conv_fwd_kernel<NT, kMaxKvol>), dim3(gx, nblk_y), dim3(256), 0, stream, a);
 }
 
-int run_conv(const float* in, int cin, const float* wp, const float* bias, int cout, int kvol, const int* nbr,
-             int64_t m_out, float* out, hipStream_t stream) {
+int run_conv(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
+             const int* nbr, int64_t m_out, float* out, hipStream_t stream) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv: bad channel counts");
   EFG_CHECK_ARG(kvol >= 1 && kvol <= kMaxKvol, "spconv: kernel volume must be in [1,%d], got %d", kMaxKvol, kvol);
   if (m_out == 0) return EFG_OK;
+  EFG_CHECK_ARG(m_in >= 0 && (unsigned long long)m_in * (unsigned long long)cin * 4ull < (1ull << 32),
+                "spconv: input features of %lld x %d floats exceed the 4 GB the gather addresses", (long long)m_in, cin);
   ConvArgs a;
   a.in = in;
   a.wp = wp;
@@ -491,15 +502,13 @@ extern "C" int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvo
 extern "C" int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                       const float* bias, int cout, int kvol, const int32_t* nbr, int64_t m_out,
                                       float* out_feat, void* stream) {
-  (void)m_in;
-  return run_conv(in_feat, cin, packed_weight, bias, cout, kvol, nbr, m_out, out_feat, (hipStream_t)stream);
+  return run_conv(in_feat, m_in, cin, packed_weight, bias, cout, kvol, nbr, m_out, out_feat, (hipStream_t)stream);
 }
 
 extern "C" int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight,
                                     int cin, int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in,
                                     void* stream) {
-  (void)m_out;
-  return run_conv(grad_out, cout, packed_weight, nullptr, cin, kvol, rnbr, m_in, grad_in, (hipStream_t)stream);
+  return run_conv(grad_out, m_out, cout, packed_weight, nullptr, cin, kvol, rnbr, m_in, grad_in, (hipStream_t)stream);
 }
 
 extern "C" size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol) {
