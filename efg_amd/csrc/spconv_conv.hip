@@ -299,8 +299,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     for (int j = wv; j < 64; j += 4) {
       // branch-free loads (clamped address, select afterwards): see conv_fwd_kernel::gather
       const int o = q_out[head + j], i = q_in[head + j];
-      const float g = a.go[(long long)max(o, 0) * a.cout + gco];
-      const float x = a.in[(long long)max(i, 0) * a.cin + gci];
+      // 32-bit byte offsets (saddr + voffset loads; wgrad checks both tensors are below 4 GB)
+      const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.go) +
+                                                      ((unsigned)max(o, 0) * (unsigned)a.cout + (unsigned)gco) * 4u);
+      const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) +
+                                                      ((unsigned)max(i, 0) * (unsigned)a.cin + (unsigned)gci) * 4u);
       g_tile[j * kWStride + lane] = (o >= 0 && co0 + lane < a.cout) ? g : 0.f;
       x_tile[j * kWStride + lane] = (o >= 0 && ci0 + lane < a.cin) ? x : 0.f;
     }
@@ -519,9 +522,11 @@ extern "C" size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int c
 extern "C" int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out,
                                     int64_t m_out, int cout, int kvol, const int32_t* nbr, float* grad_w, void* ws,
                                     size_t ws_bytes, void* stream_) {
-  (void)m_in;
   hipStream_t stream = (hipStream_t)stream_;
   EFG_CHECK_ARG(cin >= 1 && cout >= 1 && kvol >= 1 && kvol <= kMaxKvol, "spconv wgrad: bad sizes");
+  EFG_CHECK_ARG(m_in >= 0 && (unsigned long long)m_in * cin * 4ull < (1ull << 32) &&
+                    (unsigned long long)(m_out > 0 ? m_out : 0) * cout * 4ull < (1ull << 32),
+                "spconv wgrad: feature tensors must be smaller than 4 GB");
   if (m_out == 0) {
     EFG_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)cout * kvol * cin * 4, stream));
     return EFG_OK;
