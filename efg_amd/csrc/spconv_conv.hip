@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   // lives in registers) and the wave's rulebook block; 21 KB per workgroup for KV = 32
   __shared__ float a_tile[4][16 * kAStride];
   __shared__ int nbr_tile[4 / KS][KV * 16];  // one rulebook block per row tile (shared by its KS waves)
+  __shared__ unsigned vmask_tile[4 / KS][KV];  // per offset: which of the 16 tile rows have a neighbour
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   constexpr int TILES = 4 / KS;          // row tiles per workgroup
   const int tile = wv / KS, part = wv % KS;
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   if (KS == 1 && !tile_ok) return;  // whole wave out of range (with KS == 1 waves never sync with each other)
   float* at0 = a_tile[wv];
   int* nb = nbr_tile[wv / KS];
+  unsigned* vm = vmask_tile[wv / KS];
   const int n_tile0 = by * NT;  // first n-tile of this block
 
   // stage the wave's rulebook block and find the active offsets
@@ -120,13 +122,22 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
     int seen = 0;
     for (int k = 0; k < a.kvol; ++k) {
       const int v = (lane < 16) ? nb[k * 16 + lane] : -1;
-      if (__ballot(v >= 0)) {
+      const unsigned long long bal = __ballot(v >= 0);
+      if (lane == 0) vm[k] = (unsigned)bal;  // the tile's waves all write the same word
+      if (bal) {
         if (seen % KS == part) active |= 1ull << k;  // this wave's share of the tile's active offsets
         ++seen;
       }
     }
     if (!tile_ok) active = 0;
   }
+  // The gathers only need byte offsets: turn the row numbers into offsets once (invalid -> row 0, a legal address;
+  // its value is dropped through the scalar mask), so a gather costs one add + one select per row on the VALU.
+  if (KS > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+  for (int e = lane + 64 * part; e < a.kvol * 16; e += 64 * KS) nb[e] = (int)((unsigned)max(nb[e], 0) * (unsigned)a.cin * 4u);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (KS > 1) __syncthreads();
 
   f32x4 acc[NT];
 #pragma unroll
@@ -144,20 +155,17 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   auto gather = [&](int k, int ch) {
     // Branch-free: a predicated load compiles to a branch + its own basic block, and the waitcnt pass then
     // serialises the 16 loads (one s_waitcnt vmcnt(0) per load).  Clamp the address, load always, select.
-    const int c = ch * kCK + lane;
-    const int cc = min(c, a.cin - 1);
-    int rows[16];
+    // lanes past cin read a clamped (finite) channel: the packed weights are zero there, so nothing is selected
+    // per lane; rows without a neighbour are dropped with the scalar mask of the offset
+    const unsigned cc4 = (unsigned)min(ch * kCK + lane, a.cin - 1) * 4u;
+    const unsigned vmk = (unsigned)__builtin_amdgcn_readfirstlane((int)vm[k]);
+    unsigned offs[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) rows[j] = nb[k * 16 + j];
+    for (int j = 0; j < 16; ++j) offs[j] = (unsigned)nb[k * 16 + j] + cc4;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      // 32-bit byte offset from the (scalar) base: one v_mad + the saddr load form instead of 64-bit VALU address
-      // arithmetic per load (run_conv checks that the input is smaller than 4 GB)
-      const unsigned off = ((unsigned)max(rows[j], 0) * (unsigned)a.cin + (unsigned)cc) * 4u;
-      pre[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + off);
-    }
+    for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) pre[j] = (rows[j] >= 0 && c < a.cin) ? pre[j] : 0.0f;
+    for (int j = 0; j < 16; ++j) pre[j] = ((vmk >> j) & 1u) ? pre[j] : 0.0f;
   };
   auto stash = [&](float* at) {
 #pragma unroll
