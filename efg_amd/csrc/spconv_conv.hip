@@ -283,11 +283,12 @@ struct WgradArgs {
 };
 
 constexpr int kWStride = 64 + 16;  // row stride of the LDS tiles (== 16 mod 32: conflict-free fragment reads)
-constexpr int kQueue = 64 + 256;
+constexpr int kTP = 32;            // pairs per MFMA tile: 23 KB of LDS per workgroup -> 6 workgroups per CU
+constexpr int kQueue = kTP + 256;
 
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
-  __shared__ float g_tile[64 * kWStride];   // 64 pairs x 64 co of grad_out
-  __shared__ float x_tile[64 * kWStride];   // 64 pairs x 64 ci of the gathered input
+  __shared__ float g_tile[kTP * kWStride];   // kTP pairs x 64 co of grad_out
+  __shared__ float x_tile[kTP * kWStride];   // kTP pairs x 64 ci of the gathered input
   __shared__ int q_out[kQueue], q_in[kQueue];
   __shared__ int wave_cnt[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -303,8 +304,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   auto process = [&](int head) {
     __syncthreads();  // queue entries visible; previous tile fully consumed
     const int gco = min(co0 + lane, a.cout - 1), gci = min(ci0 + lane, a.cin - 1);
-#pragma unroll 4
-    for (int j = wv; j < 64; j += 4) {
+#pragma unroll
+    for (int j = wv; j < kTP; j += 4) {
       // branch-free loads (clamped address, select afterwards): see conv_fwd_kernel::gather
       const int o = q_out[head + j], i = q_in[head + j];
       // 32-bit byte offsets (saddr + voffset loads; wgrad checks both tensors are below 4 GB)
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     __syncthreads();
     // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles; reduction dim = pairs, 4 per MFMA
 #pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < kTP / 4; ++s) {
       const int row = s * 4 + kk;
       const float av = g_tile[row * kWStride + wv * 16 + m];
 #pragma unroll
@@ -345,12 +346,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     }
     qn += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     int head = 0;
-    while (qn - head >= 64) {
+    while (qn - head >= kTP) {
       process(head);
-      head += 64;
+      head += kTP;
     }
     __syncthreads();  // all reads of the queue / wave_cnt done
-    if (head > 0) {   // move the remainder (< 64 pairs) to the front
+    if (head > 0) {   // move the remainder (< kTP pairs) to the front
       const int rem = qn - head;
       int to = -1, ti = -1;
       if ((int)threadIdx.x < rem) {
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   }
   if (qn > 0) {
     __syncthreads();
-    if ((int)threadIdx.x >= qn && threadIdx.x < 64) {
+    if ((int)threadIdx.x >= qn && threadIdx.x < kTP) {
       q_out[threadIdx.x] = -1;
       q_in[threadIdx.x] = -1;
     }
