@@ -301,22 +301,39 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto process = [&](int head) {
-    __syncthreads();  // queue entries visible; previous tile fully consumed
-    const int gco = min(co0 + lane, a.cout - 1), gci = min(ci0 + lane, a.cin - 1);
+  // One MFMA tile = kTP pairs.  load(): this wave's share of the tile's rows into registers (branch-free, clamped
+  // address + select); stash(): registers -> LDS; compute(): the MFMAs.  Tiles that are already in the queue are
+  // loaded while the previous tile computes.
+  constexpr int JW = kTP / 4;  // tile rows per wave
+  float gr[JW], xr[JW];
+  unsigned okbits = 0;  // validity of the loaded rows (the selects wait for the data: they run at stash time)
+  const int gco = min(co0 + lane, a.cout - 1), gci = min(ci0 + lane, a.cin - 1);
+  const bool co_ok = co0 + lane < a.cout, ci_ok = ci0 + lane < a.cin;
+  auto load = [&](int head) {
+    okbits = 0;
 #pragma unroll
-    for (int j = wv; j < kTP; j += 4) {
-      // branch-free loads (clamped address, select afterwards): see conv_fwd_kernel::gather
+    for (int jj = 0; jj < JW; ++jj) {
+      const int j = wv + 4 * jj;
       const int o = q_out[head + j], i = q_in[head + j];
       // 32-bit byte offsets (saddr + voffset loads; wgrad checks both tensors are below 4 GB)
       const float g = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.go) +
                                                       ((unsigned)max(o, 0) * (unsigned)a.cout + (unsigned)gco) * 4u);
       const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) +
                                                       ((unsigned)max(i, 0) * (unsigned)a.cin + (unsigned)gci) * 4u);
-      g_tile[j * kWStride + lane] = (o >= 0 && co0 + lane < a.cout) ? g : 0.f;
-      x_tile[j * kWStride + lane] = (o >= 0 && ci0 + lane < a.cin) ? x : 0.f;
+      gr[jj] = g;
+      xr[jj] = x;
+      okbits |= (o >= 0 ? 1u : 0u) << jj;
     }
-    __syncthreads();
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+      const bool ok = (okbits >> jj) & 1u;
+      g_tile[(wv + 4 * jj) * kWStride + lane] = (ok && co_ok) ? gr[jj] : 0.f;
+      x_tile[(wv + 4 * jj) * kWStride + lane] = (ok && ci_ok) ? xr[jj] : 0.f;
+    }
+  };
+  auto compute = [&]() {
     // wave wv owns the co tile co0 + wv*16 and the 4 ci tiles; reduction dim = pairs, 4 per MFMA
 #pragma unroll 4
     for (int s = 0; s < kTP / 4; ++s) {
@@ -328,6 +345,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
       }
     }
+  };
+  // consume every full tile of the queue from `head` on; returns the new head
+  auto drain = [&](int head, int qn) {
+    if (qn - head < kTP) return head;
+    __syncthreads();  // queue entries visible
+    load(head);
+    while (true) {
+      __syncthreads();  // previous tile fully consumed
+      stash();
+      __syncthreads();
+      head += kTP;
+      const bool more = qn - head >= kTP;
+      if (more) load(head);  // in flight during the MFMAs below
+      compute();
+      if (!more) break;
+    }
+    return head;
   };
 
   int qn = 0;  // block-uniform queue length
@@ -346,10 +380,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     }
     qn += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     int head = 0;
-    while (qn - head >= kTP) {
-      process(head);
-      head += kTP;
-    }
+    head = drain(head, qn);
     __syncthreads();  // all reads of the queue / wave_cnt done
     if (head > 0) {   // move the remainder (< kTP pairs) to the front
       const int rem = qn - head;
@@ -372,7 +403,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
       q_out[threadIdx.x] = -1;
       q_in[threadIdx.x] = -1;
     }
-    process(0);
+    drain(0, kTP);
   }
   // partial block: row (co) = (lane>>4)*4 + reg, col (ci) = lane & 15
   float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
