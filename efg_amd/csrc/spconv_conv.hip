@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
 
   const int nchunk = (a.c16n * 16 + kCK - 1) / kCK;  // channel chunks of 64 per offset
   float pre[16];
+  unsigned pre_mask = 0;
 
   // gather of (k, chunk) into registers: row j of the wave -> pre[j] (lane = channel)
   auto gather = [&](int k, int ch) {
@@ -164,12 +165,11 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
     for (int j = 0; j < 16; ++j) offs[j] = (unsigned)nb[k * 16 + j] + cc4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) pre[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) pre[j] = ((vmk >> j) & 1u) ? pre[j] : 0.0f;
+    pre_mask = vmk;  // rows without a neighbour are zeroed at stash time (a select here would wait for the loads)
   };
   auto stash = [&](float* at) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) at[j * kAStride + lane] = pre[j];
+    for (int j = 0; j < 16; ++j) at[j * kAStride + lane] = ((pre_mask >> j) & 1u) ? pre[j] : 0.0f;
   };
   auto compute = [&](const float* at, int k, int ch) {
     const int c16_lo = ch * (kCK / 16);
