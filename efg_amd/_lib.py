@@ -35,6 +35,7 @@ _SIGS = {
                                               c_size_t, c_void_p]),
     "efg_spconv_index_downsample": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_index_rank": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_index_emit": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_spconv_build_nbr": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),

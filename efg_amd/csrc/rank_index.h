@@ -25,6 +25,12 @@ __device__ __forceinline__ void rank_set(uint2* idx, unsigned long long cell) {
   atomicOr(&idx[cell >> 5].x, 1u << (cell & 31));
 }
 
+// as rank_set; true when this call turned the bit on (exactly one caller per cell sees true)
+__device__ __forceinline__ bool rank_set_new(uint2* idx, unsigned long long cell) {
+  const unsigned bit = 1u << (cell & 31);
+  return !(atomicOr(&idx[cell >> 5].x, bit) & bit);
+}
+
 // phase a: popcount sum per tile of kRankTileWords words
 static __global__ void __launch_bounds__(256) rank_tile_sums_kernel(const uint2* __restrict__ idx, long long words,
                                                               int* __restrict__ tile_sums) {

@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(256) idx_perm_kernel(const int* __restrict__ i
 // every input site marks the output sites it feeds: o = (i + p - k) / s when divisible, in range
 __global__ void __launch_bounds__(256)
 idx_downsample_mark_kernel(const int* __restrict__ ind, long long m, Grid3 gin, Grid3 gout, ConvGeom cg,
-                           uint2* __restrict__ oidx) {
+                           uint2* __restrict__ oidx, int* __restrict__ count) {
+  // `fresh` counts the output sites this thread switched on: their sum is the number of output sites, available
+  // as soon as this kernel is done (the host sizes the next level with it while the ranking kernels still run)
+  int fresh = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4*>(ind)[i];
     if (!((unsigned)c.x < (unsigned)gin.b && (unsigned)c.y < (unsigned)gin.d && (unsigned)c.z < (unsigned)gin.h &&
@@ -72,11 +75,13 @@ idx_downsample_mark_kernel(const int* __restrict__ ind, long long m, Grid3 gin, 
           if (tx < 0 || tx % cg.s[2]) continue;
           const int ox = tx / cg.s[2];
           if (ox >= gout.w) continue;
-          rank_set(oidx, cell_of(gout, c.x, oz, oy, ox));
+          fresh += rank_set_new(oidx, cell_of(gout, c.x, oz, oy, ox)) ? 1 : 0;
         }
       }
     }
   }
+  fresh = wave_reduce_sum(fresh);
+  if (lane_id() == 0 && fresh) atomicAdd(count, fresh);
 }
 
 // one thread per index word: write the (b,z,y,x) rows of its set bits at their ranks
@@ -351,14 +356,32 @@ extern "C" int efg_spconv_index_downsample(const int32_t* in_indices, int64_t m_
     set_error("spconv index workspace too small");
     return EFG_E_WORKSPACE;
   }
+  (void)tile_sums;
   uint2* oidx = static_cast<uint2*>(out_index);
   EFG_HIP_TRY(hipMemsetAsync(oidx, 0, (size_t)words * 8, stream));
+  EFG_HIP_TRY(hipMemsetAsync(m_out_dev, 0, sizeof(int32_t), stream));
   if (m_in > 0) {
     hipLaunchKernelGGL(idx_downsample_mark_kernel, dim3(grid_for(m_in)), dim3(256), 0, stream, in_indices,
-                       (long long)m_in, gin, gout, cg, oidx);
+                       (long long)m_in, gin, gout, cg, oidx, m_out_dev);
     EFG_LAUNCH_CHECK();
   }
-  return rank_build_prefix(oidx, words, tile_sums, m_out_dev, stream);
+  return EFG_OK;
+}
+
+extern "C" int efg_spconv_index_rank(void* index, int batch, const int* shape, int32_t* m_dev, void* ws, size_t ws_bytes,
+                                     void* stream_) {
+  Grid3 g;
+  unsigned long long cells;
+  if (int rc = make_grid(batch, shape, &g, &cells)) return rc;
+  const long long words = rank_words(cells);
+  Workspace w(ws, ws_bytes);
+  int* tile_sums = w.take<int>(rank_tiles(words));
+  int* total = w.take<int>(1);
+  if (!w.ok) {
+    set_error("spconv index workspace too small");
+    return EFG_E_WORKSPACE;
+  }
+  return rank_build_prefix(static_cast<uint2*>(index), words, tile_sums, m_dev ? m_dev : total, (hipStream_t)stream_);
 }
 
 extern "C" int efg_spconv_index_emit(const void* index, int batch, const int* shape, int32_t* out_indices,

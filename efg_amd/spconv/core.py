@@ -381,7 +381,8 @@ def _downsample_geometry(x, ks, st, pad):
                                             L.host_i32(ks, 3), L.host_i32(st, 3), L.host_i32(pad, 3),
                                             L.ptr(oindex), out_shape, L.ptr(m_out_dev), L.ptr(ws), ws_bytes,
                                             L.stream()))
-    m_out = int(m_out_dev.item())  # sizes every downstream tensor of this level (one sync per level)
+    m_out = int(m_out_dev.item())  # sizes every downstream tensor of this level: waits for ONE marking kernel
+    L.check(lib.efg_spconv_index_rank(L.ptr(oindex), x.batch_size, oshp, None, L.ptr(ws), ws_bytes, L.stream()))
     out_indices = torch.empty((max(m_out, 1), 4), dtype=torch.int32, device=dev)
     L.check(lib.efg_spconv_index_emit(L.ptr(oindex), x.batch_size, oshp, L.ptr(out_indices), L.stream()))
     return out_indices[:m_out], SiteIndex(oindex, None, x.batch_size, oshape_py), oshape_py

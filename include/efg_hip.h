@@ -106,13 +106,18 @@ size_t efg_spconv_index_workspace_bytes(int batch, const int* shape_host);
 int efg_spconv_index_from_indices(const int32_t* indices, int64_t m, int batch, const int* shape_host,
                                   void* index, int32_t* perm, void* ws, size_t ws_bytes, void* stream);
 
-/* Regular SparseConv3d geometry: mark every output site touched by an input site, rank them.
- * out_shape_host receives (in + 2p - k)/s + 1 per axis.  *m_out_dev receives the site count;
- * the caller reads it back, allocates out_indices[m_out,4] and calls efg_spconv_index_emit. */
+/* Regular SparseConv3d geometry, step 1: mark every output site touched by an input site and COUNT them.
+ * out_shape_host receives (in + 2p - k)/s + 1 per axis.  *m_out_dev receives the site count as soon as the one
+ * marking kernel is done; the caller reads it back and allocates out_indices[m_out,4].  The index only becomes
+ * rankable (usable by _emit / _build_nbr) after efg_spconv_index_rank -- split off so that the count read-back
+ * does not wait for the three ranking kernels. */
 int efg_spconv_index_downsample(const int32_t* in_indices, int64_t m_in, int batch, const int* in_shape_host,
                                 const int* ksize_host, const int* stride_host, const int* pad_host,
                                 void* out_index, int* out_shape_host, int32_t* m_out_dev, void* ws,
                                 size_t ws_bytes, void* stream);
+/* step 2: popcount prefix over the bitmap (m_dev may be NULL; otherwise it receives the site count again). */
+int efg_spconv_index_rank(void* index, int batch, const int* shape_host, int32_t* m_dev, void* ws, size_t ws_bytes,
+                          void* stream);
 int efg_spconv_index_emit(const void* index, int batch, const int* shape_host, int32_t* out_indices,
                           void* stream);
 
