@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (configs[1]: batch 2; configs[2]: 16 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=180000)
     ap.add_argument("--queries", type=int, default=1000, help="reference YAML default (configs[2] names 900)")

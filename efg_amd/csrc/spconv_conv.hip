@@ -292,8 +292,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   __shared__ int q_out[kQueue], q_in[kQueue];
   __shared__ int wave_cnt[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int split = blockIdx.x, k = blockIdx.z;
-  const int co0 = (blockIdx.y / a.nci_blk) * 64, ci0 = (blockIdx.y % a.nci_blk) * 64;
+  // XCD-aware order: the kvol x (co, ci) workgroups of one row chunk re-read the same grad_out / input rows; deal
+  // them to ONE XCD, consecutively, so those rows come from its L2 (hardware order: linear id round-robin over the
+  // 8 XCDs, which spread a chunk's workgroups over all 8 L2s -- PMC: 10x the algorithmic bytes fetched past L2)
+  int split = blockIdx.x, k = blockIdx.z, yb = blockIdx.y;
+  if ((gridDim.x & 7) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned per = gridDim.y * gridDim.z, idx = lin >> 3, rest = idx % per;
+    split = (int)((lin & 7) + 8 * (idx / per));
+    yb = (int)(rest % gridDim.y);
+    k = (int)(rest / gridDim.y);
+  }
+  const int co0 = (yb / a.nci_blk) * 64, ci0 = (yb % a.nci_blk) * 64;
   const long long row_lo = (long long)split * a.rows_per_split;
   const long long row_hi = min(row_lo + a.rows_per_split, a.m_out);
   const int m = lane & 15, kk = lane >> 4;
@@ -452,6 +462,7 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
   int64_t rows = ceil_div(std::max<int64_t>(m_out, 1), s);
   rows = ceil_div(rows, 256) * 256;
   s = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), rows));
+  if (s >= 8) s = ceil_div(s, 8) * 8;  // multiple of 8: lets the kernel give every XCD whole row chunks (empty ones cost nothing)
   p.splits = (int)s;
   p.rows_per_split = (int)rows;
   p.bytes = (size_t)p.splits * per;
