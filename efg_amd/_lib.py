@@ -97,8 +97,6 @@ def lib():
                 "There is no CPU fallback on the product path." % _LIB_PATH)
         _lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            if os.environ.get("EFG_DEV_PARTIAL_LIB") and not hasattr(_lib, name):
-                continue  # bring-up only: a half-built library during kernel development
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
