@@ -76,6 +76,10 @@ _SIGS = {
                                             c_void_p, c_void_p, c_void_p]),
     "efg_box_loss_forward_f32": (c_int, [c_void_p] * 6 + [c_int64] + [c_int] * 4 + [c_void_p] * 3),
     "efg_box_loss_backward_f32": (c_int, [c_void_p] * 6 + [c_int64] + [c_int] * 4 + [c_void_p] * 4),
+    "efg_bn_workspace_bytes": (c_size_t, [c_int]),
+    "efg_bn_forward_f32": (c_int, [c_void_p] * 7 + [c_float, c_float, c_int64, c_int, c_int] + [c_void_p] * 4 +
+                           [c_size_t, c_void_p]),
+    "efg_bn_backward_f32": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "efg_lsap_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_nms_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

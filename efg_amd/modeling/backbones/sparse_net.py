@@ -12,6 +12,7 @@ from torch import nn
 
 from .. import common
 from ... import spconv
+from ...operators.batchnorm import bn_act
 from ...spconv import SparseConv3d, SubMConv3d
 
 ShapeSpec = collections.namedtuple("ShapeSpec", ["channels", "height", "width", "stride"],
@@ -72,6 +73,13 @@ class SparseBasicResBlock(spconv.SparseModule):
         )
 
     def forward(self, x):
+        mods = [m for m in self.conv._modules.values() if m is not None]
+        last = mods[-1]
+        if type(self.activation) is nn.ReLU and isinstance(last, nn.BatchNorm1d):
+            # relu(bn2(conv2(.)) + shortcut) as one fused op (operators/batchnorm.py) when the features are on the GPU
+            out = spconv.run_modules(mods[:-1], x)
+            shortcut = self.shortcut(x) if self.shortcut is not None else x
+            return out.replace_feature(bn_act(out.features, last, relu=True, residual=shortcut.features))
         out = self.conv(x)
         shortcut = self.shortcut(x) if self.shortcut is not None else x
         out = out.replace_feature(out.features + shortcut.features)

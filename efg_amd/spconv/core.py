@@ -407,6 +407,30 @@ def is_spconv_module(module):
     return isinstance(module, SparseModule)
 
 
+def run_modules(modules, input):
+    """SparseSequential.forward over a list of modules.  A BatchNorm1d (+ the nn.ReLU right after it) on the features
+    of a sparse tensor runs as one fused op (operators/batchnorm.py); everything else as in spconv."""
+    from ..operators.batchnorm import bn_act, fusable
+
+    i = 0
+    while i < len(modules):
+        module = modules[i]
+        if is_spconv_module(module):
+            input = module(input)
+        elif isinstance(input, SparseConvTensor):
+            if input.indices.shape[0] != 0:
+                if isinstance(module, nn.BatchNorm1d) and fusable(module, input.features):
+                    relu = i + 1 < len(modules) and type(modules[i + 1]) is nn.ReLU
+                    input = input.replace_feature(bn_act(input.features, module, relu=relu))
+                    i += 2 if relu else 1
+                    continue
+                input = input.replace_feature(module(input.features))
+        else:
+            input = module(input)
+        i += 1
+    return input
+
+
 class SparseSequential(SparseModule):
     """spconv.pytorch.SparseSequential: sparse modules get the tensor, plain nn.Modules (BatchNorm1d,
     ReLU, ...) are applied to `.features` (sparse_net.py:85-95)."""
@@ -432,17 +456,7 @@ class SparseSequential(SparseModule):
         self.add_module(str(len(self._modules)) if name is None else name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
-            if module is None:
-                continue
-            if is_spconv_module(module):
-                input = module(input)
-            elif isinstance(input, SparseConvTensor):
-                if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
-            else:
-                input = module(input)
-        return input
+        return run_modules([m for m in self._modules.values() if m is not None], input)
 
 
 class SparseConvolution(SparseModule):

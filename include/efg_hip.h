@@ -305,6 +305,25 @@ int efg_box_loss_backward_f32(const float* boxes, const float* tgt_boxes, const 
                               const int64_t* q_idx, const int64_t* g_idx, int64_t n, int layers, int b, int q, int g,
                               const float* denom, const float* grad_out, float* grad_boxes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d (training statistics) + optional residual + optional ReLU over sparse features [m, c]
+ * (the norm / activation steps of efg/modeling/backbones/sparse_net.py:85-95,120-165, which the reference runs as
+ * nn.BatchNorm1d, an add and nn.ReLU).  c % 4 == 0, c <= 1024.
+ *   forward : y = relu?((x - mean) * invstd * weight + bias + residual?); mean / invstd [c] saved for backward;
+ *             running_mean / running_var (NULL or both) updated with `momentum` and the unbiased variance,
+ *             *num_batches_tracked (i64, NULL ok) incremented.
+ *   backward: dx, dresidual (= dy masked by y > 0; NULL ok), dweight / dbias [c].
+ *   ws: efg_bn_workspace_bytes(c).
+ * ---------------------------------------------------------------------------------------- */
+size_t efg_bn_workspace_bytes(int c);
+int efg_bn_forward_f32(const float* x, const float* residual, const float* weight, const float* bias,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                       int64_t m, int c, int relu, float* y, float* mean, float* invstd, void* ws, size_t ws_bytes,
+                       void* stream);
+int efg_bn_backward_f32(const float* dy, const float* x, const float* y, const float* weight, const float* mean,
+                        const float* invstd, int64_t m, int c, int relu, float* dx, float* dresidual, float* dweight,
+                        float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
