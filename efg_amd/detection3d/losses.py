@@ -65,31 +65,34 @@ class Det3DLoss(nn.Module):
         return self._metric_logits, self._metric_classes
 
     # ---- one loss family over stacked layers ------------------------------------------------------------
-    def _layer_losses(self, logits, boxes, sel, tgt_labels, tgt_boxes, num_boxes):
+    def _layer_losses(self, logits, boxes, sel, tgt_labels, tgt_boxes, num_boxes, parts=("ce", "box")):
         """logits [L,B,Q,C], boxes [L,B,Q,7]; sel = (l, b, q, g) int64 index vectors of the matched pairs.
-        Returns {"loss_ce","loss_bbox","loss_giou","loss_rad"} -> [L] vectors."""
+        Returns {"loss_ce","loss_bbox","loss_giou","loss_rad"} -> [L] vectors (`parts` selects the families;
+        the tensor of an unselected family may be None)."""
         l_idx, b_idx, q_idx, g_idx = sel
-        n_layers = logits.shape[0]
+        n_layers = (logits if logits is not None else boxes).shape[0]
         out = {}
         cls = tgt_labels[b_idx, g_idx]
-        if logits.is_cuda:
+        want_ce = "focal_labels" in self.losses and "ce" in parts
+        want_box = "boxes" in self.losses and "box" in parts
+        if (logits if logits is not None else boxes).is_cuda:
             # one kernel per loss family and direction (csrc/det_loss.hip) instead of ~40 elementwise launches each
-            denom = device_scalar(num_boxes, logits.device)
-            if "focal_labels" in self.losses:
+            denom = device_scalar(num_boxes, cls.device)
+            if want_ce:
                 tcls = torch.full(logits.shape[:-1], -1, dtype=torch.int32, device=logits.device)
                 tcls.index_put_((l_idx, b_idx, q_idx), cls.to(torch.int32))
                 out["loss_ce"] = FocalLossLayers.apply(logits, tcls, denom, self.focal_alpha, 2.0)
-            if "boxes" in self.losses:
+            if want_box:
                 sums = BoxLossLayers.apply(boxes, tgt_boxes, l_idx, b_idx, q_idx, g_idx, denom)
                 out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
             return out, cls
-        if "focal_labels" in self.losses:
+        if want_ce:
             onehot = torch.zeros_like(logits)
             # (a Python scalar on the right-hand side would be uploaded synchronously)
             onehot.index_put_((l_idx, b_idx, q_idx, cls), logits.new_ones(()))
             fl = sigmoid_focal_loss(logits, onehot, alpha=self.focal_alpha, gamma=2.0, reduction="none")
             out["loss_ce"] = fl.sum(dim=(1, 2, 3)) / num_boxes
-        if "boxes" in self.losses:
+        if want_box:
             src = boxes[l_idx, b_idx, q_idx]
             tgt = tgt_boxes[b_idx, g_idx]
             l1 = F.l1_loss(src, tgt, reduction="none")
@@ -115,13 +118,17 @@ class Det3DLoss(nn.Module):
         # stack the layers: auxiliary outputs first, the final layer last
         layers = list(outputs.get("aux_outputs", [])) + [outputs]
         logits = torch.stack([o["pred_logits"] for o in layers])
-        boxes = torch.stack([o["pred_boxes"] for o in layers])
         topk = outputs.get("topk_indexes")
         if topk is not None:  # encoder proposals: the matcher and the box loss see the gathered top-k set
             assert len(layers) == 1
             m_logits = torch.gather(logits[0], 1, topk.expand(-1, -1, logits.shape[-1]))[None]
-            m_boxes = torch.gather(boxes[0], 1, topk.expand(-1, -1, boxes.shape[-1]))[None]
+            if outputs.get("topk_boxes") is not None:  # boxes evaluated on the top-k tokens only (transformer.py)
+                boxes, m_boxes = None, outputs["topk_boxes"][None]
+            else:
+                boxes = outputs["pred_boxes"][None]
+                m_boxes = torch.gather(boxes[0], 1, topk.expand(-1, -1, boxes.shape[-1]))[None]
         else:
+            boxes = torch.stack([o["pred_boxes"] for o in layers])
             m_logits, m_boxes = logits, boxes
         q_of_g = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L,B,G] on dev
         outputs["matched_query_of_gt"] = q_of_g[-1]
@@ -136,9 +143,9 @@ class Det3DLoss(nn.Module):
         if topk is not None:
             # classification targets live on the FULL token set at the positions the top-k picked
             q_full = topk[sel[1], sel[2], 0]
-            ce, cls = self._layer_losses(logits, boxes, (sel[0], sel[1], q_full, sel[3]), tgt_labels, tgt_boxes,
-                                         num_boxes)
-            bx, _ = self._layer_losses(m_logits, m_boxes, sel, tgt_labels, tgt_boxes, num_boxes)
+            ce, cls = self._layer_losses(logits, None, (sel[0], sel[1], q_full, sel[3]), tgt_labels, tgt_boxes,
+                                         num_boxes, parts=("ce",))
+            bx, _ = self._layer_losses(None, m_boxes, sel, tgt_labels, tgt_boxes, num_boxes, parts=("box",))
             per_layer = {"loss_ce": ce["loss_ce"], **{k: v for k, v in bx.items() if k != "loss_ce"}}
             self._metric_logits = m_logits[sel[0], sel[1], sel[2]]
         else:

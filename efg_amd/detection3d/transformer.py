@@ -11,7 +11,7 @@ from torch.nn import functional as F
 from ..operators.layernorm import add_layer_norm
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
-from .utils import MLP, flatten_with_shape, get_clones
+from .utils import MLP, flatten_with_shape, get_clones, inverse_sigmoid
 
 
 def _with_pos(tensor, pos):
@@ -147,13 +147,22 @@ class Transformer(nn.Module):
         return self._ref_cache
 
     def _get_enc_proposals(self, enc_embed, ref_windows):
-        """top-k (unsorted, :65) proposals of the 1-class proposal head, detached (:60-81)."""
-        out_logits, out_ref_windows = self.proposal_head(enc_embed, ref_windows)
+        """top-k (unsorted, :65) proposals of the 1-class proposal head, detached (:60-81).
+
+        The reference evaluates the proposal head over every token here, detaches the result, and evaluates it a
+        SECOND time in the loss (voxel_detr.py:198).  Here the class MLP runs once over all tokens (kept, with its
+        graph, for the encoder classification loss) and the box MLP only on the top-k tokens -- the only boxes
+        anything reads (proposals, matcher, box loss): per-token MLPs commute with the gather."""
+        head = self.proposal_head
+        out_logits = head.class_embed[0](enc_embed)
         out_probs = out_logits[..., 0].sigmoid()
-        topk_probs, indexes = torch.topk(out_probs, self.num_queries, dim=1, sorted=False)
+        topk_probs, indexes = torch.topk(out_probs.detach(), self.num_queries, dim=1, sorted=False)
         topk_probs, indexes = topk_probs.unsqueeze(-1), indexes.unsqueeze(-1)
-        out_ref_windows = torch.gather(out_ref_windows, 1, indexes.expand(-1, -1, out_ref_windows.shape[-1]))
-        out_ref_windows = torch.cat((out_ref_windows.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
+        emb_k = torch.gather(enc_embed, 1, indexes.expand(-1, -1, enc_embed.shape[-1]))
+        ref_k = torch.gather(ref_windows, 1, indexes.expand(-1, -1, ref_windows.shape[-1]))
+        boxes_k = (head.bbox_embed[0](emb_k) + inverse_sigmoid(ref_k)).sigmoid()
+        self.enc_outputs = {"pred_logits": out_logits, "topk_boxes": boxes_k, "topk_indexes": indexes}
+        out_ref_windows = torch.cat((boxes_k.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
         return None, None, out_ref_windows, indexes
 
     @torch.no_grad()

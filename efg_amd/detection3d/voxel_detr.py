@@ -229,12 +229,11 @@ class VoxelDETR(nn.Module):
         head = self.transformer.decoder.detection_head
         losses = {}
         # encoder proposal losses (class-agnostic), voxel_detr.py:198-209
-        enc_class, enc_coords = self.transformer.proposal_head(src_embed, src_ref_windows)
         bin_targets = targets.class_agnostic() if isinstance(targets, PaddedTargets) else copy.deepcopy(targets)
         if not isinstance(targets, PaddedTargets):
             for tgt in bin_targets:
                 tgt["labels"].fill_(0)
-        enc_outputs = {"topk_indexes": src_indexes, "pred_logits": enc_class, "pred_boxes": enc_coords}
+        enc_outputs = dict(self.transformer.enc_outputs)  # class logits of all tokens + boxes of the top-k (one evaluation)
         enc_losses = self.transformer.proposal_head.compute_losses(enc_outputs, bin_targets)
         losses.update({k + "_enc": v for k, v in enc_losses.items()})
         nq = self.num_queries
