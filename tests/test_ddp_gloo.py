@@ -32,20 +32,24 @@ def _worker(rank, world, port, out):
     ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
     tr = Trainer(device="cpu", overrides=ov, seed=0, ddp=True)
     tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
-    batch = synthetic_batch(500 + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
+    # three steps: the Trainer wraps the model with static_graph=True, whose steady state starts at step 2
     with cpu_backend.install():
-        loss_dict, total = tr.step(batch)
+        for it in range(3):
+            batch = synthetic_batch(500 + 10 * it + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
+            loss_dict, total = tr.step(batch)
     w = tr.model.backbone.extractor.bottom_up.stem.conv1[0].weight
     g = w.grad.detach().clone()
     gathered = [torch.zeros_like(g) for _ in range(world)]
     dist.all_gather(gathered, g)
-    pw = [torch.zeros_like(w.data) for _ in range(world)]
-    dist.all_gather(pw, w.data)
+    flat = torch.cat([p.data.reshape(-1) for p in tr.model.parameters() if p.requires_grad])
+    pw = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(pw, flat)
     if rank == 0:
         out["grads_equal"] = bool(torch.equal(gathered[0], gathered[1]))      # all-reduced (averaged) gradient
-        out["params_equal"] = bool(torch.equal(pw[0], pw[1]))                  # same update on every rank
+        out["params_equal"] = bool(torch.equal(pw[0], pw[1]))                  # same update on every rank, every parameter
         out["finite"] = bool(torch.isfinite(total))
         out["grad_norm"] = float(g.norm())
+        out["static_graph"] = bool(getattr(tr.wrapped, "static_graph", False))
     dist.destroy_process_group()
 
 
@@ -57,3 +61,4 @@ def test_two_rank_ddp_step(oracle_mod):
         mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
         res = dict(out)
     assert res["finite"] and res["grads_equal"] and res["params_equal"] and res["grad_norm"] > 0
+    assert res["static_graph"]
