@@ -93,6 +93,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.warmup == 0:
+        # lazy initialisation (code-object load, MIOpen find, TunableOp validation: ~8 s in the first step of a fresh
+        # process, scripts/ubench/first_steps.py) is start-up, not a step; with W >= 1 the warm-up absorbs it
+        trainer.step(pool[0])
     for w in range(args.warmup):
         trainer.step(pool[w % len(pool)])
     barrier()
