@@ -851,12 +851,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     const int side = (int)std::ceil(std::sqrt((double)s));
     const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
     if (l * p <= bt::PMAX) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        EFG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(box_bwd_tile_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt::kLdsBytes));
-        attr_set = true;
-      }
+      EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel, bt::kLdsBytes);
       hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes,
                          (hipStream_t)stream, value, (const long long*)shapes, ref_windows, offsets, logits,
                          kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);

@@ -1,6 +1,8 @@
 // Shared host/device helpers for libefg_hip.so (gfx950 only: wave64, no portability layer).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -31,6 +33,21 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 #define EFG_LAUNCH_CHECK() EFG_HIP_TRY(hipGetLastError())
+
+// Opt a kernel into more than 64 KB of dynamic LDS, once per DEVICE (function attributes are per device; the flag
+// word is per call site).  One process normally drives one GPU, but the C ABI accepts pointers on any device.
+#define EFG_ALLOW_DYNAMIC_LDS(kernel, bytes)                                                              \
+  do {                                                                                                    \
+    static std::atomic<unsigned long long> efg_lds_done_{0};                                              \
+    int efg_dev_ = 0;                                                                                     \
+    EFG_HIP_TRY(hipGetDevice(&efg_dev_));                                                                 \
+    const unsigned long long efg_bit_ = 1ull << (efg_dev_ & 63);                                          \
+    if (!(efg_lds_done_.load(std::memory_order_relaxed) & efg_bit_)) {                                    \
+      EFG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));         \
+      efg_lds_done_.fetch_or(efg_bit_, std::memory_order_relaxed);                                        \
+    }                                                                                                     \
+  } while (0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -216,12 +216,7 @@ extern "C" int efg_lsap_f32(const float* cost, int n_problems, int nq, int g_str
   const size_t lds = lds_bytes(small, big);
   EFG_CHECK_ARG(lds <= 150 * 1024, "efg_lsap_f32: problem %d x %d needs %zu B of LDS (limit 153600)", nq, g_stride,
                 lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    EFG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
-  }
+  EFG_ALLOW_DYNAMIC_LDS(lsap_kernel, 150 * 1024);
   hipLaunchKernelGGL(lsap_kernel, dim3(n_problems), dim3(kLsapThreads), lds, (hipStream_t)stream, cost, nq, g_stride,
                      ng, query_of_gt, status);
   EFG_LAUNCH_CHECK();
