@@ -274,9 +274,13 @@ class VoxelDETR(nn.Module):
         projs = torch.cat((outputs_class[:n_layers], outputs_coord[:n_layers]), dim=-1)     # [L, B, Q+gt, 10]
         gt_projs = self.projector(projs[:, :, nq:].detach())                                 # [L, B, gt, C]
         pred_projs = self.predictor(self.projector(projs[:, :, :nq]))                        # [L, B, Q, C]
-        gsel = F.normalize(gt_projs[:, b_idx[:, None], rows], dim=-1, eps=1e-8)              # [L, n, G, C]
-        pn = F.normalize(pred_projs, dim=-1, eps=1e-8)[:, b_idx]                             # [L, n, Q, C]
-        sim = torch.matmul(gsel, pn.transpose(-1, -2)) / self.tau                            # [L, n, G, Q]
+        # every noised-GT row against every query of its scene in ONE [R, C] x [C, Q] product per (layer, scene),
+        # then pick the rows of the matched pairs.  (Gathering the per-pair operands first, as the loop form
+        # suggests, materialises a [L, n, Q, C] copy of the query projections -- 245 MB for 80 boxes -- and runs
+        # L*n small products over it, forward and backward.)
+        gt_n = F.normalize(gt_projs, dim=-1, eps=1e-8)                                        # [L, B, R, C]
+        pn = F.normalize(pred_projs, dim=-1, eps=1e-8)                                        # [L, B, Q, C]
+        sim = (torch.matmul(gt_n, pn.transpose(-1, -2)) / self.tau)[:, b_idx[:, None], rows]  # [L, n, G, Q]
         pos = sim.gather(3, q_idx[None, :, None, None].expand(n_layers, n, groups, 1))
         neg = (torch.exp(sim) * neg_mask[b_idx][None, :, None, :]).sum(dim=-1, keepdim=True)
         per_layer = (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(2, 3)).sum(dim=1)      # [L]
