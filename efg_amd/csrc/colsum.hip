@@ -1,0 +1,192 @@
+// Column sums of a row-major fp32 matrix for gfx950: the bias gradient of the path's Linear layers.
+//
+// Every nn.Linear of the transformer ($CQ/transformer.py:215-243,273-317 linear1 / linear2, the MLP heads
+// $CQ/modules/blocks.py:5-17, $CQ/modules/box_attention.py:31-40 value_proj / output_proj / linear_box / linear_attn)
+// gets its bias gradient from autograd as grad_output.sum(0).  A training step holds ~100 of those reductions:
+// 24 over the 70 688-token encoder sequence (72-290 MB each, run by ATen at 1.8 TB/s) and ~70 over a few thousand
+// decoder rows (15 us each for 2.5 MB: launch-shaped, not bandwidth-shaped) -- 1.7 ms per step together.
+//
+//   K1 partial  one workgroup per block of rows; a lane owns one float4 (or scalar) column slot and, for narrow
+//               matrices, a wave covers several rows per step (64 / pow2ceil(columns/4)); row loop unrolled so
+//               that each wave keeps several KB in flight; rows -> waves -> LDS, fixed order;
+//   K2 final    partial[blocks][C] -> out[C], lanes over columns (coalesced), waves over blocks, fixed order.
+// Deterministic (no atomics).  HBM-bound: one pass over the matrix.
+#include "common.h"
+
+#include <algorithm>
+
+namespace efg {
+namespace {
+
+constexpr int kMaxBlocks = 512;
+
+template <bool kVec>
+struct Acc;
+template <>
+struct Acc<true> {
+  float4 v;
+  __device__ void zero() { v = float4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ void add_from(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  __device__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+  __device__ Acc xor_lane(int m) const {
+    Acc r;
+    r.v = float4{__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64)};
+    return r;
+  }
+  __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+};
+template <>
+struct Acc<false> {
+  float v;
+  __device__ void zero() { v = 0.f; }
+  __device__ void add_from(const float* p) { v += *p; }
+  __device__ void add(const Acc& o) { v += o.v; }
+  __device__ Acc xor_lane(int m) const {
+    Acc r;
+    r.v = __shfl_xor(v, m, 64);
+    return r;
+  }
+  __device__ void store(float* p) const { *p = v; }
+};
+
+// slots = number of column slots (C / 4 float4 or C scalars); slot_log2 = log2(pow2ceil(min(slots, 64))).
+template <bool kVec>
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ x, long long rows, int slots, long long row_stride,
+                      int rows_per_block, int slot_log2, int cols, float* __restrict__ partial) {
+  constexpr int kW = kVec ? 4 : 1;
+  __shared__ Acc<kVec> sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = 1 << slot_log2;  // lanes that share a row
+  const int rps = 64 >> slot_log2;   // rows a wave covers per step
+  const int slot = blockIdx.y * 64 + (lane & (width - 1));
+  const int rsub = lane >> slot_log2;
+  const bool ok = slot < slots;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  Acc<kVec> a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i].zero();
+  if (ok) {
+    const float* base = x + (long long)slot * kW;
+    const long long step = 4ll * rps;
+    long long r = r0 + (long long)wave * rps + rsub;
+    for (; r + 7 * step < r1; r += 8 * step) {  // eight independent loads in flight per lane
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i].add_from(base + (r + i * step) * row_stride);
+    }
+    for (; r < r1; r += step) a[0].add_from(base + r * row_stride);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i].add(a[i + 4]);
+  a[0].add(a[2]);
+  a[1].add(a[3]);
+  a[0].add(a[1]);
+  Acc<kVec>& a0 = a[0];
+  for (int m = width; m < 64; m <<= 1) a0.add(a0.xor_lane(m));  // the wave's row groups
+  if (rsub == 0) sm[wave][lane] = a0;
+  __syncthreads();
+  if (wave == 0 && rsub == 0 && ok) {
+    Acc<kVec> s = sm[0][lane];
+    s.add(sm[1][lane]);
+    s.add(sm[2][lane]);
+    s.add(sm[3][lane]);
+    s.store(partial + (long long)blockIdx.x * cols + (long long)slot * kW);
+  }
+}
+
+// kWaves = 16 for long partial lists (the 70 688-row matrices), 4 for the decoder-sized ones.
+template <int kWaves>
+__global__ void __launch_bounds__(64 * kWaves)
+colsum_final_kernel(const float* __restrict__ partial, int nblocks, int cols, float* __restrict__ out) {
+  __shared__ float sm[kWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    int b = wave;
+    for (; b + 3 * kWaves < nblocks; b += 4 * kWaves) {  // 4 independent loads in flight
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] += partial[(long long)(b + kWaves * i) * cols + c];
+    }
+    for (; b < nblocks; b += kWaves) s[0] += partial[(long long)b * cols + c];
+  }
+  sm[wave][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) t += sm[w][lane];
+    out[c] = t;
+  }
+}
+
+struct ColsumPlan {
+  bool vec;
+  int slots, slot_log2, rows_per_block, nblocks, ygroups;
+};
+
+ColsumPlan colsum_plan(int64_t rows, int cols, int64_t row_stride, const void* x) {
+  ColsumPlan p;
+  p.vec = (cols % 4 == 0) && (row_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  p.slots = p.vec ? cols / 4 : cols;
+  int lg = 0;
+  while ((1 << lg) < std::min(p.slots, 64)) ++lg;
+  p.slot_log2 = lg;
+  const int rps = 64 >> lg;
+  // >= 8 row steps per wave (one fully unrolled batch of loads) per block, and no more than kMaxBlocks partial rows
+  const int64_t min_rows = 32ll * rps;
+  p.rows_per_block = (int)std::max<int64_t>(min_rows, ceil_div(std::max<int64_t>(rows, 1), kMaxBlocks));
+  p.nblocks = (int)std::max<int64_t>(1, ceil_div(std::max<int64_t>(rows, 1), p.rows_per_block));
+  p.ygroups = (int)ceil_div(p.slots, 64);
+  return p;
+}
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" size_t efg_colsum_workspace_bytes(int64_t rows, int cols) {
+  if (rows < 0 || cols < 1) return 0;
+  // a block covers >= 16 rows (colsum_plan), whatever the alignment of the view turns out to be
+  const int64_t nblocks = std::min<int64_t>(kMaxBlocks, std::max<int64_t>(1, ceil_div(rows, 16)));
+  return align_up(sizeof(float) * (size_t)cols * (size_t)nblocks, 256);
+}
+
+extern "C" int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t row_stride, float* out, void* ws,
+                              size_t ws_bytes, void* stream) {
+  EFG_CHECK_ARG(rows >= 0 && cols >= 1, "colsum: bad shape %lld x %d", (long long)rows, cols);
+  EFG_CHECK_ARG(row_stride >= cols, "colsum: row_stride %lld < cols %d", (long long)row_stride, cols);
+  EFG_CHECK_ARG(out, "colsum: null output");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    EFG_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+    return EFG_OK;
+  }
+  EFG_CHECK_ARG(x && ws, "colsum: null pointer");
+  const ColsumPlan p = colsum_plan(rows, cols, row_stride, x);
+  EFG_CHECK_ARG(ws_bytes >= sizeof(float) * (size_t)cols * (size_t)p.nblocks, "colsum: workspace too small");
+  float* partial = p.nblocks == 1 ? out : static_cast<float*>(ws);
+  const dim3 grid(p.nblocks, p.ygroups);
+  if (p.vec)
+    hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, (long long)rows, p.slots,
+                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, (long long)rows, p.slots,
+                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial);
+  EFG_LAUNCH_CHECK();
+  if (p.nblocks > 64) {
+    hipLaunchKernelGGL(colsum_final_kernel<16>, dim3((unsigned)ceil_div(cols, 64)), dim3(1024), 0, st, partial,
+                       p.nblocks, cols, out);
+    EFG_LAUNCH_CHECK();
+  } else if (p.nblocks > 1) {
+    hipLaunchKernelGGL(colsum_final_kernel<4>, dim3((unsigned)ceil_div(cols, 64)), dim3(256), 0, st, partial,
+                       p.nblocks, cols, out);
+    EFG_LAUNCH_CHECK();
+  }
+  return EFG_OK;
+}

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..operators import BoxAttnFunction
+from ..operators.linear import Linear, linear
 from ..operators import box_attention_func as _baf
 
 
@@ -28,8 +29,8 @@ class Box3dAttention(nn.Module):
         self.linear_box_bias = nn.Parameter(torch.zeros(num_head * num_level * num_variable))
         self.linear_attn_weight = nn.Parameter(torch.zeros(num_head * num_level * self.num_point, d_model))
         self.linear_attn_bias = nn.Parameter(torch.zeros(num_head * num_level * self.num_point))
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.out_proj = nn.Linear(d_model, d_model)
+        self.value_proj = Linear(d_model, d_model)
+        self.out_proj = Linear(d_model, d_model)
         # k x k lattice in [-0.4, 0.4]^2 (odd k) as (x, y) pairs, :39-50
         if kernel_size % 2 == 0:
             indices = torch.linspace(-kernel_size // 2 + 0.5, kernel_size // 2 - 0.5, kernel_size)
@@ -52,7 +53,7 @@ class Box3dAttention(nn.Module):
     def _where_to_attend(self, query, v_valid_ratios, ref_windows):
         """:62-95 -> sampling grid [B, L, H, levels, k*k, 2] in normalised (x, y)."""
         B, L = ref_windows.shape[:2]
-        offset_boxes = F.linear(query, self.linear_box_weight, self.linear_box_bias)
+        offset_boxes = linear(query, self.linear_box_weight, self.linear_box_bias)
         offset_boxes = offset_boxes.view(B, L, self.num_head, self.num_level, self.num_variable)
         ref_windows = ref_windows.unsqueeze(2).unsqueeze(3) if ref_windows.dim() == 3 else ref_windows.unsqueeze(3)
         ref_boxes = ref_windows[..., [0, 1, 3, 4]]
@@ -80,12 +81,12 @@ class Box3dAttention(nn.Module):
         if v_mask is not None:
             value = value.masked_fill(v_mask[..., None], float(0))
         value = value.view(B, LV, self.num_head, self.head_dim)
-        attn_weights = F.linear(query, self.linear_attn_weight, self.linear_attn_bias)
+        attn_weights = linear(query, self.linear_attn_weight, self.linear_attn_bias)
         if (v_valid_ratios is None and not ref_windows.requires_grad
                 and _baf.box_attn_fused_available(value, ref_windows, self.head_dim, self.num_level, self.num_point)):
             # MI355X path: geometry + softmax + sampling in one kernel (csrc/box_fused.hip); same result as the
             # reference sequence below without materialising the [B, LQ, H, L, 25, 2] grid.
-            offsets = F.linear(query, self.linear_box_weight, self.linear_box_bias)
+            offsets = linear(query, self.linear_box_weight, self.linear_box_bias)
             output = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, offsets, attn_weights,
                                                      self.kernel_indices, self.num_variable)
             return self.out_proj(output), None

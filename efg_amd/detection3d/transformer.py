@@ -9,6 +9,7 @@ from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
 from ..operators.layernorm import add_layer_norm
+from ..operators.linear import Linear
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
 from .utils import MLP, flatten_with_shape, get_clones, inverse_sigmoid
@@ -24,9 +25,9 @@ class TransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, nlevel, dim_feedforward, dropout, activation="relu"):
         super().__init__()
         self.self_attn = Box3dAttention(d_model, nlevel, nhead, with_rotation=False)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
@@ -63,8 +64,8 @@ class TransformerDecoderLayer(nn.Module):
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.multihead_attn = Box3dAttention(d_model, nlevel, nhead, with_rotation=True)
         self.pos_embed_layer = MLP(10, d_model, d_model, 3)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)

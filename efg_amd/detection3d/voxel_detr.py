@@ -24,6 +24,7 @@ from ..modeling.backbones.fpn import build_resnet_fpn_backbone
 from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import voxelize_batch
+from ..operators.linear import Linear
 from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
@@ -108,8 +109,8 @@ class VoxelDETR(nn.Module):
         self._host_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range)
         cc = config.model.contrastive
         self.eqco, self.tau, self.contras_loss_coeff = cc.eqco, cc.tau, cc.loss_coeff
-        self.projector = nn.Sequential(nn.Linear(10, cc.dim), nn.ReLU(), nn.Linear(cc.dim, cc.dim))
-        self.predictor = nn.Sequential(nn.Linear(cc.dim, cc.dim), nn.ReLU(), nn.Linear(cc.dim, cc.dim))
+        self.projector = nn.Sequential(Linear(10, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
+        self.predictor = nn.Sequential(Linear(cc.dim, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
         self.similarity_f = nn.CosineSimilarity(dim=2)
         self.config = config
         vz = config.dataset.processors

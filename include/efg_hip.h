@@ -324,6 +324,14 @@ int efg_bn_backward_f32(const float* dy, const float* x, const float* y, const f
                         const float* invstd, int64_t m, int c, int relu, float* dx, float* dresidual, float* dweight,
                         float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- column sums: the bias gradient of the path's Linear layers -------------------------------------------
+ * Replaces autograd's grad_output.sum(0) for every nn.Linear of the transformer ($CQ/transformer.py:215-243,
+ * 273-317; $CQ/modules/blocks.py:5-17; $CQ/modules/box_attention.py:31-40).  x: rows x cols fp32, row-major with
+ * `row_stride` floats between rows; out[cols].  Deterministic two-pass reduction; rows == 0 zero-fills. */
+size_t efg_colsum_workspace_bytes(int64_t rows, int cols);
+int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t row_stride, float* out, void* ws, size_t ws_bytes,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

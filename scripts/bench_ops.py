@@ -226,6 +226,16 @@ def bench_copy():
         print("copy %5d MB: %8.1f us  %6.2f TB/s (read + write)" % (mb, t, 2 * a.numel() * 4 / t / 1e6))
 
 
+def bench_colsum():
+    """Bias-gradient column sums: csrc/colsum.hip vs ATen's sum(0)."""
+    from efg_amd.operators.linear import column_sum
+    for rows, cols in [(70688, 256), (70688, 1024), (70688, 200), (70688, 32), (2480, 256), (2800, 256), (2480, 1024)]:
+        x = torch.randn(rows, cols, device=dev)
+        t = timeit(lambda: column_sum(x))
+        ta = timeit(lambda: x.sum(0))
+        print("colsum %6d x %4d: %7.1f us (%5.2f TB/s)   aten sum(0) %7.1f us" % (rows, cols, t, rows * cols * 4 / t / 1e6, ta))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
     for w in which:

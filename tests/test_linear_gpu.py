@@ -1,0 +1,91 @@
+"""csrc/colsum.hip (the bias gradient of the path's Linear layers) and operators/linear.py against PyTorch."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(70688, 256), (70688, 1024), (70688, 200), (70688, 32), (2480, 256), (2800, 256), (2480, 3), (2480, 7),
+          (2480, 1), (5, 10), (1, 256), (17, 1028), (63, 260), (16, 4), (100000, 8), (33, 65)]
+
+
+def _ref(x):
+    return x.double().sum(0)
+
+
+@pytest.mark.parametrize("rows,cols", SHAPES)
+def test_column_sum_matches_fp64(rows, cols):
+    from efg_amd.operators.linear import column_sum
+
+    g = torch.Generator(device="cuda").manual_seed(rows * 7 + cols)
+    x = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 0.25
+    out = column_sum(x)
+    ref = _ref(x)
+    # fp32 tree sum: a few ulps of the partial sums, whose size is ~ |mean| * rows + 3 * sqrt(rows)
+    tol = 4e-7 * (0.25 * rows + 3 * rows ** 0.5) * 4 + 1e-6
+    assert out.shape == (cols,)
+    assert float((out.double() - ref).abs().max()) <= tol, (rows, cols, float((out.double() - ref).abs().max()), tol)
+    # and at least as accurate as ATen's own fp32 reduction (x4 slack)
+    aten = float((x.sum(0).double() - ref).abs().max())
+    assert float((out.double() - ref).abs().max()) <= 4 * aten + 1e-6
+    assert torch.equal(out, column_sum(x))  # deterministic
+
+
+def test_column_sum_views():
+    from efg_amd.operators.linear import column_sum
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    wide = torch.randn(5000, 256, device="cuda", generator=g)
+    for view in (wide[:, :200], wide[:, 1:], wide[:, 4:132], wide[7:, 3:6], wide.t()[:, :77]):
+        out = column_sum(view)
+        assert float((out.double() - _ref(view)).abs().max()) < 2e-3
+    empty = torch.empty(0, 256, device="cuda")
+    assert torch.equal(column_sum(empty), torch.zeros(256, device="cuda"))
+
+
+def test_column_sum_exact_on_integers():
+    """Small integers sum exactly in fp32 whatever the order: the reduction must be bit-exact."""
+    from efg_amd.operators.linear import column_sum
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows, cols in [(70688, 256), (2480, 200), (999, 33)]:
+        x = torch.randint(-8, 9, (rows, cols), device="cuda", generator=g).float()
+        assert torch.equal(column_sum(x), x.double().sum(0).float())
+
+
+@pytest.mark.parametrize("shape,fin,fout", [((2, 1240, 256), 256, 256), ((1240, 2, 256), 256, 1024),
+                                             ((2, 35344, 256), 256, 200), ((2, 300, 10), 10, 256), ((77, 256), 256, 3)])
+def test_linear_matches_nn_linear(shape, fin, fout):
+    from efg_amd.operators.linear import Linear
+
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(fin, fout).cuda()
+    mine = Linear(fin, fout).cuda()
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(*shape, device="cuda")
+    if len(shape) == 3 and shape[0] > shape[1]:
+        x = x.transpose(0, 1).contiguous().transpose(0, 1)  # a strided [Q, B, C] view, as in the decoder
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ref(xa), mine(xb)
+    assert torch.equal(ya, yb)  # same addmm
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    # same product (x^T @ grad); over 70 688 rows the library's split-K order may differ between two calls
+    k = x.numel() // fin
+    assert torch.allclose(ref.weight.grad, mine.weight.grad, rtol=1e-4, atol=2e-6 * k ** 0.5 * float(ref.weight.grad.abs().max()) + 1e-3)
+    scale = float(ref.bias.grad.abs().max()) + 1.0
+    assert float((ref.bias.grad - mine.bias.grad).abs().max()) <= 2e-5 * scale * (x.numel() / fin) ** 0.5
+    # inference / no-grad path is plain F.linear
+    with torch.no_grad():
+        assert torch.equal(mine(x), ref(x))
+
+
+def test_linear_refuses_nothing_on_cpu():
+    """Host tensors run the plain PyTorch layer (dense layers are PyTorch plumbing, not a HIP op)."""
+    from efg_amd.operators.linear import Linear
+
+    m = Linear(8, 4)
+    x = torch.randn(3, 8, requires_grad=True)
+    m(x).sum().backward()
+    assert m.bias.grad is not None
