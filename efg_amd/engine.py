@@ -4,6 +4,7 @@ Counterpart of the slice of efg/engine/trainer.py:168-199,278-305 and efg/engine
 surrounds the path: `step()` = zero_grad -> loss_dict = model(batch) -> sum of differentiable losses
 -> backward (DDP all-reduces gradient buckets over xGMI while backward runs) -> optimizer.step().
 One process per GPU; scenes are sharded across ranks, no activation exchange."""
+import gc
 import os
 
 import numpy as np
@@ -74,9 +75,26 @@ def use_tuned_gemms(path=TUNED_GEMMS):
     return True
 
 
+def limit_host_threads():
+    """The host side of a step is ~2000 kernel launches from two Python threads; nothing in it is a parallel CPU
+    loop worth more than a few cores.  Left alone, OpenMP sizes its pool to the machine (256 hardware threads on
+    the GPU box) and the spin-waiting workers of any stray parallel region burn the container's CPU quota
+    (16 cores per 100 ms period here): the cgroup then throttles the WHOLE process for tens of ms -- 13-21 throttled
+    periods per 45-step run, sporadic 25-45 ms stalls of the launch threads, 37.6-41.2 ms/step instead of 37.1-37.3
+    (scripts/ubench/throttle_ab.sh).  torchrun already exports OMP_NUM_THREADS=1 for N > 1; this does the same job
+    for a bare `python bench.py`.  EFG_HOST_THREADS / OMP_NUM_THREADS override."""
+    if "OMP_NUM_THREADS" in os.environ and "EFG_HOST_THREADS" not in os.environ:
+        return int(os.environ["OMP_NUM_THREADS"])
+    n = int(os.environ.get("EFG_HOST_THREADS", "4"))
+    torch.set_num_threads(n)
+    return n
+
+
 class Trainer:
     def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
+        if str(cfg.model.device if device is None else device).startswith("cuda"):
+            limit_host_threads()
         if device is not None:
             cfg.model.device = str(device)
         if str(cfg.model.device).startswith("cuda"):
@@ -93,6 +111,8 @@ class Trainer:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         use_ddp = (world > 1) if ddp is None else ddp
         self.wrapped = self.model
+        self._steps = 0
+        self._manual_gc = (self.model.device.type == "cuda" and os.environ.get("EFG_MANUAL_GC", "1") != "0")
         if use_ddp:
             dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
             # The reference asks for find_unused_parameters=True ($CQ/config.yaml:183) because the unused FPN levels
@@ -114,7 +134,22 @@ class Trainer:
                 bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),
                 gradient_as_bucket_view=os.environ.get("EFG_DDP_BUCKET_VIEW", "1") == "1", **kw)
 
+    def _collect_garbage(self):
+        """Python's cyclic collector runs a few hundred times per step on the containers autograd creates and
+        costs ~3 ms of host time per step (35.5 -> 32 ms, scripts/ubench/jitter.py); the step frees its graph by
+        reference counting.  After the first steps: freeze what exists, switch the automatic collector off and
+        collect by hand every 100 steps.  EFG_MANUAL_GC=0 leaves the interpreter alone."""
+        if self._steps == 3:
+            gc.collect()
+            gc.freeze()
+            gc.disable()
+        elif self._steps % 100 == 0:
+            gc.collect()
+
     def step(self, batch):
+        self._steps += 1
+        if self._manual_gc:
+            self._collect_garbage()
         self.optimizer.zero_grad(set_to_none=True)
         with record_function("efg::forward"):
             loss_dict = self.wrapped(batch)

@@ -4,6 +4,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ...operators.linear import linear
+
 
 def get_norm(norm, out_channels):
     """efg/modeling/common/batch_norm.py:140-168.  "BN" / "BN1d" / "GN" (32 groups); "" -> None."""
@@ -47,7 +49,7 @@ class Conv2d(nn.Conv2d):
         if self._is_pointwise():
             # 1x1 conv == Linear over the channel axis of the channels-last map: goes to hipBLASLt
             # (MIOpen's 1x1 weight-gradient picks a single-workgroup GEMM for K = B*H*W ~ 70k rows).
-            y = F.linear(x.permute(0, 2, 3, 1), self.weight.view(self.out_channels, self.in_channels), self.bias)
+            y = linear(x.permute(0, 2, 3, 1), self.weight.view(self.out_channels, self.in_channels), self.bias)
             x = y.permute(0, 3, 1, 2)
         else:
             x = super().forward(x)

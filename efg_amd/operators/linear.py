@@ -1,8 +1,9 @@
 """`Linear`: nn.Linear whose backward takes the bias gradient from libefg_hip.so (csrc/colsum.hip).
 
-The matrix products stay where they were -- `addmm` forward, `grad @ W` and `xᵀ @ grad` backward, the very calls
-autograd makes for `F.linear`, so the tuned hipBLASLt solutions (efg_amd/tuned/gemm_gfx950.csv) keep applying --
-only `grad_output.sum(0)` is replaced: ATen runs the ~100 such reductions of a training step at 1.8 TB/s on the
+The forward `addmm` and the input gradient `grad @ W` are the very calls autograd makes for `F.linear`, so the tuned
+hipBLASLt solutions (efg_amd/tuned/gemm_gfx950.csv) keep applying.  Two things change in the backward: the weight
+gradient of the 70 688-row encoder layers is computed as 16 row chunks in one batched product (`weight_grad`), and
+`grad_output.sum(0)` is replaced: ATen runs the ~100 such reductions of a training step at 1.8 TB/s on the
 70 688-token encoder sequence and at 15 us apiece on the decoder's few thousand rows (1.7 ms per step together).
 Same parameters and state-dict names as nn.Linear ($CQ/transformer.py:215-243,273-317, $CQ/modules/blocks.py:5-17,
 $CQ/modules/box_attention.py:31-40)."""
@@ -31,13 +32,33 @@ def column_sum(x2):
     return out
 
 
+_SPLIT_MIN_ROWS = 32768
+_FUSED_MIN_ROWS = 16384  # linear(): rows from which the custom backward is used
+_SPLITS = 16
+
+
+def weight_grad(x2, g2):
+    """grad_outputᵀ @ x -> [out, in].  With tens of thousands of rows and a 256-wide output the product is one
+    long reduction over few output tiles; the library's own split runs [256, 70688] x [70688, 256] in 136 us
+    (68 TFLOP/s).  Sixteen explicit row chunks as one batched product plus a fixed-order sum of the 16 partial
+    matrices take 85 us (scripts/ubench/wgrad_split.py: 333 -> 262 us for the 1024-wide FFN layers, 138 -> 76 us
+    for the 200-wide attention logits).  Deterministic, same fp32 products."""
+    k = x2.shape[0]
+    if k >= _SPLIT_MIN_ROWS and k % _SPLITS == 0 and x2.is_contiguous() and g2.is_contiguous():
+        gs = g2.view(_SPLITS, k // _SPLITS, g2.shape[1])
+        xs = x2.view(_SPLITS, k // _SPLITS, x2.shape[1])
+        return torch.bmm(gs.transpose(1, 2), xs).sum(0)
+    return x2.t().mm(g2).t()  # the call autograd makes for F.linear (tuned solutions apply)
+
+
 class LinearFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
-        return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
+        y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2.mm(weight.t())
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     @once_differentiable
@@ -45,17 +66,23 @@ class LinearFunction(Function):
         x2, weight = ctx.saved_tensors
         g2 = grad.reshape(-1, grad.shape[-1])
         gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        gw = x2.t().mm(g2).t() if ctx.needs_input_grad[1] else None
-        gb = column_sum(g2) if ctx.needs_input_grad[2] else None
+        gw = weight_grad(x2, g2) if ctx.needs_input_grad[1] else None
+        gb = column_sum(g2) if ctx.needs_input_grad[2] else None  # bias=None -> needs_input_grad[2] is False
         return gx, gw, gb
 
 
 def linear(x, weight, bias=None):
     """F.linear; on the GPU, in training, with the bias gradient from the HIP column sum."""
-    if (x.is_cuda and bias is not None and x.dtype == torch.float32 and torch.is_grad_enabled()
-            and bias.requires_grad and x.numel() > 0 and os.environ.get("EFG_FUSED_LINEAR", "1") != "0"):
+    # Only the long matrices (the 70 688-token encoder sequence and the BEV 1x1 convolutions) take the custom
+    # backward: there it saves 50-70 us of device time per layer.  On the decoder's few thousand rows the saving is
+    # ~5 us per layer while a Python autograd.Function costs ~30 us more host time than F.linear, and the step is
+    # close enough to host-bound (~30 ms of launch work against ~37 ms of kernels) for that to matter.
+    if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and x.numel() >= _FUSED_MIN_ROWS * x.shape[-1]
+            and (weight.requires_grad or (bias is not None and bias.requires_grad))
+            and os.environ.get("EFG_FUSED_LINEAR", "1") != "0"):
         return LinearFunction.apply(x, weight, bias)
-    return F.linear(x, weight, bias)  # host tensors (the CPU tests), inference: plain PyTorch, same math
+    return F.linear(x, weight, bias)  # short matrices, inference, host tensors (the CPU tests): same math
 
 
 class Linear(nn.Linear):

@@ -55,7 +55,7 @@ def test_column_sum_exact_on_integers():
 @pytest.mark.parametrize("shape,fin,fout", [((2, 1240, 256), 256, 256), ((1240, 2, 256), 256, 1024),
                                              ((2, 35344, 256), 256, 200), ((2, 300, 10), 10, 256), ((77, 256), 256, 3)])
 def test_linear_matches_nn_linear(shape, fin, fout):
-    from efg_amd.operators.linear import Linear
+    from efg_amd.operators.linear import Linear, LinearFunction
 
     torch.manual_seed(0)
     ref = torch.nn.Linear(fin, fout).cuda()
@@ -65,7 +65,8 @@ def test_linear_matches_nn_linear(shape, fin, fout):
     if len(shape) == 3 and shape[0] > shape[1]:
         x = x.transpose(0, 1).contiguous().transpose(0, 1)  # a strided [Q, B, C] view, as in the decoder
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    ya, yb = ref(xa), mine(xb)
+    # linear() routes short matrices to F.linear; exercise the custom backward at every size
+    ya, yb = ref(xa), LinearFunction.apply(xb, mine.weight, mine.bias)
     assert torch.equal(ya, yb)  # same addmm
     w = torch.randn_like(ya)
     (ya * w).sum().backward()
@@ -79,6 +80,56 @@ def test_linear_matches_nn_linear(shape, fin, fout):
     # inference / no-grad path is plain F.linear
     with torch.no_grad():
         assert torch.equal(mine(x), ref(x))
+
+
+def test_weight_grad_split_matches_single_product():
+    """The 16-chunk batched weight gradient of the 70 688-row layers against the single product, fp64 as referee."""
+    from efg_amd.operators.linear import weight_grad
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for k, cin, cout in [(70688, 256, 256), (70688, 256, 1024), (70688, 1024, 256), (70688, 256, 200), (35344, 384, 256)]:
+        x = torch.randn(k, cin, device="cuda", generator=g)
+        go = torch.randn(k, cout, device="cuda", generator=g)
+        got = weight_grad(x, go)
+        assert got.shape == (cout, cin) and got.is_contiguous()
+        ref = go.double().t().mm(x.double())
+        one = x.t().mm(go).t()
+        scale = float(ref.abs().max())
+        e_split, e_one = float((got.double() - ref).abs().max()) / scale, float((one.double() - ref).abs().max()) / scale
+        assert e_split < 2e-5 and e_split <= 4 * e_one + 1e-7, (k, cin, cout, e_split, e_one)
+        assert torch.equal(got, weight_grad(x, go))  # deterministic
+    # short matrices keep the single product
+    x, go = torch.randn(2480, 256, device="cuda"), torch.randn(2480, 256, device="cuda")
+    assert torch.equal(weight_grad(x, go), x.t().mm(go).t())
+
+
+def test_linear_without_bias_and_pointwise_conv():
+    from efg_amd.modeling.common import Conv2d
+    from efg_amd.operators.linear import LinearFunction, linear
+
+    torch.manual_seed(1)
+    w = torch.randn(64, 32, device="cuda", requires_grad=True)
+    x = torch.randn(3, 50, 32, device="cuda", requires_grad=True)
+    y = LinearFunction.apply(x, w, None)
+    y2 = torch.nn.functional.linear(x.detach(), w.detach())
+    assert torch.equal(y, y2)
+    y.square().sum().backward()
+    wr, xr = w.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr).square().sum().backward()
+    assert torch.allclose(w.grad, wr.grad, rtol=1e-5, atol=1e-4) and torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-5)
+    conv = Conv2d(32, 48, kernel_size=1).cuda()
+    ref = torch.nn.Conv2d(32, 48, kernel_size=1).cuda()
+    ref.load_state_dict(conv.state_dict())
+    assert linear(x.detach().requires_grad_(True), w).grad_fn.__class__.__name__ != "LinearFunctionBackward"  # short
+    xi = torch.randn(2, 32, 100, 96, device="cuda").contiguous(memory_format=torch.channels_last)  # 19 200 rows
+    a, b = xi.clone().requires_grad_(True), xi.clone().requires_grad_(True)
+    ya, yb = conv(a), ref(b)
+    assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5)
+    ya.square().sum().backward()
+    yb.square().sum().backward()
+    assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(conv.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-4)
 
 
 def test_linear_refuses_nothing_on_cpu():
