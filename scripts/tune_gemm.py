@@ -49,7 +49,7 @@ if os.environ.get("EFG_TUNE_ROTATE_MB"):  # cold-cache timing: rotate operands t
 t0 = time.perf_counter()
 steps(3, "tuning:")
 print("tuning took %.1f s, %d entries" % (time.perf_counter() - t0, len(tunable.get_results())), flush=True)
-tunable.write_file(out)
+# (the results file is written as tuning proceeds)
 tunable.tuning_enable(False)
 steps(8, "tuned:")
 print("validators:", tunable.get_validators())
