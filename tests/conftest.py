@@ -19,6 +19,19 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
 
+@pytest.fixture(autouse=True)
+def _restore_gc():
+    """A Trainer that runs >= 3 steps on the GPU freezes and disables the cyclic collector (engine.py); give the
+    next test the interpreter's default back."""
+    import gc
+
+    yield
+    if not gc.isenabled():
+        gc.enable()
+        gc.unfreeze()
+        gc.collect()
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     """The CPU checker (oracle/).  Test infrastructure only."""
