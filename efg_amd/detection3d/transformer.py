@@ -9,7 +9,7 @@ from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
 from ..operators.layernorm import add_layer_norm
-from ..operators.linear import Linear
+from ..operators.linear import Linear, linear
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
 from .utils import MLP, flatten_with_shape, get_clones, inverse_sigmoid
@@ -38,7 +38,8 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, src_shape, src_start_idx, ref_windows):
         src2 = self.self_attn(_with_pos(src, pos), src, src_shape, None, src_start_idx, None, ref_windows)[0]
         src = add_layer_norm(src, self.dropout1(src2), self.norm1)
-        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        hidden = linear(src, self.linear1.weight, self.linear1.bias, relu=True)  # activation(linear1(src))
+        src2 = self.linear2(self.dropout(hidden))
         return add_layer_norm(src, self.dropout2(src2), self.norm2)
 
 

@@ -53,36 +53,49 @@ def weight_grad(x2, g2):
 
 class LinearFunction(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu=False):
         x2 = x.reshape(-1, x.shape[-1])
-        ctx.save_for_backward(x2, weight)
+        if relu and bias is not None:
+            # bias + ReLU in the GEMM epilogue (hipBLASLt): bit-identical to relu(addmm(...)), and the 290 MB
+            # activation of the encoder FFN is written once instead of written, read and written again
+            # (scripts/ubench/addmm_relu.py: 294 us against 304 + 103 us)
+            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+        else:
+            y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2.mm(weight.t())
+            if relu:
+                y = torch.relu_(y)
+        ctx.relu = relu
+        ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.x_shape = x.shape
-        y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2.mm(weight.t())
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad):
-        x2, weight = ctx.saved_tensors
+        x2, weight, y = ctx.saved_tensors
         g2 = grad.reshape(-1, grad.shape[-1])
+        if ctx.relu:
+            g2 = torch.ops.aten.threshold_backward(g2, y, 0)  # what autograd runs for relu
         gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = weight_grad(x2, g2) if ctx.needs_input_grad[1] else None
         gb = column_sum(g2) if ctx.needs_input_grad[2] else None  # bias=None -> needs_input_grad[2] is False
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def linear(x, weight, bias=None):
-    """F.linear; on the GPU, in training, with the bias gradient from the HIP column sum."""
+def linear(x, weight, bias=None, relu=False):
+    """F.linear (followed by ReLU when `relu`); on the GPU, in training, on long matrices with the backward of
+    this module."""
     # Only the long matrices (the 70 688-token encoder sequence and the BEV 1x1 convolutions) take the custom
     # backward: there it saves 50-70 us of device time per layer.  On the decoder's few thousand rows the saving is
     # ~5 us per layer while a Python autograd.Function costs ~30 us more host time than F.linear, and the step is
-    # close enough to host-bound (~30 ms of launch work against ~37 ms of kernels) for that to matter.
+    # close enough to host-bound (~31 ms of launch work against ~36 ms of kernels) for that to matter.
     if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
             and x.numel() >= _FUSED_MIN_ROWS * x.shape[-1]
             and (weight.requires_grad or (bias is not None and bias.requires_grad))
             and os.environ.get("EFG_FUSED_LINEAR", "1") != "0"):
-        return LinearFunction.apply(x, weight, bias)
-    return F.linear(x, weight, bias)  # short matrices, inference, host tensors (the CPU tests): same math
+        return LinearFunction.apply(x, weight, bias, relu)
+    y = F.linear(x, weight, bias)  # short matrices, inference, host tensors (the CPU tests): same math
+    return F.relu(y) if relu else y
 
 
 class Linear(nn.Linear):

@@ -66,7 +66,7 @@ def test_linear_matches_nn_linear(shape, fin, fout):
         x = x.transpose(0, 1).contiguous().transpose(0, 1)  # a strided [Q, B, C] view, as in the decoder
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     # linear() routes short matrices to F.linear; exercise the custom backward at every size
-    ya, yb = ref(xa), LinearFunction.apply(xb, mine.weight, mine.bias)
+    ya, yb = ref(xa), LinearFunction.apply(xb, mine.weight, mine.bias, False)
     assert torch.equal(ya, yb)  # same addmm
     w = torch.randn_like(ya)
     (ya * w).sum().backward()
@@ -110,7 +110,7 @@ def test_linear_without_bias_and_pointwise_conv():
     torch.manual_seed(1)
     w = torch.randn(64, 32, device="cuda", requires_grad=True)
     x = torch.randn(3, 50, 32, device="cuda", requires_grad=True)
-    y = LinearFunction.apply(x, w, None)
+    y = LinearFunction.apply(x, w, None, False)
     y2 = torch.nn.functional.linear(x.detach(), w.detach())
     assert torch.equal(y, y2)
     y.square().sum().backward()
@@ -130,6 +130,30 @@ def test_linear_without_bias_and_pointwise_conv():
     assert torch.allclose(conv.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(conv.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-4)
+
+
+def test_linear_relu_epilogue():
+    """linear(..., relu=True): bias + ReLU in the GEMM epilogue, identical values, autograd-identical gradients."""
+    from efg_amd.operators.linear import linear
+
+    torch.manual_seed(2)
+    w = (torch.randn(1024, 256, device="cuda") * 0.05).requires_grad_(True)
+    b = torch.randn(1024, device="cuda").requires_grad_(True)
+    x = torch.randn(2, 10000, 256, device="cuda", requires_grad=True)
+    y = linear(x, w, b, relu=True)
+    assert y.grad_fn.__class__.__name__ == "LinearFunctionBackward"
+    wr, br, xr = (t.detach().clone().requires_grad_(True) for t in (w, b, x))
+    yr = torch.relu(torch.nn.functional.linear(xr, wr, br))
+    assert torch.equal(y, yr)
+    up = torch.randn_like(y)
+    (y * up).sum().backward()
+    (yr * up).sum().backward()
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(w.grad, wr.grad, rtol=1e-4, atol=2e-2)
+    assert torch.allclose(b.grad, br.grad, rtol=1e-4, atol=2e-2)
+    # short input: plain PyTorch
+    xs = torch.randn(2, 100, 256, device="cuda", requires_grad=True)
+    assert torch.equal(linear(xs, w, b, relu=True), torch.relu(torch.nn.functional.linear(xs, w, b)))
 
 
 def test_linear_refuses_nothing_on_cpu():
