@@ -1,4 +1,5 @@
-// BatchNorm1d (+ residual) (+ ReLU) over sparse-tensor features [M, C] for gfx950, training mode.
+// BatchNorm1d (+ residual) (+ ReLU) over sparse-tensor features [M, C] for gfx950, training mode
+// (and, further down, GroupNorm over the channels-last BEV map with the same chunked statistics).
 //
 // The sparse backbone normalises after every convolution (sparse_net.py:85-95,120-165): BatchNorm1d over the M
 // active sites, then ReLU, in the residual blocks `relu(bn(conv) + shortcut)`.  PyTorch runs that as 4 kernels
@@ -62,6 +63,9 @@ bn_stats_kernel(const float* __restrict__ x, long long m, int c, float* __restri
   const int q4 = c / 4, rstep = 256 / q4;
   const int cq = threadIdx.x % q4, r0 = threadIdx.x / q4;
   const bool lane_on = r0 < rstep;  // 256 % q4 may leave idle threads
+  // blockIdx.y = sample for the per-sample statistics of GroupNorm (m rows each); BatchNorm launches one
+  x += (long long)blockIdx.y * m * c;
+  partial += (long long)blockIdx.y * gridDim.x * 3 * c;
   const Chunk ck = chunk_of(m, gridDim.x, blockIdx.x);
   const float n = (float)(ck.row_hi - ck.row_lo);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -254,6 +258,159 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
   st4(dx + e * 4, o);
 }
 
+// ---- GroupNorm over channels-last BEV maps [B][rows = H*W][C] ------------------------------------------------
+// (the input projection in front of the transformer, $CQ/voxel_detr.py:43-51: Conv2d 1x1 + GroupNorm(32, 256)).
+// ATen's GroupNorm wants NCHW: on the channels-last map that costs a 72 MB transposing copy before it, one after it
+// (the [B, HW, C] token layout the encoder reads) and the same two on the way back.  Here the statistics of a
+// (sample, group) are the Chan merge of the per-chunk per-channel triples over the chunks and the group's channels.
+
+// one wave per (group, sample): lanes over (chunk, channel-in-group) items
+__global__ void __launch_bounds__(64)
+gn_stats_merge_kernel(const float* __restrict__ partial, int nchunks, int c, int cpg, float eps,
+                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x, g = blockIdx.x, b = blockIdx.y, groups = c / cpg;
+  const float* base = partial + (long long)b * nchunks * 3 * c;
+  float cnt = 0.f, mean = 0.f, M2 = 0.f;
+  const int items = nchunks * cpg;
+  for (int i = lane; i < items; i += 64) {
+    const float* p = base + (long long)(i / cpg) * 3 * c + g * cpg + i % cpg;
+    const float nb = p[0], mb = p[c], qb = p[2 * c];
+    if (nb > 0.f) {
+      const float tot_n = cnt + nb, d = mb - mean;
+      mean += d * (nb / tot_n);
+      M2 += qb + d * d * (cnt * nb / tot_n);
+      cnt = tot_n;
+    }
+  }
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const float n2 = __shfl_xor(cnt, dlt, 64), m2 = __shfl_xor(mean, dlt, 64), q2 = __shfl_xor(M2, dlt, 64);
+    const bool low = !(lane & dlt);
+    const float na = low ? cnt : n2, ma = low ? mean : m2, qa = low ? M2 : q2;
+    const float nb = low ? n2 : cnt, mb = low ? m2 : mean, qb = low ? q2 : M2;
+    const float tot_n = na + nb;
+    if (tot_n > 0.f) {
+      const float d = mb - ma;
+      mean = ma + d * (nb / tot_n);
+      M2 = qa + qb + d * d * (na * nb / tot_n);
+    } else {
+      mean = 0.f;
+      M2 = 0.f;
+    }
+    cnt = tot_n;
+  }
+  if (lane == 0) {
+    mean_out[b * groups + g] = mean;
+    rstd_out[b * groups + g] = 1.0f / sqrtf((cnt > 0.f ? M2 / cnt : 0.f) + eps);
+  }
+}
+
+// blockIdx.y = sample; e = float4 index inside the sample
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                const float* __restrict__ mean, const float* __restrict__ rstd, long long total4, int c, int cpg,
+                float* __restrict__ y) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  const int ch = (int)((e * 4) % c), sg = blockIdx.y * (c / cpg) + ch / cpg;
+  const long long o = ((long long)blockIdx.y * total4 + e) * 4;
+  const float mu = mean[sg], rs = rstd[sg];
+  const float4 v = ld4(x + o), ww = ld4(w + ch), bb = ld4(bias + ch);
+  st4(y + o, make_float4((v.x - mu) * rs * ww.x + bb.x, (v.y - mu) * rs * ww.y + bb.y, (v.z - mu) * rs * ww.z + bb.z,
+                         (v.w - mu) * rs * ww.w + bb.w));
+}
+
+// partial[sample][chunk][0][c] = sum dy, [1][c] = sum dy * xhat
+__global__ void __launch_bounds__(256)
+gn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, long long m, int c, int cpg, float* __restrict__ partial) {
+  __shared__ float4 smem[256];
+  const int q4 = c / 4, rstep = 256 / q4;
+  const int cq = threadIdx.x % q4, r0 = threadIdx.x / q4;
+  const bool lane_on = r0 < rstep;
+  dy += (long long)blockIdx.y * m * c;
+  x += (long long)blockIdx.y * m * c;
+  partial += (long long)blockIdx.y * gridDim.x * 2 * c;
+  const Chunk ck = chunk_of(m, gridDim.x, blockIdx.x);
+  const int sg = blockIdx.y * (c / cpg) + (cq * 4) / cpg;
+  const float mu = mean[sg], rs = rstd[sg];
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (lane_on)
+    for (long long r = ck.row_lo + r0; r < ck.row_hi; r += rstep) {
+      const long long o = r * c + cq * 4;
+      const float4 d = ld4(dy + o), v = ld4(x + o);
+      s1.x += d.x;
+      s1.y += d.y;
+      s1.z += d.z;
+      s1.w += d.w;
+      s2.x += d.x * (v.x - mu) * rs;
+      s2.y += d.y * (v.y - mu) * rs;
+      s2.z += d.z * (v.z - mu) * rs;
+      s2.w += d.w * (v.w - mu) * rs;
+    }
+  const float4 t1 = quad_sum(s1, q4, smem), t2 = quad_sum(s2, q4, smem);
+  if ((int)threadIdx.x < q4) {
+    float* p = partial + (long long)blockIdx.x * 2 * c + cq * 4;
+    st4(p, t1);
+    st4(p + c, t2);
+  }
+}
+
+// one wave per (element of [2][c], sample): sums[sample][2][c], lanes over the chunks
+__global__ void __launch_bounds__(64)
+gn_bwd_merge_kernel(const float* __restrict__ partial, int nchunks, int c, float* __restrict__ sums) {
+  const int lane = threadIdx.x, e = blockIdx.x, b = blockIdx.y;
+  const float* base = partial + (long long)b * nchunks * 2 * c;
+  float s = 0.f;
+  for (int k = lane; k < nchunks; k += 64) s += base[(long long)k * 2 * c + e];
+#pragma unroll
+  for (int dlt = 32; dlt > 0; dlt >>= 1) s += __shfl_xor(s, dlt, 64);
+  if (lane == 0) sums[(long long)b * 2 * c + e] = s;
+}
+
+// dbias / dweight over the samples; per (sample, group): A = sum_c w_c S1, B = sum_c w_c S2  (ab[sample][group][2])
+__global__ void __launch_bounds__(256)
+gn_bwd_finish_kernel(const float* __restrict__ sums, const float* __restrict__ w, int batch, int c, int cpg,
+                     float* __restrict__ dbias, float* __restrict__ dweight, float* __restrict__ ab) {
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < batch; ++b) {
+      s1 += sums[(long long)b * 2 * c + ch];
+      s2 += sums[(long long)b * 2 * c + c + ch];
+    }
+    dbias[ch] = s1;
+    dweight[ch] = s2;
+  }
+  const int groups = c / cpg;
+  for (int i = threadIdx.x; i < batch * groups; i += 256) {
+    const int b = i / groups, g = i % groups;
+    float a = 0.f, bb = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      const int ch = g * cpg + k;
+      a += w[ch] * sums[(long long)b * 2 * c + ch];
+      bb += w[ch] * sums[(long long)b * 2 * c + c + ch];
+    }
+    ab[2 * i] = a;
+    ab[2 * i + 1] = bb;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ ab,
+                    long long total4, long long m, int c, int cpg, float* __restrict__ dx) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total4) return;
+  const int ch = (int)((e * 4) % c), sg = blockIdx.y * (c / cpg) + ch / cpg;
+  const long long o = ((long long)blockIdx.y * total4 + e) * 4;
+  const float mu = mean[sg], rs = rstd[sg];
+  const float inv_n = 1.0f / ((float)m * (float)cpg);
+  const float a = ab[2 * sg] * inv_n, b = ab[2 * sg + 1] * inv_n;
+  const float4 d = ld4(dy + o), v = ld4(x + o), ww = ld4(w + ch);
+  st4(dx + o, make_float4((ww.x * d.x - a - (v.x - mu) * rs * b) * rs, (ww.y * d.y - a - (v.y - mu) * rs * b) * rs,
+                          (ww.z * d.z - a - (v.z - mu) * rs * b) * rs, (ww.w * d.w - a - (v.w - mu) * rs * b) * rs));
+}
+
 int nblocks_for(long long m) { return (int)std::max<long long>(1, std::min<long long>(kBnBlocks, ceil_div(m, 32))); }
 
 }  // namespace
@@ -311,6 +468,63 @@ extern "C" int efg_bn_backward_f32(const float* dy, const float* x, const float*
   const long long total4 = (long long)m * c / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, st, dy, x, y, weight, mean,
                      invstd, dbias, dweight, total4, (long long)m, c, relu, dx, dresidual);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+// ---- GroupNorm (channels-last) --------------------------------------------------------------------------------
+// workspace: partials [batch][kBnBlocks][3][c] + sums [batch][2][c] + ab [batch][groups][2] floats
+extern "C" size_t efg_gn_workspace_bytes(int batch, int c) {
+  if (batch < 1 || c < 1) return 0;
+  return align_up(sizeof(float) * ((size_t)batch * kBnBlocks * 3 * c + (size_t)batch * 4 * c), 256) + 256;
+}
+
+static int gn_check(int batch, int64_t rows, int c, int groups) {
+  EFG_CHECK_ARG(batch >= 1 && batch <= 65535 && rows >= 1, "group_norm: need batch in [1, 65535] and rows >= 1");
+  EFG_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= 1024, "group_norm: need c %% 4 == 0 and c <= 1024 (got %d)", c);
+  EFG_CHECK_ARG(groups >= 1 && c % groups == 0 && (c / groups) % 4 == 0,
+                "group_norm: channels per group must be a multiple of 4 (c = %d, groups = %d)", c, groups);
+  return EFG_OK;
+}
+
+extern "C" int efg_gn_forward_f32(const float* x, const float* weight, const float* bias, float eps, int batch,
+                                  int64_t rows, int c, int groups, float* y, float* mean, float* rstd, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (int rc = gn_check(batch, rows, c, groups)) return rc;
+  EFG_CHECK_ARG(x && weight && bias && y && mean && rstd && ws, "group_norm: null pointer");
+  EFG_CHECK_ARG(ws_bytes >= efg_gn_workspace_bytes(batch, c), "group_norm: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblocks_for(rows), cpg = c / groups;
+  float* partial = static_cast<float*>(ws);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, batch), dim3(256), 0, st, x, (long long)rows, c, partial);
+  hipLaunchKernelGGL(gn_stats_merge_kernel, dim3(groups, batch), dim3(64), 0, st, partial, nb, c, cpg, eps, mean, rstd);
+  EFG_LAUNCH_CHECK();
+  const long long total4 = (long long)rows * c / 4;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)ceil_div(total4, 256), batch), dim3(256), 0, st, x, weight, bias,
+                     mean, rstd, total4, c, cpg, y);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_gn_backward_f32(const float* dy, const float* x, const float* weight, const float* mean,
+                                   const float* rstd, int batch, int64_t rows, int c, int groups, float* dx,
+                                   float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = gn_check(batch, rows, c, groups)) return rc;
+  EFG_CHECK_ARG(dy && x && weight && mean && rstd && dx && dweight && dbias && ws, "group_norm backward: null pointer");
+  EFG_CHECK_ARG(ws_bytes >= efg_gn_workspace_bytes(batch, c), "group_norm backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblocks_for(rows), cpg = c / groups;
+  float* partial = static_cast<float*>(ws);
+  float* sums = partial + (size_t)batch * kBnBlocks * 3 * c;
+  float* ab = sums + (size_t)batch * 2 * c;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nb, batch), dim3(256), 0, st, dy, x, mean, rstd, (long long)rows, c, cpg,
+                     partial);
+  hipLaunchKernelGGL(gn_bwd_merge_kernel, dim3(2 * c, batch), dim3(64), 0, st, partial, nb, c, sums);
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(1), dim3(256), 0, st, sums, weight, batch, c, cpg, dbias, dweight, ab);
+  EFG_LAUNCH_CHECK();
+  const long long total4 = (long long)rows * c / 4;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)ceil_div(total4, 256), batch), dim3(256), 0, st, dy, x, weight,
+                     mean, rstd, ab, total4, (long long)rows, c, cpg, dx);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

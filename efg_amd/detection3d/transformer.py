@@ -179,7 +179,10 @@ class Transformer(nn.Module):
         assert pos is not None, "position encoding is required!"
         src_anchors = self._create_ref_windows(src)
         src, src_shape = flatten_with_shape(src)
-        src_pos = torch.cat([pe.flatten(2).transpose(1, 2) for pe in pos], dim=1)
+        if len(pos) == 1:
+            src_pos = pos[0].flatten(2).transpose(1, 2).contiguous()  # cached channels-last: a view, no copy
+        else:
+            src_pos = torch.cat([pe.flatten(2).transpose(1, 2) for pe in pos], dim=1)
         src_start_index = torch.cat([src_shape.new_zeros(1), src_shape.prod(1).cumsum(0)[:-1]])
         with record_function("efg::encoder"):
             memory = self.encoder(src, src_pos, src_shape, src_start_index, src_anchors)

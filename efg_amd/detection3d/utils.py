@@ -115,7 +115,10 @@ def _shapes_on_device(shapes, device):
 def flatten_with_shape(tensor_list):
     """[(B,C,Hi,Wi)] -> ((B, sum Hi*Wi, C), int64 [N,2] shapes) ($CQ/modules/utils.py:277-314)."""
     shapes = _shapes_on_device(tuple((t.shape[2], t.shape[3]) for t in tensor_list), tensor_list[0].device)
-    flat = torch.cat([t.flatten(2).permute(0, 2, 1) for t in tensor_list], dim=1)
+    if len(tensor_list) == 1:  # one level: a channels-last map already IS the token layout (cat would copy it)
+        flat = tensor_list[0].flatten(2).permute(0, 2, 1).contiguous()
+    else:
+        flat = torch.cat([t.flatten(2).permute(0, 2, 1) for t in tensor_list], dim=1)
     return flat, shapes
 
 

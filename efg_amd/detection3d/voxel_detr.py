@@ -23,8 +23,8 @@ from torch.autograd.profiler import record_function
 from ..modeling.backbones.fpn import build_resnet_fpn_backbone
 from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
-from ..operators import voxelize_batch
-from ..operators.linear import Linear
+from ..operators import groupnorm, voxelize_batch
+from ..operators.linear import Linear, linear
 from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
@@ -152,6 +152,20 @@ class VoxelDETR(nn.Module):
                 t.record_stream(main)
         return out["voxels"], out["coordinates"], out["num_points_per_voxel"], self.grid_size, mean
 
+    @staticmethod
+    def _project(proj, x):
+        """input_proj[i](x) = GroupNorm(Conv2d 1x1 (x)) (:43-51).  On the GPU both run on the channels-last map: the
+        convolution as a GEMM, the norm by the HIP kernel in the same layout -- which is also the [B, H*W, C] token
+        layout the encoder reads, so no transposing copy is left between the backbone and the transformer."""
+        conv, norm = proj[0], proj[1]
+        if (len(proj) == 2 and x.is_cuda and isinstance(conv, Conv2d) and conv._is_pointwise() and conv.norm is None
+                and conv.activation is None):
+            y = linear(x.permute(0, 2, 3, 1), conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+            if groupnorm.fusable(y, norm):
+                return groupnorm.group_norm_nhwc(y, norm).permute(0, 3, 1, 2)
+            return norm(y.permute(0, 3, 1, 2))
+        return proj(x)
+
     def _geometry_stream(self):
         """High-priority side stream for voxelization + sparse-conv geometry (spconv/core.py `geometry_stream`);
         None on CPU or with EFG_GEOMETRY_STREAM=0."""
@@ -190,7 +204,7 @@ class VoxelDETR(nn.Module):
         with record_function("efg::backbone+fpn"):
             with spconv_core.geometry_stream(self._geometry_stream()):
                 feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
-            features = [self.input_proj[i](fp[0]) for i, fp in enumerate(feats_pos)]
+            features = [self._project(self.input_proj[i], fp[0]) for i, fp in enumerate(feats_pos)]
         pos_encodings = [fp[1] for fp in feats_pos]
         dn = self.config.model.dn
         if self.training and dn.enabled and dn.dn_number > 0:

@@ -324,6 +324,18 @@ int efg_bn_backward_f32(const float* dy, const float* x, const float* y, const f
                         const float* invstd, int64_t m, int c, int relu, float* dx, float* dresidual, float* dweight,
                         float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- GroupNorm over a channels-last map [batch][rows = H*W][c] ---------------------------------------------
+ * The input projection in front of the transformer ($CQ/voxel_detr.py:43-51: Conv2d 1x1 + nn.GroupNorm(32, 256)),
+ * computed in the token layout the encoder reads instead of NCHW (two 72 MB transposing copies each way).
+ * Biased variance, eps inside the square root (torch.nn.functional.group_norm).  c / groups must be a multiple of 4.
+ *   forward : y, mean / rstd [batch * groups];   backward: dx, dweight / dbias [c].   ws: efg_gn_workspace_bytes. */
+size_t efg_gn_workspace_bytes(int batch, int c);
+int efg_gn_forward_f32(const float* x, const float* weight, const float* bias, float eps, int batch, int64_t rows,
+                       int c, int groups, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes, void* stream);
+int efg_gn_backward_f32(const float* dy, const float* x, const float* weight, const float* mean, const float* rstd,
+                        int batch, int64_t rows, int c, int groups, float* dx, float* dweight, float* dbias, void* ws,
+                        size_t ws_bytes, void* stream);
+
 /* ---- column sums: the bias gradient of the path's Linear layers -------------------------------------------
  * Replaces autograd's grad_output.sum(0) for every nn.Linear of the transformer ($CQ/transformer.py:215-243,
  * 273-317; $CQ/modules/blocks.py:5-17; $CQ/modules/box_attention.py:31-40).  x: rows x cols fp32, row-major with
