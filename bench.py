@@ -12,11 +12,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import efg_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def parse():

@@ -90,6 +90,54 @@ def limit_host_threads():
     return n
 
 
+class FlatGradientAllReduce:
+    """The data-parallel exchange step: ONE all-reduce (mean) of all gradients after backward.
+
+    Replaces the reference's DistributedDataParallel wrapper (efg/engine/trainer.py:191-198).  DDP hangs a hook on
+    each of the ~300 parameters, copies every gradient into a bucket (one small kernel per parameter) and launches
+    an all-reduce per bucket so that communication overlaps with backward.  On this step that machinery costs more
+    than it can hide: 69 MB of gradients are ~0.4 ms on the xGMI ring, while the wrapper adds 2-3.5 ms per step
+    (scripts/ubench/ddp_modes.py, 1 rank on the RCCL backend: bare model 35.4-35.8 ms, `static_graph` DDP 38.9 ms,
+    this 35.7-36.3 ms) -- the step is close to host-bound and the hooks sit on the backward thread's critical path.
+    Here the gradients are packed by one multi-tensor copy into a persistent flat buffer, reduced by one RCCL call
+    (a single large collective: what the point-to-point xGMI links like), and the optimizer reads them through views
+    of that buffer (no copy back): 0.23 ms of device time and ~1.1 ms of host time per step
+    (scripts/ubench/flat_reduce_cost.py).  The set of parameters that receive a gradient is fixed by the model (the
+    unused FPN levels never do) and is taken from the first step."""
+
+    def __init__(self, model, world):
+        self.model, self.world = model, world
+        self.params = self.flat = self.views = None
+        self.avg = dist.get_backend() == "nccl"  # gloo has no AVG
+        # every rank starts from rank 0's parameters and buffers (DDP's constructor does the same)
+        tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+        with torch.no_grad():
+            try:
+                dist._broadcast_coalesced(dist.group.WORLD, tensors, 256 * 1024 * 1024, 0)
+            except (AttributeError, RuntimeError):
+                for t in tensors:
+                    dist.broadcast(t, 0)
+
+    @torch.no_grad()
+    def reduce(self):
+        if self.params is None:
+            self.params = [p for p in self.model.parameters() if p.grad is not None]
+            total = sum(p.numel() for p in self.params)
+            self.flat = torch.empty(total, dtype=self.params[0].dtype, device=self.params[0].device)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        torch._foreach_copy_(self.views, [p.grad for p in self.params])  # multi-tensor pack into the flat buffer
+        if self.avg:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self.flat)
+            self.flat.div_(self.world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
 class Trainer:
     def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
@@ -113,26 +161,29 @@ class Trainer:
         self.wrapped = self.model
         self._steps = 0
         self._manual_gc = (self.model.device.type == "cuda" and os.environ.get("EFG_MANUAL_GC", "1") != "0")
+        self.grad_sync = None
         if use_ddp:
-            dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
-            # The reference asks for find_unused_parameters=True ($CQ/config.yaml:183) because the unused FPN levels
-            # never get a gradient.  With locally unused parameters DDP then makes a BLOCKING D2H copy of its "used"
-            # bitmap at the end of every backward, which drains the GPU queue: 55.5 ms/step instead of 40.5
-            # (scripts/ubench/ddp_modes.py, 1 rank).  The set of used parameters is the same every step, so
-            # static_graph=True gives the same result without the per-step search and copy (42.1 ms; 41.4 with
-            # the gradients living in the bucket memory).  EFG_DDP_MODE=find_unused restores the literal setting.
-            mode = os.environ.get("EFG_DDP_MODE", "static" if cfg.ddp.find_unused_parameters else "plain")
-            kw = {}
-            if mode == "find_unused":
-                kw["find_unused_parameters"] = True
-            elif mode == "static":
-                kw["static_graph"] = True
-            elif mode != "plain":
-                raise ValueError("EFG_DDP_MODE must be static, find_unused or plain, got %r" % mode)
-            self.wrapped = torch.nn.parallel.DistributedDataParallel(
-                self.model, device_ids=dev_ids, broadcast_buffers=False,
-                bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),
-                gradient_as_bucket_view=os.environ.get("EFG_DDP_BUCKET_VIEW", "1") == "1", **kw)
+            # "flat" (default): one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
+            # "static" / "find_unused" / "plain": torch DistributedDataParallel as in the reference, with
+            # static_graph=True / find_unused_parameters=True ($CQ/config.yaml:183) / neither.  The literal
+            # find_unused_parameters setting costs +14 ms/step: with locally unused parameters (the skipped FPN
+            # levels) DDP makes a BLOCKING D2H copy of its "used" bitmap at the end of every backward.
+            mode = os.environ.get("EFG_DDP_MODE", "flat")
+            if mode == "flat":
+                self.grad_sync = FlatGradientAllReduce(self.model, world)
+            else:
+                kw = {}
+                if mode == "find_unused":
+                    kw["find_unused_parameters"] = True
+                elif mode == "static":
+                    kw["static_graph"] = True
+                elif mode != "plain":
+                    raise ValueError("EFG_DDP_MODE must be flat, static, find_unused or plain, got %r" % mode)
+                dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
+                self.wrapped = torch.nn.parallel.DistributedDataParallel(
+                    self.model, device_ids=dev_ids, broadcast_buffers=False,
+                    bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),
+                    gradient_as_bucket_view=os.environ.get("EFG_DDP_BUCKET_VIEW", "1") == "1", **kw)
 
     def _collect_garbage(self):
         """Python's cyclic collector runs a few hundred times per step on the containers autograd creates and
@@ -157,6 +208,8 @@ class Trainer:
             losses = torch.stack([v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad]).sum()
         with record_function("efg::backward"):
             losses.backward()
+            if self.grad_sync is not None:
+                self.grad_sync.reduce()
         with record_function("efg::optimizer"):
             self.optimizer.step()
         return loss_dict, losses

@@ -3,7 +3,13 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from efg_amd.engine import Trainer, synthetic_batch
 dev = torch.device('cuda:0')
-tr = Trainer(device=dev, seed=0)
+import os
+DDP = os.environ.get('JITTER_DDP', '0') == '1'
+if DDP:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29517')
+    torch.cuda.set_device(0); dist.init_process_group('nccl', rank=0, world_size=1)
+tr = Trainer(device=dev, seed=0, ddp=DDP)
 pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
 for s in range(4): tr.step(pool[s % 2])
 torch.cuda.synchronize()
@@ -40,3 +46,8 @@ for s, r in enumerate(rows):
     flag = " <--" if gpu > 47 or sum(r) * 1e3 > 47 else ""
     w = per_step_waits[s]
     print("step %2d cpu fwd %.1f bwd %.1f opt %.1f = %.1f ms | gpu interval %.1f ms%s | item() waits: %s" % (s, r[0] * 1e3, r[1] * 1e3, r[2] * 1e3, sum(r) * 1e3, gpu, flag, " ".join("%.1f" % (x * 1e3) for x in w)))
+
+import statistics
+print("median cpu fwd %.1f bwd %.1f opt %.1f | gpu interval %.1f ms (ddp=%s)" % (
+    statistics.median(r[0] for r in rows) * 1e3, statistics.median(r[1] for r in rows) * 1e3,
+    statistics.median(r[2] for r in rows) * 1e3, statistics.median(ev[s].elapsed_time(ev[s + 1]) for s in range(40)), DDP))

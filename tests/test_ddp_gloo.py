@@ -19,7 +19,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
+    os.environ["EFG_DDP_MODE"] = mode
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     import oracle  # noqa: F401
@@ -32,9 +33,9 @@ def _worker(rank, world, port, out):
     ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
     tr = Trainer(device="cpu", overrides=ov, seed=0, ddp=True)
     tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
-    # three steps: the Trainer wraps the model with static_graph=True, whose steady state starts at step 2
+    # three steps: the flat buffer is laid out in step 1; DDP's static_graph steady state starts at step 2
     with cpu_backend.install():
-        for it in range(3):
+        for it in range(3 if mode == "flat" else 2):
             batch = synthetic_batch(500 + 10 * it + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
             loss_dict, total = tr.step(batch)
     w = tr.model.backbone.extractor.bottom_up.stem.conv1[0].weight
@@ -49,16 +50,17 @@ def _worker(rank, world, port, out):
         out["params_equal"] = bool(torch.equal(pw[0], pw[1]))                  # same update on every rank, every parameter
         out["finite"] = bool(torch.isfinite(total))
         out["grad_norm"] = float(g.norm())
-        out["static_graph"] = bool(getattr(tr.wrapped, "static_graph", False))
+        out["mode"] = "flat" if tr.grad_sync is not None else ("static" if getattr(tr.wrapped, "static_graph", False) else "other")
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_ddp_step(oracle_mod):
+@pytest.mark.parametrize("mode", ["flat", "static"])
+def test_two_rank_ddp_step(oracle_mod, mode):
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
         res = dict(out)
     assert res["finite"] and res["grads_equal"] and res["params_equal"] and res["grad_norm"] > 0
-    assert res["static_graph"]
+    assert res["mode"] == mode
