@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 A step = voxelize (GPU) -> sparse-conv backbone -> BEV/FPN -> box-attention DETR enc/dec -> losses ->
-backward -> (DDP all-reduce over RCCL) -> AdamW, on `--scenes` synthetic Waymo-shaped scenes per GPU
+backward -> (gradient all-reduce over RCCL) -> AdamW, on `--scenes` synthetic Waymo-shaped scenes per GPU
 that are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 """
 import argparse

@@ -1,8 +1,8 @@
-"""Minimal training engine for the hot path: model + AdamWMulti + (optionally) DDP over RCCL.
+"""Minimal training engine for the hot path: model + AdamWMulti + (for N > 1) a gradient all-reduce over RCCL.
 
 Counterpart of the slice of efg/engine/trainer.py:168-199,278-305 and efg/engine/hooks.py:68-81 that
 surrounds the path: `step()` = zero_grad -> loss_dict = model(batch) -> sum of differentiable losses
--> backward (DDP all-reduces gradient buckets over xGMI while backward runs) -> optimizer.step().
+-> backward -> one all-reduce of the gradients over xGMI (FlatGradientAllReduce) -> optimizer.step().
 One process per GPU; scenes are sharded across ranks, no activation exchange."""
 import gc
 import os
