@@ -428,16 +428,133 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// grad_w[co][k][ci] = sum_s partial[s][k][co][ci]
+// ---- wgrad for the low-channel layers (cin <= 16, cout <= 32: the stem, 5 -> 16 -> 16 -> 32) -------------------
+// The 64 x 64 block kernel above spends most of its MFMA tile on padding there and launches kvol workgroups per row
+// chunk that each compact and re-read the same rows: 226 us for 0.9 GFLOP on the 117 697-site input level.  These
+// layers are not arithmetic at all (a few GFLOP against ~35 MB of rows and table), so: one workgroup = one row chunk
+// x a group of <= 4 kernel offsets; the wave walks its 256 rows four at a time, loads the grad_out fragment of the
+// four rows ONCE and feeds it to one 16x16x4 MFMA per (offset, 16 output channels) with the gathered input row as the
+// other operand -- no compaction, rows without a neighbour contribute a zero operand.  dW[k] lives in registers
+// (<= 4 offsets x 2 tiles x 4); the four waves are summed through LDS in a fixed order and written as one partial
+// block per row chunk, which the same wgrad_reduce_kernel folds.
+
+template <int T, int KJ>  // T = 16-channel tiles of cout, KJ = offsets per group (compile-time bound of the loops)
+__global__ void __launch_bounds__(256) conv_wgrad_small_kernel(WgradArgs a) {
+  __shared__ float red[3][KJ * T * 4 * 64];  // waves 1..3 park their accumulators here
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;  // A: ci = m of row kk;  B: co = 16 t + m of row kk
+  const int g = blockIdx.y, kg = gridDim.y;  // offset group: k = g, g + kg, g + 2 kg, ...
+  const long long chunk_lo = (long long)blockIdx.x * a.rows_per_split;
+  const long long chunk_hi = min(chunk_lo + a.rows_per_split, a.m_out);
+  const int nk = (a.kvol - g + kg - 1) / kg;  // offsets of this group (<= KJ)
+  f32x4 acc[KJ][T];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool ci_ok = m < a.cin;
+  const int ci = ci_ok ? m : 0;
+  // rows of this wave: steps of 4 rows, the 4 waves interleaved; kU steps are loaded together (table entries first,
+  // then the rows they point to, then the MFMAs) so that each wave keeps kU * (KJ + T) independent loads in flight --
+  // with two waves per SIMD the memory latency is all there is to hide
+  constexpr int kU = 4;
+  for (long long r = chunk_lo + wv * 4; r < chunk_hi; r += 16 * kU) {
+    bool row_ok[kU];
+    long long rr[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long row = r + 16 * u + kk;
+      row_ok[u] = row < chunk_hi;
+      rr[u] = row_ok[u] ? row : chunk_lo;
+    }
+    int idx[kU][KJ];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) idx[u][j] = (j < nk) ? a.nbr[(long long)(g + kg * j) * a.m_out + rr[u]] : -1;
+    float bfrag[kU][T];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int co = 16 * t + m;
+        const float v = a.go[rr[u] * a.cout + (co < a.cout ? co : 0)];
+        bfrag[u][t] = (row_ok[u] && co < a.cout) ? v : 0.f;
+      }
+    float afrag[kU][KJ];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) afrag[u][j] = a.in[(long long)max(idx[u][j], 0) * a.cin + ci];
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int j = 0; j < KJ; ++j) {
+        const float av = (idx[u][j] >= 0 && row_ok[u] && ci_ok) ? afrag[u][j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bfrag[u][t], acc[j][t], 0, 0, 0);
+      }
+  }
+  // waves 1..3 -> LDS, wave 0 sums in wave order and writes partial[split][k][co][ci]
+  if (wv > 0) {
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wv - 1][((j * T + t) * 4 + q) * 64 + lane] = acc[j][t][q];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    // D layout of 16x16x4: lane holds C[row = 4 * (lane >> 4) + q][col = lane & 15] = dW[ci = 4 kk + q][co = 16 t + m]
+    float* out = a.partial + (long long)blockIdx.x * a.kvol * a.cout * a.cin;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      if (j >= nk) break;
+      const int k = g + kg * j;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int co = 16 * t + m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cix = 4 * kk + q;
+          float v = acc[j][t][q];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) v += red[w][((j * T + t) * 4 + q) * 64 + lane];
+          if (co < a.cout && cix < a.cin) out[((long long)k * a.cout + co) * a.cin + cix] = v;
+        }
+      }
+    }
+  }
+}
+
+// grad_w[co][k][ci] = sum_s partial[s][k][co][ci].  64 elements per workgroup (coalesced), the 4 waves take every
+// fourth split with 4 loads in flight each, then a fixed-order sum through LDS: with ~120 splits on the low-channel
+// layers a one-thread-per-element loop over the splits was a chain of 120 dependent-latency loads (40-60 us).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int kvol,
                                                             int cout, int cin, float* __restrict__ gw) {
+  __shared__ float sm[4][64];
   const long long per = (long long)kvol * cout * cin;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per;
-       e += (long long)gridDim.x * blockDim.x) {
-    float s = 0.0f;
-    for (int sp = 0; sp < splits; ++sp) s += partial[sp * per + e];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < per) {
+    int sp = wv;
+    for (; sp + 12 < splits; sp += 16) {
+      s0 += partial[(long long)sp * per + e];
+      s1 += partial[(long long)(sp + 4) * per + e];
+      s2 += partial[(long long)(sp + 8) * per + e];
+      s3 += partial[(long long)(sp + 12) * per + e];
+    }
+    for (; sp < splits; sp += 4) s0 += partial[(long long)sp * per + e];
+  }
+  sm[wv][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wv == 0 && e < per) {
+    const float s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     const int ci = (int)(e % cin);
-    long long q = e / cin;
+    const long long q = e / cin;
     const int co = (int)(q % cout);
     const int k = (int)(q / cout);
     gw[((long long)co * kvol + k) * cin + ci] = s;
@@ -598,11 +715,22 @@ extern "C" int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin,
   a.kvol = kvol;
   a.rows_per_split = p.rows_per_split;
   a.nci_blk = p.nci_blk;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.splits, p.nco_blk * p.nci_blk, kvol), dim3(256), 0, stream, a);
+  static const bool small_env = !(getenv("EFG_WGRAD_SMALL") && atoi(getenv("EFG_WGRAD_SMALL")) == 0);
+  if (small_env && cin <= 16 && cout <= 32 && m_in == m_out) {
+    // low-channel submanifold layers (dense tables: ~15 of 27 offsets per row; the strided stem conv has 4 of 27 and
+    // keeps the compacting kernel): one workgroup per (row chunk, group of <= 4 offsets), see conv_wgrad_small_kernel
+    const dim3 grid(p.splits, (unsigned)ceil_div(kvol, 4));
+    if (cout <= 16)
+      hipLaunchKernelGGL((conv_wgrad_small_kernel<1, 4>), grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_small_kernel<2, 4>), grid, dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.splits, p.nco_blk * p.nci_blk, kvol), dim3(256), 0, stream, a);
+  }
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>(ceil_div(per, 256), 4096)), dim3(256), 0,
-                     stream, a.partial, p.splits, kvol, cout, cin, grad_w);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(per, 64)), dim3(256), 0, stream, a.partial, p.splits,
+                     kvol, cout, cin, grad_w);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
