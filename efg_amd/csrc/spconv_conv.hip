@@ -626,13 +626,18 @@ int run_conv(const float* in, int64_t m_in, int cin, const float* wp, const floa
   // long serial MFMA chain per wave on a third of the CUs.  Wider outputs tile over grid.y.
   const long long row_waves = ceil_div(m_out, 16);
   int nt = 16;
-  while (nt > 1 && (nt / 2 >= ntiles || row_waves * ((ntiles + nt - 1) / nt) < 2048)) nt >>= 1;
+  // With the kernel offsets split over the 4 waves of a workgroup (KS, below) a row tile already is 4 waves, so the
+  // 3x3x3 layers fill the chip with fewer tiles: 1400 instead of 2048 lets the 256-channel layers (371 row tiles) take
+  // 4 n-tiles per wave instead of 2 -- half the gathers per MFMA: 205 -> 170 us, 60 -> 72 TFLOP/s (EFG_CONV_FILL).
+  static const long long fill_env = getenv("EFG_CONV_FILL") ? atoll(getenv("EFG_CONV_FILL")) : 0;
+  static const int ks_env = getenv("EFG_CONV_KS") ? atoi(getenv("EFG_CONV_KS")) : 4;
+  const long long fill = fill_env > 0 ? fill_env : ((kvol >= 8 && ks_env > 1) ? 1400 : 2048);
+  while (nt > 1 && (nt / 2 >= ntiles || row_waves * ((ntiles + nt - 1) / nt) < fill)) nt >>= 1;
   if (nt > ntiles) nt = ntiles >= 16 ? 16 : ntiles >= 8 ? 8 : ntiles >= 4 ? 4 : ntiles >= 2 ? 2 : 1;
   while (nt < ntiles && nt < 16 && (ntiles % nt) != 0) nt <<= 1;  // keep grid.y exact where possible
   const int ny = (ntiles + nt - 1) / nt;
   // split-K over the 4 waves of a workgroup for the 3x3x3 kernels with 2-4 n-tiles per wave (measured -10 %);
   // 16-channel outputs (NT = 1) and the 3-offset z-collapsing heads gain nothing.  EFG_CONV_KS overrides (1 | 2 | 4).
-  static const int ks_env = getenv("EFG_CONV_KS") ? atoi(getenv("EFG_CONV_KS")) : 4;
   const int ks = (kvol >= 8) ? ks_env : 1;
   switch (nt) {
     case 16: launch_fwd<16>(a, ny, 1, stream); break;

@@ -12,6 +12,7 @@ every output site touched by an input site and returns rows in canonical order (
 row-aligned (required by `out.features + shortcut.features`, sparse_net.py:162).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -79,7 +80,7 @@ def _conv_forward(features, w, bias, rb):
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-    with _prof.timed(_fwd_kernel_name(cout, rb.m_out), _Cost(rb, cin, cout, "fwd")):
+    with _prof.timed(_fwd_kernel_name(cout, rb.m_out, kvol), _Cost(rb, cin, cout, "fwd")):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
                                            L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
     return out
@@ -93,7 +94,7 @@ def _conv_dgrad(grad_out, w, rb):
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     rnbr = rb.rnbr
-    with _prof.timed(_fwd_kernel_name(cin, rb.m_in), _Cost(rb, cin, cout, "dgrad")):
+    with _prof.timed(_fwd_kernel_name(cin, rb.m_in, kvol), _Cost(rb, cin, cout, "dgrad")):
         L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
                                          rb.m_in, L.ptr(grad_in), L.stream()))
     return grad_in
@@ -111,12 +112,13 @@ def _conv_wgrad(features, grad_out, rb):
     return grad_w
 
 
-def _fwd_kernel_name(n_out_channels, n_rows):
+def _fwd_kernel_name(n_out_channels, n_rows, kvol=27):
     """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks (same rule)."""
     ntiles = (n_out_channels + 15) // 16
     row_waves = (n_rows + 15) // 16
+    fill = int(os.environ.get("EFG_CONV_FILL", "0")) or (1400 if kvol >= 8 and os.environ.get("EFG_CONV_KS", "4") != "1" else 2048)
     nt = 16
-    while nt > 1 and (nt // 2 >= ntiles or row_waves * ((ntiles + nt - 1) // nt) < 2048):
+    while nt > 1 and (nt // 2 >= ntiles or row_waves * ((ntiles + nt - 1) // nt) < fill):
         nt >>= 1
     if nt > ntiles:
         nt = 16 if ntiles >= 16 else 8 if ntiles >= 8 else 4 if ntiles >= 4 else 2 if ntiles >= 2 else 1
