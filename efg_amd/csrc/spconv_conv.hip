@@ -68,6 +68,7 @@ struct ConvArgs {
   const float* bias;   // [cout] or null
   const int* nbr;      // [kvol][m_out]
   float* out;          // [m_out][cout]
+  const int* order;    // null, or a permutation of the m_out rows: tile t computes rows order[16 t .. 16 t + 15]
   long long m_out;
   int cin, cout, kvol;
   int c16n;            // round16(cin)/16
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   __shared__ float a_tile[4][16 * kAStride];
   __shared__ int nbr_tile[4 / KS][KV * 16];  // one rulebook block per row tile (shared by its KS waves)
   __shared__ unsigned vmask_tile[4 / KS][KV];  // per offset: which of the 16 tile rows have a neighbour
+  __shared__ int prow_tile[4 / KS][16];        // the tile's rows when a row order is given (else r0 + j)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   constexpr int TILES = 4 / KS;          // row tiles per workgroup
   const int tile = wv / KS, part = wv % KS;
@@ -110,9 +112,22 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
   const int n_tile0 = by * NT;  // first n-tile of this block
 
   // stage the wave's rulebook block and find the active offsets
-  for (int e = lane + 64 * part; e < a.kvol * 16; e += 64 * KS) {
-    const int k = e >> 4, j = e & 15;
-    nb[e] = (r0 + j < a.m_out) ? a.nbr[(long long)k * a.m_out + r0 + j] : -1;
+  int* prow = prow_tile[wv / KS];
+  if (a.order) {  // (uniform) rows of this tile through the caller's order: e.g. grouped by coordinate parity, so that
+                  // the rows of a tile of a strided layer's dgrad need the same few offsets
+    if (part == 0 && lane < 16) prow[lane] = (r0 + lane < a.m_out) ? a.order[r0 + lane] : -1;
+    if (KS > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int e = lane + 64 * part; e < a.kvol * 16; e += 64 * KS) {
+      const int k = e >> 4, j = e & 15;
+      const int pr = prow[j];
+      nb[e] = (pr >= 0) ? a.nbr[(long long)k * a.m_out + pr] : -1;
+    }
+  } else {
+    for (int e = lane + 64 * part; e < a.kvol * 16; e += 64 * KS) {
+      const int k = e >> 4, j = e & 15;
+      nb[e] = (r0 + j < a.m_out) ? a.nbr[(long long)k * a.m_out + r0 + j] : -1;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -258,8 +273,9 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs a) {
     if (co < a.cout) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long long row = r0 + (lane >> 4) * 4 + r;
-        if (row < a.m_out) a.out[row * a.cout + co] = acc[t][r];
+        const int j = (lane >> 4) * 4 + r;
+        const long long row = a.order ? (long long)prow[j] : ((r0 + j < a.m_out) ? r0 + j : -1);
+        if (row >= 0) a.out[row * a.cout + co] = acc[t][r];
       }
     }
   }
@@ -602,7 +618,7 @@ void launch_fwd(const ConvArgs& a, int nblk_y, int ks, hipStream_t stream) {
 }
 
 int run_conv(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
-             const int* nbr, int64_t m_out, float* out, hipStream_t stream) {
+             const int* nbr, int64_t m_out, float* out, hipStream_t stream, const int* order = nullptr) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv: bad channel counts");
   EFG_CHECK_ARG(kvol >= 1 && kvol <= kMaxKvol, "spconv: kernel volume must be in [1,%d], got %d", kMaxKvol, kvol);
   if (m_out == 0) return EFG_OK;
@@ -614,6 +630,7 @@ int run_conv(const float* in, int64_t m_in, int cin, const float* wp, const floa
   a.bias = bias;
   a.nbr = nbr;
   a.out = out;
+  a.order = order;
   a.m_out = m_out;
   a.cin = cin;
   a.cout = cout;
@@ -682,9 +699,80 @@ extern "C" int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int ci
 }
 
 extern "C" int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight,
-                                    int cin, int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in,
-                                    void* stream) {
-  return run_conv(grad_out, m_out, cout, packed_weight, nullptr, cin, kvol, rnbr, m_in, grad_in, (hipStream_t)stream);
+                                    int cin, int kvol, const int32_t* rnbr, int64_t m_in, const int32_t* row_order,
+                                    float* grad_in, void* stream) {
+  return run_conv(grad_out, m_out, cout, packed_weight, nullptr, cin, kvol, rnbr, m_in, grad_in, (hipStream_t)stream,
+                  row_order);
+}
+
+// ---- row order by coordinate parity ---------------------------------------------------------------------------
+// The dgrad of a stride-2 convolution computes one row per FINE site, and which of the 27 offsets reach a parent
+// depends only on the parity of the site's (z, y, x): 8 classes with ~3.4 offsets each.  Neighbouring rows of the
+// canonical order differ in parity, so a 16-row tile runs ~10 offsets (scripts/ubench/tile_waste.py: x2.9).  This
+// orders the rows by class (within a class in the order the waves arrive, i.e. roughly spatially); results do not
+// depend on the order -- a row's sum runs over its own offsets in ascending k whatever its tile mates are.
+namespace efg {
+namespace {
+__device__ __forceinline__ int parity_class(const int* __restrict__ idx, long long r) {
+  const int4 v = *reinterpret_cast<const int4*>(idx + r * 4);  // (b, z, y, x)
+  return ((v.y & 1) << 2) | ((v.z & 1) << 1) | (v.w & 1);
+}
+
+__global__ void __launch_bounds__(256) parity_count_kernel(const int* __restrict__ idx, long long m, int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const long long nwave_rows = ((m + 63) / 64) * 64;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nwave_rows; r += (long long)gridDim.x * 256) {
+    const int c = r < m ? parity_class(idx, r) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long bal = __ballot(c == k);
+      if (lane == 0 && bal) atomicAdd(&counts[k], __popcll(bal));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) parity_scatter_kernel(const int* __restrict__ idx, long long m, const int* __restrict__ counts,
+                                                              int* __restrict__ cursor, int* __restrict__ order) {
+  const int lane = threadIdx.x & 63;
+  int base[8];
+  int acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    base[k] = acc;
+    acc += counts[k];
+  }
+  const long long nwave_rows = ((m + 63) / 64) * 64;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nwave_rows; r += (long long)gridDim.x * 256) {
+    const int c = r < m ? parity_class(idx, r) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long bal = __ballot(c == k);
+      if (bal) {
+        int start = 0;
+        if (lane == 0) start = atomicAdd(&cursor[k], __popcll(bal));
+        start = __shfl(start, 0, 64);
+        if (c == k) order[base[k] + start + __popcll(bal & ((1ull << lane) - 1ull))] = (int)r;
+      }
+    }
+  }
+}
+}  // namespace
+}  // namespace efg
+
+extern "C" int efg_spconv_parity_order(const int32_t* indices, int64_t m, int32_t* order, void* ws, size_t ws_bytes,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(m >= 0 && m < (1ll << 31), "parity_order: bad row count");
+  if (m == 0) return EFG_OK;
+  EFG_CHECK_ARG(indices && order && ws && ws_bytes >= 64, "parity_order: null pointer / workspace < 64 bytes");
+  int* counts = static_cast<int*>(ws);
+  EFG_HIP_TRY(hipMemsetAsync(counts, 0, 64, stream));
+  const int blocks = (int)std::min<int64_t>(ceil_div(m, 256), 2048);
+  hipLaunchKernelGGL(parity_count_kernel, dim3(blocks), dim3(256), 0, stream, indices, (long long)m, counts);
+  hipLaunchKernelGGL(parity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, indices, (long long)m, counts, counts + 8,
+                     order);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
 }
 
 extern "C" size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol) {

@@ -94,9 +94,10 @@ def _conv_dgrad(grad_out, w, rb):
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     rnbr = rb.rnbr
+    order = rb.dgrad_order()
     with _prof.timed(_fwd_kernel_name(cin, rb.m_in, kvol), _Cost(rb, cin, cout, "dgrad")):
         L.check(lib.efg_spconv_dgrad_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), cin, kvol, L.ptr(rnbr),
-                                         rb.m_in, L.ptr(grad_in), L.stream()))
+                                         rb.m_in, L.ptr(order), L.ptr(grad_in), L.stream()))
     return grad_in
 
 
@@ -239,11 +240,27 @@ def _hand_over(main, *tensors):
 class Rulebook:
     """Output-stationary neighbour table of one convolution geometry."""
 
-    def __init__(self, nbr, m_in, m_out, kvol, subm):
+    def __init__(self, nbr, m_in, m_out, kvol, subm, in_indices=None):
         self.nbr = nbr          # int32 [kvol, m_out]
         self.m_in, self.m_out, self.kvol, self.subm = m_in, m_out, kvol, subm
+        self.in_indices = in_indices  # int32 [m_in, 4] of a strided geometry (for the dgrad row order)
         self._rnbr = None
         self._pairs = None
+        self._order = None
+
+    def dgrad_order(self):
+        """int32 [m_in] row order for the dgrad of a strided geometry: input rows grouped by coordinate parity, so the
+        16 rows of a tile share their reachable offsets (csrc/spconv_conv.hip: efg_spconv_parity_order); None for
+        submanifold geometries (every row reaches every offset) or with EFG_DGRAD_ORDER=0."""
+        if self.subm or self.in_indices is None or self.m_in == 0 or os.environ.get("EFG_DGRAD_ORDER", "1") == "0":
+            return None
+        if self._order is None:
+            idx = self.in_indices
+            order = torch.empty(self.m_in, dtype=torch.int32, device=idx.device)
+            ws = torch.empty(64, dtype=torch.uint8, device=idx.device)
+            L.check(L.lib().efg_spconv_parity_order(L.ptr(idx), self.m_in, L.ptr(order), L.ptr(ws), 64, L.stream()))
+            self._order = order
+        return self._order
 
     @property
     def rnbr(self):
@@ -515,7 +532,7 @@ class SparseConvolution(SparseModule):
             m_out = out_indices.shape[0]
             nbr = _build_nbr(si, out_indices, m_out, ks, st, pad)
             _hand_over(main, nbr, out_indices, out_site_index.index, si.index, si.perm)
-        rb = Rulebook(nbr, x.indices.shape[0], m_out, nbr.shape[0], False)
+        rb = Rulebook(nbr, x.indices.shape[0], m_out, nbr.shape[0], False, in_indices=x.indices)
         geom = (out_indices, out_site_index, oshape_py)
         x._conv_cache[key] = (rb, geom)
         return rb, geom

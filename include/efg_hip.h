@@ -142,9 +142,16 @@ int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin,
 int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                            const float* bias, int cout, int kvol, const int32_t* nbr, int64_t m_out,
                            float* out_feat, void* stream);
-/* grad_in[i][:] = sum_k W[:,k,:]^T . grad_out[rnbr[k][i]][:]   (packed: for_dgrad = 1) */
+/* grad_in[i][:] = sum_k W[:,k,:]^T . grad_out[rnbr[k][i]][:]   (packed: for_dgrad = 1).
+ * row_order: NULL, or a permutation of the m_in rows (efg_spconv_parity_order): workgroup tiles take their 16 rows
+ * in that order; the result does not depend on it. */
 int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight, int cin,
-                         int kvol, const int32_t* rnbr, int64_t m_in, float* grad_in, void* stream);
+                         int kvol, const int32_t* rnbr, int64_t m_in, const int32_t* row_order, float* grad_in,
+                         void* stream);
+/* order[m]: the rows of `indices` (int32 [m][4] = b, z, y, x) grouped by the parity of (z, y, x) -- the rows of a
+ * stride-2 layer's dgrad that share their set of reachable kernel offsets.  ws: 64 bytes. */
+int efg_spconv_parity_order(const int32_t* indices, int64_t m, int32_t* order, void* ws, size_t ws_bytes,
+                            void* stream);
 size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
 /* grad_w[cout][kvol][cin] = sum_o grad_out[o]^T (x) in[nbr[k][o]]  (deterministic two-pass) */
 int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
