@@ -188,9 +188,9 @@ class Trainer:
     def _collect_garbage(self):
         """Python's cyclic collector runs a few hundred times per step on the containers autograd creates and
         costs ~3 ms of host time per step (35.5 -> 32 ms, scripts/ubench/jitter.py); the step frees its graph by
-        reference counting.  After the first steps: freeze what exists, switch the automatic collector off and
-        collect by hand every 100 steps.  EFG_MANUAL_GC=0 leaves the interpreter alone."""
-        if self._steps == 3:
+        reference counting.  At the first step (always a warm-up step): freeze what exists, switch the automatic
+        collector off; afterwards collect by hand every 100 steps.  EFG_MANUAL_GC=0 leaves the interpreter alone."""
+        if self._steps == 1:
             gc.collect()
             gc.freeze()
             gc.disable()

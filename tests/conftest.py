@@ -21,7 +21,7 @@ def golden(name):
 
 @pytest.fixture(autouse=True)
 def _restore_gc():
-    """A Trainer that runs >= 3 steps on the GPU freezes and disables the cyclic collector (engine.py); give the
+    """A Trainer that runs a step on the GPU freezes and disables the cyclic collector (engine.py); give the
     next test the interpreter's default back."""
     import gc
 
