@@ -1,4 +1,9 @@
-"""VoxelDETR / ConQueR model ($CQ/voxel_detr.py:17-291), MI355X path.
+"""VoxelDETR / ConQueR model ($CQ/voxel_detr.py:17-291, $VD/voxel_detr.py:17-214), MI355X path.
+
+One class serves both experiments of playground/detection.3d/waymo/conquer: a config WITH `model.contrastive` /
+`model.dn` builds ConQueR (momentum GT decoder, denoising queries, contrastive query loss); a config WITHOUT them
+builds plain Voxel-DETR ($VD: no `decoder_gt`, `projector`, `predictor` parameters, 17 loss terms, top-300
+inference) -- configs/voxeldetr_waymo_res18.yaml.
 
 forward(batched_inputs) keeps the reference contract: a list of `(sample, {"annotations": ...})`
 pairs in, a dict of losses out (training) or per-scene detections (eval).  Differences, all on
@@ -96,22 +101,25 @@ class VoxelDETR(nn.Module):
                                        num_encoder_layers=tc.enc_layers, num_decoder_layers=tc.dec_layers,
                                        dim_feedforward=tc.dim_feedforward, dropout=tc.dropout,
                                        num_queries=tc.num_queries, num_classes=self.num_classes,
-                                       mom=config.model.contrastive.mom)
+                                       mom=config.model.contrastive.mom if "contrastive" in config.model else None)
         self.transformer.proposal_head = Det3DHead(config, with_aux=False, with_metrics=False, num_classes=1,
                                                    num_layers=1)
         self.transformer.decoder.detection_head = Det3DHead(config, with_aux=True, with_metrics=True,
                                                             num_classes=self.num_classes, num_layers=tc.dec_layers)
-        # momentum ("GT") decoder: a frozen copy updated by EMA every step (voxel_detr.py:86-89)
-        self.transformer.decoder_gt = copy.deepcopy(self.transformer.decoder)
-        for p in self.transformer.decoder_gt.parameters():
-            p.requires_grad = False
+        self.is_conquer = "contrastive" in config.model  # else: plain Voxel-DETR ($VD/voxel_detr.py)
+        if self.is_conquer:
+            # momentum ("GT") decoder: a frozen copy updated by EMA every step (voxel_detr.py:86-89)
+            self.transformer.decoder_gt = copy.deepcopy(self.transformer.decoder)
+            for p in self.transformer.decoder_gt.parameters():
+                p.requires_grad = False
         self.box_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range, device=self.device)
         self._host_coder = VoxelBoxCoder3D(config.dataset.voxel_size, config.dataset.pc_range)
-        cc = config.model.contrastive
-        self.eqco, self.tau, self.contras_loss_coeff = cc.eqco, cc.tau, cc.loss_coeff
-        self.projector = nn.Sequential(Linear(10, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
-        self.predictor = nn.Sequential(Linear(cc.dim, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
-        self.similarity_f = nn.CosineSimilarity(dim=2)
+        if self.is_conquer:
+            cc = config.model.contrastive
+            self.eqco, self.tau, self.contras_loss_coeff = cc.eqco, cc.tau, cc.loss_coeff
+            self.projector = nn.Sequential(Linear(10, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
+            self.predictor = nn.Sequential(Linear(cc.dim, cc.dim), nn.ReLU(), Linear(cc.dim, cc.dim))
+            self.similarity_f = nn.CosineSimilarity(dim=2)
         self.config = config
         vz = config.dataset.processors
         self._vox_cfg = {k: vz[k].Voxelization for k in vz if "Voxelization" in vz[k]} if isinstance(vz, dict) else {}
@@ -206,8 +214,8 @@ class VoxelDETR(nn.Module):
                 feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
             features = [self._project(self.input_proj[i], fp[0]) for i, fp in enumerate(feats_pos)]
         pos_encodings = [fp[1] for fp in feats_pos]
-        dn = self.config.model.dn
-        if self.training and dn.enabled and dn.dn_number > 0:
+        dn = self.config.model.dn if self.is_conquer else None
+        if self.training and dn is not None and dn.enabled and dn.dn_number > 0:
             with record_function("efg::cdn"):
                 # the denoising queries are a few hundred numbers derived from host annotations: build them on
                 # the host (CPU generator -> device-independent noise) and upload three small tensors
@@ -223,7 +231,8 @@ class VoxelDETR(nn.Module):
             input_query_bbox = input_query_label = attn_mask = dn_meta = None
         with record_function("efg::transformer"):
             hidden_state, init_reference, inter_references, src_embed, src_ref_windows, src_indexes = self.transformer(
-                features, pos_encodings, input_query_bbox, input_query_label, attn_mask, targets=targets)
+                features, pos_encodings, input_query_bbox, input_query_label, attn_mask,
+                targets=targets if self.is_conquer else None)
         head = self.transformer.decoder.detection_head
         outputs_classes, outputs_coords = [], []
         for idx in range(hidden_state.shape[0]):
@@ -232,7 +241,7 @@ class VoxelDETR(nn.Module):
             outputs_classes.append(oc)
             outputs_coords.append(ob)
         outputs_class, outputs_coord = torch.stack(outputs_classes), torch.stack(outputs_coords)
-        if dn.dn_number > 0 and dn_meta is not None:
+        if dn is not None and dn.dn_number > 0 and dn_meta is not None:
             outputs_class, outputs_coord = dn_post_process(outputs_class, outputs_coord, dn_meta, self.aux_loss,
                                                            self._set_aux_loss)
         if not self.training:
@@ -256,9 +265,10 @@ class VoxelDETR(nn.Module):
                    "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
         with record_function("efg::losses.decoder"):
             losses.update(head.compute_losses(outputs, targets, dn_meta))
-        with record_function("efg::losses.contrastive"):
-            losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
-                                                   targets, dn_meta))
+        if self.is_conquer:
+            with record_function("efg::losses.contrastive"):
+                losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
+                                                       targets, dn_meta))
         return losses
 
     def _contrastive_losses(self, outputs_class, outputs_coord, query_of_gt, targets, dn_meta):
@@ -304,11 +314,20 @@ class VoxelDETR(nn.Module):
         return out
 
     def _inference(self, outputs_class, outputs_coord):
-        """voxel_detr.py:257-284: keep every (query, class) with score >= 0.1 (batch 1)."""
+        """ConQueR ($CQ/voxel_detr.py:257-284): keep every (query, class) with score >= 0.1 (batch 1);
+        Voxel-DETR ($VD/voxel_detr.py:166-200): the 300 best (query, class) pairs per scene (unsorted top-k)."""
         out_logits = outputs_class[-1][:, : self.num_queries]
         out_bbox = outputs_coord[-1][:, : self.num_queries]
         out_prob = out_logits.sigmoid().view(out_logits.shape[0], -1)
         out_bbox = self.box_coder.decode(out_bbox.clone())
+        if not self.is_conquer:
+            ncls = out_logits.shape[2]
+            scores, keep = torch.topk(out_prob, min(300, out_prob.shape[1]), dim=1, sorted=False)
+            box_idx = keep.div(ncls, rounding_mode="floor")
+            labels = keep % ncls + 1
+            boxes = torch.gather(out_bbox, 1, box_idx.unsqueeze(-1).repeat(1, 1, out_bbox.shape[-1]))
+            return [{"scores": s.detach().cpu(), "labels": l.detach().cpu(), "boxes3d": b.detach().cpu()}
+                    for s, l, b in zip(scores, labels, boxes)]
         keep = torch.nonzero(out_prob >= 0.1, as_tuple=True)[1]
         scores = out_prob[:, keep]
         ncls = out_logits.shape[2]
