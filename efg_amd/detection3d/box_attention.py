@@ -1,97 +1,87 @@
-"""Box3dAttention: the DETR encoder/decoder sampling attention ($CQ/modules/box_attention.py:10-115).
+"""Box3dAttention: the sampling attention of the Voxel-DETR encoder (axis-aligned windows) and decoder (rotated
+boxes).  Drop-in for $CQ/modules/box_attention.py:10-115: same parameter names and shapes (`linear_box_weight/bias`,
+`linear_attn_weight/bias`, `value_proj.*`, `out_proj.*`), the `kernel_indices` buffer, the same initial values and the
+same forward contract `(query, value, v_shape, v_mask, v_start_index, v_valid_ratios, ref_windows) -> (out, weights)`.
 
-Parameters (`linear_box_weight/bias`, `linear_attn_weight/bias`, `value_proj`, `out_proj`), the
-`kernel_indices` buffer, init and forward contract are the reference's; the sampling core is
-`BoxAttnFunction` -> csrc/msda.hip.  Dense projections stay on hipBLASLt.
+MI355X structure: a query contributes three small Linears (value is projected once per call); everything between
+them and the output projection -- box geometry, softmax over the L * k * k logits, bilinear sampling -- is ONE HIP
+kernel (csrc/box_fused.hip) that never writes the [B, Lq, H, L, k*k, 2] grid or the softmaxed weights to HBM.  When
+that kernel does not apply (head width != 32, per-level valid ratios, a gradient requested for the windows) the same
+quantities are materialised with `box_sampling_grid` and handed to the plain sampling op (`BoxAttnFunction`,
+csrc/msda.hip), which is what the reference module does on every call.
 """
-import math
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..operators import BoxAttnFunction
-from ..operators.linear import Linear, linear
 from ..operators import box_attention_func as _baf
+from ..operators.linear import Linear, linear
+
+
+def _lattice(k):
+    """k x k sampling lattice as (x, y) pairs, y-major, spanning (-0.5, 0.5) exclusive: {(j, i) - (k-1)/2} / k."""
+    axis = (torch.arange(k, dtype=torch.float32) - (k - 1) / 2) / k
+    return torch.stack((axis.repeat(k), axis.repeat_interleave(k)), dim=-1)
 
 
 class Box3dAttention(nn.Module):
     def __init__(self, d_model, num_level, num_head, with_rotation=True, kernel_size=5):
         super().__init__()
-        assert d_model % num_head == 0, "d_model should be divided by num_head"
-        num_variable = 5 if with_rotation else 4
-        self.im2col_step = 64
+        if d_model % num_head:
+            raise ValueError("d_model (%d) must be a multiple of num_head (%d)" % (d_model, num_head))
         self.d_model, self.num_head, self.num_level = d_model, num_head, num_level
         self.head_dim = d_model // num_head
-        self.with_rotation, self.num_variable = with_rotation, num_variable
-        self.kernel_size, self.num_point = kernel_size, kernel_size ** 2
-        self.linear_box_weight = nn.Parameter(torch.zeros(num_level * num_head * num_variable, d_model))
-        self.linear_box_bias = nn.Parameter(torch.zeros(num_head * num_level * num_variable))
-        self.linear_attn_weight = nn.Parameter(torch.zeros(num_head * num_level * self.num_point, d_model))
-        self.linear_attn_bias = nn.Parameter(torch.zeros(num_head * num_level * self.num_point))
+        self.with_rotation = with_rotation
+        self.num_variable = 5 if with_rotation else 4          # dx, dy, dl, dw (, dangle) per head and level
+        self.kernel_size, self.num_point = kernel_size, kernel_size * kernel_size
+        self.im2col_step = 64
+        per_query = num_head * num_level
+        self.linear_box_weight = nn.Parameter(torch.empty(per_query * self.num_variable, d_model))
+        self.linear_box_bias = nn.Parameter(torch.empty(per_query * self.num_variable))
+        self.linear_attn_weight = nn.Parameter(torch.empty(per_query * self.num_point, d_model))
+        self.linear_attn_bias = nn.Parameter(torch.empty(per_query * self.num_point))
         self.value_proj = Linear(d_model, d_model)
         self.out_proj = Linear(d_model, d_model)
-        # k x k lattice in [-0.4, 0.4]^2 (odd k) as (x, y) pairs, :39-50
-        if kernel_size % 2 == 0:
-            indices = torch.linspace(-kernel_size // 2 + 0.5, kernel_size // 2 - 0.5, kernel_size)
-        else:
-            indices = torch.linspace(-(kernel_size - 1) // 2, (kernel_size - 1) // 2, kernel_size)
-        i, j = torch.meshgrid(indices, indices, indexing="ij")
-        self.register_buffer("kernel_indices", torch.stack([j, i], dim=-1).view(-1, 2) / kernel_size)
-        self._reset_parameters()
+        self.register_buffer("kernel_indices", _lattice(kernel_size))
+        self.reset_parameters()
 
-    def _reset_parameters(self):
-        nn.init.xavier_uniform_(self.out_proj.weight)
-        nn.init.constant_(self.out_proj.bias, 0.0)
-        nn.init.xavier_uniform_(self.value_proj.weight)
-        nn.init.constant_(self.value_proj.bias, 0.0)
-        nn.init.constant_(self.linear_attn_weight, 0.0)
-        nn.init.constant_(self.linear_attn_bias, 0.0)
-        nn.init.constant_(self.linear_box_weight, 0.0)
-        nn.init.uniform_(self.linear_box_bias)
+    def reset_parameters(self):
+        """Start as a plain average over a window of the reference size: zero box / attention weights, box bias
+        U(0, 1) (reference :52-60), Xavier projections."""
+        with torch.no_grad():
+            for p in (self.linear_box_weight, self.linear_attn_weight, self.linear_attn_bias):
+                p.zero_()
+            self.linear_box_bias.uniform_()
+            for proj in (self.value_proj, self.out_proj):
+                nn.init.xavier_uniform_(proj.weight)
+                proj.bias.zero_()
+
+    _reset_parameters = reset_parameters  # the reference's name
 
     def _where_to_attend(self, query, v_valid_ratios, ref_windows):
-        """:62-95 -> sampling grid [B, L, H, levels, k*k, 2] in normalised (x, y)."""
-        B, L = ref_windows.shape[:2]
-        offset_boxes = linear(query, self.linear_box_weight, self.linear_box_bias)
-        offset_boxes = offset_boxes.view(B, L, self.num_head, self.num_level, self.num_variable)
-        ref_windows = ref_windows.unsqueeze(2).unsqueeze(3) if ref_windows.dim() == 3 else ref_windows.unsqueeze(3)
-        ref_boxes = ref_windows[..., [0, 1, 3, 4]]
-        ref_angles = ref_windows[..., [6]]
-        if self.with_rotation:
-            offset_boxes, offset_angles = offset_boxes.split(4, dim=-1)
-            angles = (ref_angles + offset_angles / 16) * 2 * math.pi
-        else:
-            angles = ref_angles.expand(B, L, self.num_head, self.num_level, 1)
-        boxes = ref_boxes + offset_boxes / 8 * ref_boxes[..., [2, 3, 2, 3]]
-        center, size = boxes.unsqueeze(-2).split(2, dim=-1)
-        cos_angle, sin_angle = torch.cos(angles), torch.sin(angles)
-        rot_matrix = torch.stack([cos_angle, -sin_angle, sin_angle, cos_angle], dim=-1)
-        rot_matrix = rot_matrix.view(B, L, self.num_head, self.num_level, 1, 2, 2)
-        grid = self.kernel_indices * torch.relu(size)
-        grid = center + (grid.unsqueeze(-2) * rot_matrix).sum(-1)
-        if v_valid_ratios is not None:
-            grid = grid * v_valid_ratios
-        return grid.contiguous()
+        """Sampling grid [B, Lq, H, L, k*k, 2] for `query` (the reference's method name, :62-95)."""
+        offsets = linear(query, self.linear_box_weight, self.linear_box_bias)
+        return _baf.box_sampling_grid(ref_windows, offsets, self.kernel_indices, self.num_head, self.num_level,
+                                      self.with_rotation, v_valid_ratios)
 
     def forward(self, query, value, v_shape, v_mask, v_start_index, v_valid_ratios, ref_windows):
-        B, LQ = query.shape[:2]
-        LV = value.shape[1]
+        b, lq = query.shape[:2]
         value = self.value_proj(value)
         if v_mask is not None:
-            value = value.masked_fill(v_mask[..., None], float(0))
-        value = value.view(B, LV, self.num_head, self.head_dim)
-        attn_weights = linear(query, self.linear_attn_weight, self.linear_attn_bias)
-        if (v_valid_ratios is None and not ref_windows.requires_grad
-                and _baf.box_attn_fused_available(value, ref_windows, self.head_dim, self.num_level, self.num_point)):
-            # MI355X path: geometry + softmax + sampling in one kernel (csrc/box_fused.hip); same result as the
-            # reference sequence below without materialising the [B, LQ, H, L, 25, 2] grid.
-            offsets = linear(query, self.linear_box_weight, self.linear_box_bias)
-            output = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, offsets, attn_weights,
-                                                     self.kernel_indices, self.num_variable)
-            return self.out_proj(output), None
-        attn_weights = F.softmax(attn_weights.view(B, LQ, self.num_head, -1), dim=-1)
-        attn_weights = attn_weights.view(B, LQ, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
-        sampled_grid = self._where_to_attend(query, v_valid_ratios, ref_windows)
-        output = BoxAttnFunction.apply(value, v_shape, v_start_index, sampled_grid, attn_weights, self.im2col_step)
-        return self.out_proj(output), attn_weights
+            value = value.masked_fill(v_mask[..., None], 0.0)
+        value = value.view(b, value.shape[1], self.num_head, self.head_dim)
+        logits = linear(query, self.linear_attn_weight, self.linear_attn_bias)   # [B, Lq, H * L * k*k]
+        offsets = linear(query, self.linear_box_weight, self.linear_box_bias)    # [B, Lq, H * L * V]
+        fused = (v_valid_ratios is None and not ref_windows.requires_grad and
+                 _baf.box_attn_fused_available(value, ref_windows, self.head_dim, self.num_level, self.num_point))
+        if fused:
+            sampled = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, offsets, logits,
+                                                      self.kernel_indices, self.num_variable)
+            return self.out_proj(sampled), None
+        weights = F.softmax(logits.view(b, lq, self.num_head, self.num_level * self.num_point), dim=-1)
+        weights = weights.view(b, lq, self.num_head, self.num_level, self.kernel_size, self.kernel_size)
+        grid = _baf.box_sampling_grid(ref_windows, offsets, self.kernel_indices, self.num_head, self.num_level,
+                                      self.with_rotation, v_valid_ratios)
+        sampled = BoxAttnFunction.apply(value, v_shape, v_start_index, grid, weights, self.im2col_step)
+        return self.out_proj(sampled), weights

@@ -7,6 +7,8 @@ layers x {matching, denoising} x {labels, boxes} x scenes with ~40 tiny kernels 
 each (~1000 launches and 4 syncs per step at 3 layers); here all layers are stacked, matched with ONE
 cost-matrix transfer, and each loss family is one pass whose per-layer sums are read off a vector.
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -75,7 +77,7 @@ class Det3DLoss(nn.Module):
         cls = tgt_labels[b_idx, g_idx]
         want_ce = "focal_labels" in self.losses and "ce" in parts
         want_box = "boxes" in self.losses and "box" in parts
-        if (logits if logits is not None else boxes).is_cuda:
+        if (logits if logits is not None else boxes).is_cuda and os.environ.get("EFG_FUSED_LOSS", "1") != "0":
             # one kernel per loss family and direction (csrc/det_loss.hip) instead of ~40 elementwise launches each
             denom = device_scalar(num_boxes, cls.device)
             if want_ce:

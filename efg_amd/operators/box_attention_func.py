@@ -5,6 +5,8 @@ signatures of the reference bindings (efg/operators/src/box_attn/box_attn.h:29-8
 efg/operators/src/deform_attn/ms_deform_attn.h:22-63); both names run the same HIP kernel family
 (csrc/msda.hip).  fp32 only, like the ConQueR path (`custom_fwd(cast_inputs=torch.float32)`).
 """
+import math
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -91,6 +93,39 @@ class BoxAttnFunction(Function):
         grad_value, grad_loc, grad_attn = box_attn_backward(value, shapes, start, loc, attn,
                                                             grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
+
+
+# ---- box geometry: where a query's k x k lattice lands on the value map --------------------------------------
+def box_sampling_grid(ref_windows, offsets, kernel_indices, num_head, num_level, with_rotation, valid_ratios=None):
+    """The sampling geometry of Box3dAttention (contract: SURVEY.md B.5; reference $CQ/modules/box_attention.py:62-95;
+    the same arithmetic, in the same order, as csrc/box_fused.hip evaluates per lane).
+
+    ref_windows [B, Lq, 7] (x, y, z, l, w, h, angle/2pi), normalised; offsets [B, Lq, H * L * V] raw outputs of the
+    box Linear with V = 5 (dx, dy, dl, dw, dangle) when `with_rotation` else 4; kernel_indices [P, 2] lattice.
+    Returns the grid [B, Lq, H, L, P, 2] of normalised (x, y) sampling locations:
+        centre = (x, y) + (dx, dy) / 8 * (l, w);  size = (l, w) + (dl, dw) / 8 * (l, w)
+        theta  = (angle + dangle / 16) * 2 pi
+        point  = centre + R(theta) * (lattice * relu(size))
+    Plain slicing only -- no index lists, so it is legal inside a HIP-graph capture."""
+    b, lq = ref_windows.shape[:2]
+    nvar = 5 if with_rotation else 4
+    off = offsets.reshape(b, lq, num_head, num_level, nvar)
+    ref = ref_windows.reshape(b, lq, 1, 1, ref_windows.shape[-1]) if ref_windows.dim() == 3 else ref_windows.unsqueeze(3)
+    cx0, cy0, length, width, angle = ref[..., 0], ref[..., 1], ref[..., 3], ref[..., 4], ref[..., 6]
+    cx = cx0 + off[..., 0] / 8 * length
+    cy = cy0 + off[..., 1] / 8 * width
+    sx = torch.relu(length + off[..., 2] / 8 * length)
+    sy = torch.relu(width + off[..., 3] / 8 * width)
+    theta = ((angle + off[..., 4] / 16) * 2 * math.pi) if with_rotation else angle.expand(b, lq, num_head, num_level)
+    cos_t, sin_t = torch.cos(theta).unsqueeze(-1), torch.sin(theta).unsqueeze(-1)
+    kx = kernel_indices[:, 0] * sx.unsqueeze(-1)  # [B, Lq, H, L, P]
+    ky = kernel_indices[:, 1] * sy.unsqueeze(-1)
+    gx = cx.unsqueeze(-1) + (kx * cos_t + ky * (-sin_t))
+    gy = cy.unsqueeze(-1) + (kx * sin_t + ky * cos_t)
+    grid = torch.stack((gx, gy), dim=-1)
+    if valid_ratios is not None:
+        grid = grid * valid_ratios
+    return grid.contiguous()
 
 
 # ---- fused Box3dAttention sampling (csrc/box_fused.hip) -------------------------------------------------

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
-from torch.nn.init import constant_, xavier_uniform_
+from torch.nn.init import xavier_uniform_
 
 from .box_attention_func import ms_deform_attn_backward, ms_deform_attn_forward
 
@@ -36,72 +36,81 @@ class MSDeformAttnFunction(Function):
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
-def _is_power_of_2(n):
-    if (not isinstance(n, int)) or (n < 0):
-        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
-    return (n & (n - 1) == 0) and n != 0
-
-
 class MSDeformAttn(nn.Module):
-    """Multi-scale deformable attention module, efg/operators/ms_deform_attn.py:85-198: same
-    parameters (sampling_offsets, attention_weights, value_proj, output_proj), init and forward
-    contract; the sampling core is the HIP kernel."""
+    """Multi-scale deformable attention (Deformable-DETR), drop-in for efg/operators/ms_deform_attn.py:85-198: the
+    parameters `sampling_offsets.*`, `attention_weights.*`, `value_proj.*`, `output_proj.*`, their initial values and
+    the call `forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+    input_padding_mask=None)` are the reference's.
+
+    A query predicts, per head, level and point, a 2-D offset and an attention logit; the value map is sampled
+    bilinearly at reference + offset and the samples are mixed with the softmaxed weights.  Sampling + mixing is
+    the HIP kernel family of csrc/msda.hip (the same one `BoxAttnFunction` runs); the projections stay on hipBLASLt.
+    """
 
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        if d_model % n_heads != 0:
+        head_dim, rem = divmod(d_model, n_heads)
+        if rem:
             raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
-        if not _is_power_of_2(d_model // n_heads):
-            warnings.warn("You'd better set d_model in MSDeformAttn to make the dimension of each attention head a "
-                          "power of 2 which is more efficient in our CUDA implementation.")
-        self.im2col_step = 64
+        if head_dim & (head_dim - 1):
+            warnings.warn("MSDeformAttn: a head width of %d is not a power of two; the sampling kernel vectorises "
+                          "best over power-of-two widths" % head_dim)
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.head_dim = head_dim
+        self.im2col_step = 64
+        samples = n_heads * n_levels * n_points
+        self.sampling_offsets = nn.Linear(d_model, 2 * samples)
+        self.attention_weights = nn.Linear(d_model, samples)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
-        self._reset_parameters()
+        self.reset_parameters()
 
-    def _reset_parameters(self):
-        constant_(self.sampling_offsets.weight.data, 0.0)
-        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
-        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
-        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
-            1, self.n_levels, self.n_points, 1)
-        for i in range(self.n_points):
-            grid_init[:, :, i, :] *= i + 1
+    def reset_parameters(self):
+        """Offsets start as a star: head h looks along direction 2 pi h / H (scaled to the unit square's edge), its
+        p-th point p + 1 steps out, the same on every level; uniform attention; Xavier projections (:107-121)."""
         with torch.no_grad():
-            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
-        constant_(self.attention_weights.weight.data, 0.0)
-        constant_(self.attention_weights.bias.data, 0.0)
-        xavier_uniform_(self.value_proj.weight.data)
-        constant_(self.value_proj.bias.data, 0.0)
-        xavier_uniform_(self.output_proj.weight.data)
-        constant_(self.output_proj.bias.data, 0.0)
+            angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+            direction = torch.stack((angle.cos(), angle.sin()), dim=-1)
+            direction = direction / direction.abs().amax(dim=-1, keepdim=True)              # [H, 2]
+            steps = torch.arange(1, self.n_points + 1, dtype=torch.float32)                  # [P]
+            star = direction[:, None, None, :] * steps[None, None, :, None]                  # [H, 1, P, 2]
+            self.sampling_offsets.weight.zero_()
+            self.sampling_offsets.bias.copy_(star.expand(-1, self.n_levels, -1, -1).reshape(-1))
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            for proj in (self.value_proj, self.output_proj):
+                xavier_uniform_(proj.weight)
+                proj.bias.zero_()
+
+    _reset_parameters = reset_parameters  # the reference's name
+
+    def _sampling_locations(self, reference_points, offsets, spatial_shapes):
+        """reference_points [N, Lq, L, 2 | 4] in [0, 1]; offsets [N, Lq, H, L, P, 2] -> locations of the same shape.
+        2 columns: offsets are in pixels of each level (divided by (W_l, H_l)); 4 columns (cx, cy, w, h): offsets are
+        fractions of half the box size, 1 / n_points per unit (:173-187)."""
+        ref = reference_points[:, :, None, :, None, :]
+        width = reference_points.shape[-1]
+        if width == 2:
+            wh = spatial_shapes.flip(-1).to(offsets.dtype)  # (H, W) rows -> (W, H)
+            return ref + offsets / wh[None, None, None, :, None, :]
+        if width == 4:
+            return ref[..., :2] + offsets / self.n_points * ref[..., 2:] * 0.5
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(width))
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
-        N, Len_q, _ = query.shape
-        N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        n, len_q = query.shape[:2]
+        len_in = input_flatten.shape[1]
+        if int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) != len_in:
+            raise AssertionError("input_spatial_shapes do not add up to the %d flattened input cells" % len_in)
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels,
-                                                                   self.n_points)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            sampling_locations = (reference_points[:, :, None, :, None, :] +
-                                  sampling_offsets / offset_normalizer[None, None, None, :, None, :])
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = (reference_points[:, :, None, :, None, :2] +
-                                  sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
-        else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
-                reference_points.shape[-1]))
-        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, sampling_locations,
-                                            attention_weights, self.im2col_step)
-        return self.output_proj(output)
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(n, len_in, self.n_heads, self.head_dim)
+        offsets = self.sampling_offsets(query).view(n, len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        logits = self.attention_weights(query).view(n, len_q, self.n_heads, self.n_levels * self.n_points)
+        weights = F.softmax(logits, dim=-1).view(n, len_q, self.n_heads, self.n_levels, self.n_points)
+        locations = self._sampling_locations(reference_points, offsets, input_spatial_shapes)
+        sampled = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                             self.im2col_step)
+        return self.output_proj(sampled)

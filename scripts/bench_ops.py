@@ -237,6 +237,6 @@ def bench_colsum():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "spconv", "voxelize"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["msda", "spconv", "voxelize"]
     for w in which:
         globals()["bench_" + w]()

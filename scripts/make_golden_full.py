@@ -118,7 +118,7 @@ class _Conv(SparseModule):
         occ = torch.zeros_like(dense[:, :1])
         i = x.indices.long()
         occ[i[:, 0], 0, i[:, 1], i[:, 2], i[:, 3]] = 1
-        act = F.conv3d(occ, torch.ones(1, 1, *self.k), None, self.s, self.p) > 0
+        act = F.conv3d(occ, torch.ones(1, 1, *self.k, dtype=occ.dtype), None, self.s, self.p) > 0
         idx = torch.nonzero(act[:, 0])  # sorted (b, z, y, x)
         feats = y[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
         return SparseConvTensor(feats, idx.int(), list(y.shape[2:]), x.batch_size)
@@ -194,9 +194,18 @@ def install_shims(model_dir=CQ):
     from efg.operators.ms_deform_attn import ms_deform_attn_core_pytorch as core
 
     class BoxAttnFunction:
+        kink = []  # distance of every sampling coordinate (pixel units) to the nearest bilinear kink (an integer)
+
         @staticmethod
         def apply(value, shapes, start, loc, attn, step):
             b, lq, h, l = attn.shape[:4]
+            if loc.requires_grad or value.requires_grad:
+                with torch.no_grad():
+                    wh = torch.as_tensor(shapes.tolist(), dtype=loc.dtype).flip(-1)  # (W, H) per level
+                    pix = loc.detach() * wh[None, None, None, :, None, :] - 0.5
+                    d = (pix - pix.round()).abs()
+                    inside = (pix > -1) & (pix < wh[None, None, None, :, None, :])
+                    BoxAttnFunction.kink.append(torch.where(inside, d, torch.ones_like(d)).flatten().double())
             return core(value, shapes.tolist(), loc, attn.reshape(b, lq, h, l, -1))
 
     _mod("efg.modeling.operators", BoxAttnFunction=BoxAttnFunction)
@@ -266,7 +275,8 @@ def run(tag, model_dir, yaml_name, out_name):
 
         def spy_cdn(*a, **k):
             r = orig_cdn(*a, **k)
-            cap.update(dn_label=r[0].detach().clone(), dn_box=r[1].detach().clone())
+            cap.update(dn_label=r[0].detach().clone(), dn_box=r[1].detach().clone(), dn_mask=r[2].clone(),
+                       dn_meta={k: v for k, v in r[3].items()})
             return r
 
         voxel_detr.prepare_for_cdn = spy_cdn
@@ -277,17 +287,63 @@ def run(tag, model_dir, yaml_name, out_name):
     losses = model(batch)
     total = sum(v for v in losses.values() if v.requires_grad)
     total.backward()
+    kinks = torch.cat(sys.modules["efg.modeling.operators"].BoxAttnFunction.kink)
+    print("   bilinear kink distances (pixels): n=%d, smallest %s" % (
+        kinks.numel(), ["%.1e" % float(x) for x in torch.sort(kinks)[0][:6]]))
     grads = {}
     want = ["backbone.extractor.bottom_up.stem.conv1.0.weight", "backbone.extractor.bottom_up.res3.0.shortcut.0.weight",
             "backbone.extractor.fpn_lateral3.weight", "backbone.extractor.fpn_output3.weight", "input_proj.0.0.weight",
             "transformer.encoder.layers.0.self_attn.linear_box_weight", "projector.0.weight", "predictor.2.weight",
             "transformer.decoder.layers.1.multihead_attn.value_proj.weight",
-            "backbone.extractor.bottom_up.res4.1.conv2.0.weight", "backbone.extractor.bottom_up.res3_out.0.weight"]
+            "backbone.extractor.bottom_up.res4.1.conv2.0.weight", "backbone.extractor.bottom_up.res3_out.0.weight",
+            # small tensors from the loss inwards (they localise a backward discrepancy)
+            "transformer.decoder.detection_head.class_embed.2.layers.2.weight",
+            "transformer.decoder.detection_head.bbox_embed.2.layers.2.weight",
+            "transformer.decoder.detection_head.bbox_embed.0.layers.0.bias",
+            "transformer.decoder.layers.2.norm3.weight", "transformer.decoder.layers.2.linear2.bias",
+            "transformer.decoder.layers.2.multihead_attn.linear_box_weight",
+            "transformer.decoder.layers.2.multihead_attn.linear_attn_weight",
+            "transformer.decoder.layers.2.multihead_attn.out_proj.bias",
+            "transformer.decoder.layers.2.multihead_attn.value_proj.bias",
+            "transformer.decoder.layers.2.self_attn.out_proj.bias", "transformer.decoder.layers.2.self_attn.in_proj_bias",
+            "transformer.decoder.layers.2.norm1.weight", "transformer.decoder.layers.2.norm2.weight",
+            "transformer.decoder.layers.0.pos_embed_layer.layers.0.weight",
+            "transformer.proposal_head.class_embed.0.layers.2.weight", "transformer.proposal_head.bbox_embed.0.layers.2.weight",
+            "transformer.encoder.layers.0.norm2.weight", "transformer.encoder.layers.0.linear2.bias",
+            "transformer.encoder.layers.0.self_attn.value_proj.bias", "input_proj.0.1.weight",
+            "backbone.extractor.fpn_output3.norm.weight", "backbone.extractor.bottom_up.res4.1.conv.4.weight"]
     params = dict(model.named_parameters())
     for n in want:
         if n in params and params[n].grad is not None:
             grads[n] = params[n].grad.detach().clone()
     dead = sorted(n for n, p in params.items() if p.requires_grad and p.grad is None)
+    # ---- the same reference model in float64 (ground truth for the gradient tolerances): same weights, same
+    # inputs, the CDN queries of the fp32 run replayed (rand_like on double tensors would draw a different stream)
+    grads64 = {}
+    if "--no-fp64" not in sys.argv:
+        model64 = voxel_detr.VoxelDETR(cfg)
+        model64.load_state_dict(state, strict=True)
+        model64.double().train()
+        model64.box_coder.pc_range = model64.box_coder.pc_range.double() if torch.is_tensor(model64.box_coder.pc_range) else model64.box_coder.pc_range
+        batch64 = reference_samples(cfg, points_list, copy.deepcopy(annos))
+        for smp, tgt in batch64:
+            smp["voxels"] = smp["voxels"].astype(np.float64)
+            tgt["annotations"]["gt_boxes"] = tgt["annotations"]["gt_boxes"].astype(np.float64)
+        if "dn_box" in cap:
+            fixed = (cap["dn_label"].double(), cap["dn_box"].double())
+
+            def replay_cdn(*a, **k):
+                return fixed[0], fixed[1], cap["dn_mask"], dict(cap["dn_meta"])
+
+            voxel_detr.prepare_for_cdn = replay_cdn
+        torch.manual_seed(1234)
+        losses64 = model64(batch64)
+        total64 = sum(v for v in losses64.values() if v.requires_grad)
+        total64.backward()
+        p64 = dict(model64.named_parameters())
+        for n in grads:
+            grads64[n] = p64[n].grad.detach().clone()
+        print("   fp64 total loss %.9f (fp32 %.9f)" % (float(total64), float(total)))
     save = {"total_loss": total.detach(), "n_params": np.array(sum(p.numel() for p in params.values() if p.requires_grad))}
     light = "prepare_for_cdn" not in vars(voxel_detr)  # Voxel-DETR: same weights => same maps as the ConQueR fixture
     for k in ("memory", "topk") if light else ("bu_res3", "bu_res4", "fpn_p3", "src", "memory", "topk", "dn_label",
@@ -302,10 +358,17 @@ def run(tag, model_dir, yaml_name, out_name):
     for k, v in grads.items():
         # large tensors: the first 8 output rows only (the test slices its gradient the same way)
         save["grad::" + k] = v[:8].contiguous() if v.numel() > 65536 else v
-        print("   grad", k, tuple(v.shape), float(v.abs().max()))
+        if k in grads64:
+            g64 = grads64[k]
+            e = float((v.double() - g64).abs().max() / g64.abs().max())
+        else:
+            e = float("nan")
+        print("   grad %-75s %-22s max %.3e   fp32-vs-fp64 err/max %.2e" % (k, tuple(v.shape), float(v.abs().max()), e))
+    print("   missing:", [n for n in want if n not in grads])
     bn = model.backbone.extractor.bottom_up.stem.conv1[1]
     save["bn_running_mean_after"] = bn.running_mean.detach().clone()
     save["dead_params"] = np.array(";".join(dead))
+    save["min_kink_distance_px"] = np.array(float(kinks.min()))
     out = os.path.join(ROOT, "tests", "golden", out_name)
     np.savez_compressed(out, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in save.items()})
     print(tag, "saved", out, os.path.getsize(out) // 1024, "KiB;", len(losses), "loss terms; total", float(total),

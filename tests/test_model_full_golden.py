@@ -73,7 +73,7 @@ def _run(model, device):
     return cap, losses, total
 
 
-def _check(model, g, cap, losses, total, full_graph, act_tol=2e-4, loss_rtol=5e-4):
+def _check(model, g, cap, losses, total, full_graph, act_tol=5e-5, loss_rtol=1e-4, grad_tol=3e-3, grad_tol_exact=1e-4):
     c = lambda x: x.detach().float().cpu().numpy()  # noqa: E731
 
     def close(name, got, want, tol):
@@ -104,12 +104,27 @@ def _check(model, g, cap, losses, total, full_graph, act_tol=2e-4, loss_rtol=5e-
     np.testing.assert_allclose(float(total), float(g["total_loss"]), rtol=1e-4)
     params = dict(model.named_parameters())
     assert int(g["n_params"]) == sum(p.numel() for p in params.values() if p.requires_grad)
+    # Gradients.  Two tiers (see the module docstring of scripts/grad_bisect.py and DESIGN.md "bilinear kinks"):
+    #  * tensors whose gradient does not pass through a sampling location (the heads and the last decoder layer's
+    #    biases / norms, evaluated before any sampling backward): 1e-4 of the tensor's max;
+    #  * everything behind a box-attention backward: 3e-3.  Bilinear sampling is piecewise linear in the location;
+    #    the reference run has ~350 000 sampling coordinates and the closest lies 9.5e-7 px from an integer
+    #    (fixture key `min_kink_distance_px`), inside the fp32 rounding of a pixel coordinate, so CPU and GPU pick
+    #    different one-sided derivatives for a handful of samples.  Measured on MI355X: ONE query row differs (1 % of
+    #    its own gradient), every other row agrees to 1e-7; that row's contribution is ~1e-3 of a weight gradient --
+    #    with the HIP kernels and with PyTorch's own grid_sample on the GPU alike.  Convolutions in front of a
+    #    BatchNorm are ill-conditioned on top: the reference's own fp32 gradient is 6-8e-4 off its fp64 run.
+    exact = ("detection_head", "proposal_head", "decoder.layers.2.norm", "decoder.layers.2.linear2",
+             "decoder.layers.2.multihead_attn.out_proj", "decoder.layers.2.multihead_attn.value_proj",
+             "decoder.layers.2.self_attn", "projector", "predictor")
     for k, v in g.items():
         if k.startswith("grad::"):
             got = c(params[k[6:]].grad)
             if got.size > 65536:
                 got = got[:8]
-            np.testing.assert_allclose(got, v, rtol=1e-3, atol=1e-3 * np.abs(v).max(), err_msg=k)  # 1e-3 rel
+            tol = grad_tol_exact if any(e in k for e in exact) else grad_tol
+            err = float(np.abs(got - v).max() / np.abs(v).max())
+            assert err <= tol, "%s: gradient error %.2e of the tensor max (tolerance %.1e)" % (k, err, tol)
     dead_ref = set(str(g["dead_params"]).split(";"))
     dead = {n for n, p in params.items() if p.requires_grad and p.grad is None}
     assert dead == dead_ref, dead ^ dead_ref
@@ -124,7 +139,8 @@ def test_reference_full_model_cpu(oracle_mod):
     model, g = _build(torch.device("cpu"), full_graph=True)
     with cpu_backend.install():
         cap, losses, total = _run(model, torch.device("cpu"))
-    _check(model, g, cap, losses, total, full_graph=True)
+    # same PyTorch CPU arithmetic as the reference run around the (oracle) ops: no kink flips, 1e-3 everywhere
+    _check(model, g, cap, losses, total, full_graph=True, grad_tol=1e-3)
 
 
 @pytest.mark.gpu

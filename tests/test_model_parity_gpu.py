@@ -1,7 +1,11 @@
 """GPU: the WHOLE model (GPU voxelizer -> sparse backbone -> FPN -> box-attention transformer -> 32 losses
 -> backward) on the HIP path against the same model on the CPU with the oracle standing in for every
 HIP op, identical weights / scenes / CDN noise.  Bars: voxel indices bit-exact (checked in
-test_voxelize_gpu), fp32 logits within 1e-4 (north star), losses 1e-3 rel, gradients 5e-3 of max."""
+test_voxelize_gpu), fp32 logits within 1e-4 (north star), losses 1e-4 rel, gradients 3e-3 of the tensor max --
+the floor set by bilinear-sampling kinks, not by arithmetic: with ~10^5 sampling coordinates per step a few lie
+within fp32 rounding of a pixel boundary and CPU / GPU take different one-sided derivatives there
+(scripts/grad_bisect.py: one query row differs, all others agree to 1e-7; PyTorch's own grid_sample on the GPU shows
+the same).  The reference-pinned twin of this test is tests/test_model_full_golden.py."""
 import numpy as np
 import pytest
 import torch
@@ -84,8 +88,8 @@ def test_full_model_gpu_matches_cpu_oracle(dev, oracle_mod):
                 o1, o2 = np.lexsort(np.round(p1, 3).T), np.lexsort(np.round(p2, 3).T)
                 np.testing.assert_allclose(p2[o2], p1[o1], atol=2e-4, rtol=0)
     for k in l_cpu:
-        assert l_gpu[k] == pytest.approx(l_cpu[k], rel=1e-3, abs=1e-4), k
+        assert l_gpu[k] == pytest.approx(l_cpu[k], rel=1e-4, abs=2e-5), k
     assert len(g_cpu) >= 6
     for n, g in g_cpu.items():
-        # deepest layers accumulate fp32 roundoff through ~60 layers incl. BatchNorm: 5e-3 of the tensor max
-        np.testing.assert_allclose(g_gpu[n].numpy(), g.numpy(), rtol=5e-3, atol=5e-3 * float(g.abs().max()), err_msg=n)
+        err = float((g_gpu[n] - g).abs().max() / g.abs().max())
+        assert err <= 3e-3, "%s: gradient error %.2e of the tensor max" % (n, err)

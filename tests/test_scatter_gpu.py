@@ -88,3 +88,41 @@ def test_dynamic_scatter_module_batched(dev, oracle_mod):
         np.testing.assert_allclose(vf[sl].cpu().numpy(), evf, rtol=1e-5, atol=1e-5)
         rows += evf.shape[0]
     assert vf.shape[0] == rows
+
+
+@pytest.mark.parametrize("reduce", ["max", "mean", "sum"])
+@pytest.mark.parametrize("n,c", [(30000, 6), (4097, 33)])
+def test_forward_backward_vs_torch_unique_scatter_reduce(dev, reduce, n, c):
+    """Independent of oracle/: the semantics of scatter_points_cuda.cu:209-352 written with stock PyTorch ops in
+    fp64 -- voxel id = rank of the row-major key (dims = coors.max(0) + 1) among the distinct valid keys
+    (`torch.unique`, ascending), features reduced per voxel with `scatter_reduce`, gradients by autograd through it
+    (no ties in random data, so amax's tie rule does not matter)."""
+    from efg_amd.operators.scatter_points import dynamic_point_to_voxel_forward, dynamic_scatter
+
+    feats, coors = _cloud(n, c, seed=3 * n + c)
+    f = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    cg = torch.from_numpy(coors).to(dev)
+    vf, vc = dynamic_scatter(f, cg, reduce)
+    _, _, p2v, cnt = dynamic_point_to_voxel_forward(f.detach(), cg, reduce)
+    ct = torch.from_numpy(coors).long()
+    valid = (ct >= 0).all(1)
+    dims = ct.max(0)[0] + 1
+    key = (ct[:, 0] * dims[1] + ct[:, 1]) * dims[2] + ct[:, 2]
+    uniq, inv = torch.unique(key[valid], return_inverse=True)  # sorted ascending
+    m = uniq.numel()
+    ref_map = torch.full((n,), -1, dtype=torch.int64)
+    ref_map[valid] = inv
+    assert np.array_equal(p2v.cpu().numpy(), ref_map.numpy().astype(np.int32))
+    ref_coors = torch.stack([uniq // (dims[1] * dims[2]), (uniq // dims[2]) % dims[1], uniq % dims[2]], 1)
+    assert np.array_equal(vc.cpu().numpy(), ref_coors.numpy().astype(np.int32))
+    x = torch.from_numpy(feats).double().requires_grad_(True)
+    red = {"max": "amax", "mean": "mean", "sum": "sum"}[reduce]
+    ref = torch.zeros(m, c, dtype=torch.float64).scatter_reduce(0, inv[:, None].expand(-1, c), x[valid], red,
+                                                                include_self=False)
+    np.testing.assert_allclose(vf.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    if reduce == "mean":
+        assert np.array_equal(cnt.cpu().numpy(), torch.bincount(inv, minlength=m).numpy().astype(np.int32))
+    g = np.random.default_rng(2).standard_normal((m, c)).astype(np.float32)
+    vf.backward(torch.from_numpy(g).to(dev))
+    ref.backward(torch.from_numpy(g).double())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=1e-6)
