@@ -14,10 +14,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import efg_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts)
-
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+from efg_amd.engine import configure_hip_runtime  # noqa: E402
+
+configure_hip_runtime()  # GPU_MAX_HW_QUEUES, before the first HIP call of the process
 
 
 def parse():

@@ -143,7 +143,7 @@ box_loss_kernel(const float* __restrict__ boxes, const float* __restrict__ tgt, 
   const int l = blockIdx.x;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   for (long long i = threadIdx.x; i < n; i += 1024) {
-    if (li[i] != l) continue;
+    if (li[i] != l || qi[i] < 0 || qi[i] >= Q) continue;  // unmatched column (infeasible assignment): no pair
     const float* s = boxes + ((li[i] * B + bi[i]) * Q + qi[i]) * 7;
     const float* t = tgt + (bi[i] * G + gi[i]) * 7;
     float l1 = 0.f;
@@ -170,7 +170,7 @@ box_loss_grad_kernel(const float* __restrict__ boxes, const float* __restrict__ 
                      long long n, int B, int Q, int G, const float* __restrict__ denom, const float* __restrict__ gout,
                      float* __restrict__ gboxes) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || qi[i] < 0 || qi[i] >= Q) return;  // unmatched column: nothing to write (never index out of range)
   const long long row = ((li[i] * B + bi[i]) * Q + qi[i]) * 7;
   const float* s = boxes + row;
   const float* t = tgt + (bi[i] * G + gi[i]) * 7;

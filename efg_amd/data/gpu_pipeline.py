@@ -28,9 +28,12 @@ class _PointOp(ctypes.Structure):
 class DevicePoints:
     """An [N, F] float32 cloud on the GPU plus the transforms queued on it."""
 
-    def __init__(self, points):
-        if isinstance(points, np.ndarray):
-            points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32))
+    def __init__(self, points, device=None):
+        if isinstance(points, np.ndarray):  # host array: upload to `device` (default: the current GPU)
+            if device is None:
+                L.lib()  # no GPU library => the usual loud failure, before touching torch.cuda
+                device = torch.device("cuda", torch.cuda.current_device())
+            points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
         L.require_gpu(points)
         self.tensor = points.contiguous().float()
         self.ops = []

@@ -134,6 +134,11 @@ class VoxelDETR(nn.Module):
         samples = [bi[0] for bi in batched_inputs]
         if "voxels" in samples[0]:  # reference format: CPU-voxelized arrays
             c = collate(samples, self.device)
+            geo = self._geometry_stream()
+            if geo is not None:
+                # the uploads (and any dtype conversion of the coordinates) are queued on the main stream; the
+                # sparse-conv geometry kernels read them on the geometry stream
+                geo.wait_stream(torch.cuda.current_stream())
             return c["voxels"], c["coordinates"], c["num_points_per_voxel"], list(c["shape"][0]), None
         mode = "train" if self.training else "val"
         vc = self._vox_cfg[mode]
@@ -147,10 +152,12 @@ class VoxelDETR(nn.Module):
             # the readback does not wait for the previous step's backward still queued on the main stream
             main = torch.cuda.current_stream()
             events = [s.get("ready_event") for s in samples]
-            if all(e is not None for e in events):
+            converted = any(torch.is_tensor(s["points"]) and (not s["points"].is_cuda or s["points"].dtype !=
+                                                               torch.float32) for s in samples)
+            if all(e is not None for e in events) and not converted:
                 for e in events:
                     geo.wait_event(e)  # the caller's promise: the points are complete once this event fires
-            else:
+            else:  # (also when `pts` were uploaded / converted on the main stream just above)
                 geo.wait_stream(main)  # unknown provenance: order after everything queued so far
             with torch.cuda.stream(geo):
                 out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
@@ -291,7 +298,7 @@ class VoxelDETR(nn.Module):
                               torch.cat([torch.arange(n, dtype=torch.int64) for n in per_gt])]).to(
                                   dev, non_blocking=True)
         b_idx, g_idx = static[0], static[1]
-        q_idx = query_of_gt[b_idx, g_idx]
+        q_idx = query_of_gt[b_idx, g_idx].clamp(min=0)  # -1 = unmatched (infeasible assignment; the engine raises)
         n = num_gts
         neg_mask = torch.ones(len(targets), nq, dtype=torch.bool, device=dev)
         neg_mask.index_put_((b_idx, q_idx), torch.zeros((), dtype=torch.bool, device=dev))  # unmatched queries

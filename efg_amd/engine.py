@@ -75,6 +75,22 @@ def use_tuned_gemms(path=TUNED_GEMMS):
     return True
 
 
+def configure_hip_runtime():
+    """Process-level HIP runtime settings of a TRAINING process (bench.py and Trainer call this; importing efg_amd
+    does not touch the environment).
+
+    GPU_MAX_HW_QUEUES: the step uses three device queues at once -- the main stream, the high-priority geometry
+    stream (voxelization and sparse-conv site counts, whose read-backs the host waits on) and, with more than one
+    rank, RCCL's streams.  The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware
+    queues (default 4); once the RCCL communicator exists the geometry stream shares a hardware queue with other
+    work and its kernels wait behind unrelated ones: +1.4 ms/step with nothing else changed
+    (scripts/ubench/ddp_modes.py none vs none:comm: 35.4 -> 36.8 ms; 35.8 / 35.8 with 8 queues).  The runtime reads
+    the variable when it initialises, so this only has an effect before the first HIP call of the process; an
+    explicit setting in the environment wins.  Returns True if the setting can still take effect."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    return not torch.cuda.is_initialized()
+
+
 def limit_host_threads():
     """The host side of a step is ~2000 kernel launches from two Python threads; nothing in it is a parallel CPU
     loop worth more than a few cores.  Left alone, OpenMP sizes its pool to the machine (256 hardware threads on
@@ -102,8 +118,13 @@ class FlatGradientAllReduce:
     Here the gradients are packed by one multi-tensor copy into a persistent flat buffer, reduced by one RCCL call
     (a single large collective: what the point-to-point xGMI links like), and the optimizer reads them through views
     of that buffer (no copy back): 0.23 ms of device time and ~1.1 ms of host time per step
-    (scripts/ubench/flat_reduce_cost.py).  The set of parameters that receive a gradient is fixed by the model (the
-    unused FPN levels never do) and is taken from the first step."""
+    (scripts/ubench/flat_reduce_cost.py).
+
+    Which parameters are exchanged: those that received a gradient in the first step (the unused FPN levels never
+    do, and exchanging 1.3 M zeros for them is wasted wire).  The set is fixed by the graph, not by the data; it is
+    nevertheless CHECKED across ranks on that first step (a mismatch would desynchronise the flat buffers: the
+    reference runs DDP with find_unused_parameters=True for this reason, $CQ/config.yaml:182-183), and a parameter of
+    the set that has no gradient in a later step contributes zeros instead of crashing the pack."""
 
     def __init__(self, model, world):
         self.model, self.world = model, world
@@ -121,14 +142,26 @@ class FlatGradientAllReduce:
     @torch.no_grad()
     def reduce(self):
         if self.params is None:
-            self.params = [p for p in self.model.parameters() if p.grad is not None]
+            named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+            used = torch.tensor([1.0 if p.grad is not None else 0.0 for _, p in named], device=named[0][1].device)
+            lo, hi = used.clone(), used.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                bad = [named[i][0] for i in torch.nonzero(lo != hi).flatten().tolist()]
+                raise RuntimeError("FlatGradientAllReduce: ranks disagree on which parameters receive a gradient "
+                                   "(%d parameters, e.g. %s); use EFG_DDP_MODE=find_unused" % (len(bad), bad[:3]))
+            self.params = [p for _, p in named if p.grad is not None]
             total = sum(p.numel() for p in self.params)
             self.flat = torch.empty(total, dtype=self.params[0].dtype, device=self.params[0].device)
             self.views, off = [], 0
             for p in self.params:
                 self.views.append(self.flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        torch._foreach_copy_(self.views, [p.grad for p in self.params])  # multi-tensor pack into the flat buffer
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):  # a data-dependent branch skipped a parameter this step: it sends zeros
+            grads = [v.zero_() if g is None else g for g, v in zip(grads, self.views)]
+        torch._foreach_copy_(self.views, grads)  # multi-tensor pack into the flat buffer
         if self.avg:
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
         else:
@@ -138,10 +171,35 @@ class FlatGradientAllReduce:
             p.grad = v
 
 
+# iterations of the reference ConQueR run: 6 epochs over the 158 081 Waymo training frames at 6 scenes x 8 GPUs
+# ($CQ/config.yaml:62-64,147-149); Trainer(max_iters=...) overrides it
+REFERENCE_MAX_ITERS = 6 * (158081 // (6 * 8))
+
+
+def build_one_cycle(cfg, optimizer, max_iters):
+    """`solver.lr_scheduler: {type: OneCycle, ...}` -> torch OneCycleLR exactly as efg/solver/lr_schedulers.py:222-237
+    builds it: max_lr = solver.optimizer.lr for EVERY parameter group (the scalar overrides the per-group rates of
+    AdamWMulti -- kept, it is what the reference trains with), total_steps = max_iters, cycled Adam beta1 between
+    base_momentum and max_momentum.  None when the config has no scheduler."""
+    sc = cfg.solver.get("lr_scheduler") if hasattr(cfg.solver, "get") else None
+    if not sc:
+        return None
+    if sc.get("type", "OneCycle") != "OneCycle":
+        raise ValueError("only the OneCycle scheduler of the ConQueR / Voxel-DETR configs is mirrored, got %r" % sc.type)
+    kw = {k: sc[k] for k in ("pct_start", "base_momentum", "max_momentum", "div_factor", "final_div_factor",
+                             "anneal_strategy", "three_phase") if k in sc}
+    return torch.optim.lr_scheduler.OneCycleLR(optimizer, cfg.solver.optimizer.lr, total_steps=int(max_iters), **kw)
+
+
 class Trainer:
-    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None):
+    """step() = the reference's `DefaultTrainer.step` + `Optimization.after_step` + `LRScheduler.after_step`
+    (efg/engine/trainer.py:278-305, efg/engine/hooks.py:68-81,118-121): zero_grad, forward, sum of the differentiable
+    losses, non-finite check, backward, gradient exchange, optional clipping, optimizer step, scheduler step."""
+
+    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
         if str(cfg.model.device if device is None else device).startswith("cuda"):
+            configure_hip_runtime()
             limit_host_threads()
         if device is not None:
             cfg.model.device = str(device)
@@ -156,6 +214,12 @@ class Trainer:
         self.model = VoxelDETR(cfg)
         self.model.train()
         self.optimizer = build_adamw_multi(cfg, self.model)
+        self.lr_scheduler = build_one_cycle(cfg, self.optimizer, max_iters or REFERENCE_MAX_ITERS)
+        gc_cfg = cfg.solver.get("grad_clipper") if hasattr(cfg.solver, "get") else None
+        self.grad_clipper = gc_cfg if (gc_cfg and gc_cfg.get("enabled")) else None
+        self.anomaly_every = int(os.environ.get("EFG_ANOMALY_EVERY", "50"))
+        self._nonfinite = None
+        self._gc_state = None
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         use_ddp = (world > 1) if ddp is None else ddp
         self.wrapped = self.model
@@ -191,11 +255,51 @@ class Trainer:
         reference counting.  At the first step (always a warm-up step): freeze what exists, switch the automatic
         collector off; afterwards collect by hand every 100 steps.  EFG_MANUAL_GC=0 leaves the interpreter alone."""
         if self._steps == 1:
+            self._gc_state = gc.isenabled()
             gc.collect()
             gc.freeze()
             gc.disable()
         elif self._steps % 100 == 0:
             gc.collect()
+
+    def close(self):
+        """Give the interpreter its cyclic collector back (the process may go on to do other things) and run the
+        pending anomaly check."""
+        if self._gc_state is not None:
+            gc.unfreeze()
+            if self._gc_state:
+                gc.enable()
+            self._gc_state = None
+        self._check_anomaly(force=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _check_anomaly(self, losses=None, force=False):
+        """The reference raises FloatingPointError when the summed loss is not finite (trainer.py:307-311) and scipy
+        raises on an infeasible cost matrix (matcher.py:89) -- both by reading a device value on the host EVERY step.
+        Here both conditions are accumulated on the device and read every `anomaly_every` steps (EFG_ANOMALY_EVERY,
+        default 50; the first step always): same failure, at most that many steps late, no per-step drain of the
+        stream.  Unmatched queries never index out of range in between (csrc/det_loss.hip skips them)."""
+        if losses is not None:  # running sum: one tiny kernel per step; a NaN / Inf stays non-finite in the sum
+            self._nonfinite = losses.detach() if self._nonfinite is None else self._nonfinite + losses.detach()
+        if not (force or self._steps == 1 or (self.anomaly_every > 0 and self._steps % self.anomaly_every == 0)):
+            return
+        lsap_bad = None
+        if self.model.device.type == "cuda":
+            from .operators.assignment import take_failures
+
+            lsap_bad = take_failures(self.model.device)
+        flag, self._nonfinite = self._nonfinite, None
+        if flag is not None and not bool(torch.isfinite(flag)):
+            raise FloatingPointError("Loss became infinite or NaN at or before iteration=%d!" % self._steps)
+        if lsap_bad is not None and int(lsap_bad) > 0:
+            raise FloatingPointError("Hungarian matching met %d infeasible cost matrices (non-finite costs) at or "
+                                     "before iteration=%d" % (int(lsap_bad), self._steps))
 
     def step(self, batch):
         self._steps += 1
@@ -211,5 +315,14 @@ class Trainer:
             if self.grad_sync is not None:
                 self.grad_sync.reduce()
         with record_function("efg::optimizer"):
+            if self.grad_clipper is not None:  # hooks.py:74-79 (disabled in the ConQueR / Voxel-DETR configs)
+                params = [p for p in self.model.parameters() if p.grad is not None]
+                if self.grad_clipper.clip_type == "norm":
+                    torch.nn.utils.clip_grad_norm_(params, **dict(self.grad_clipper.params))
+                elif self.grad_clipper.clip_type == "value":
+                    torch.nn.utils.clip_grad_value_(params, **dict(self.grad_clipper.params))
             self.optimizer.step()
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+        self._check_anomaly(losses)
         return loss_dict, losses
