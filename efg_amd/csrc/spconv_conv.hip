@@ -42,8 +42,13 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
   const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
   const int r16n = round16(red) / 16, np = round16(nn);
   const long long total = (long long)kvol * r16n * np * 16;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+  // (+ the slack row kernels with NT > tiles read past the last n-tile: written as zeros here, no separate memset)
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total + 16 * 256;
        e += (long long)gridDim.x * blockDim.x) {
+    if (e >= total) {
+      packed[e] = 0.0f;
+      continue;
+    }
     const int t = (int)(e & 15);
     const int kk = t >> 2, j = t & 3;
     long long q = e >> 4;
@@ -587,8 +592,10 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
   p.nco_blk = (cout + 63) / 64;
   p.nci_blk = (cin + 63) / 64;
   const size_t per = (size_t)kvol * cout * cin * 4;
-  // ~4096 workgroups (16 per CU) when the level is large enough, >= 512 rows per chunk, <= 128 MB partials
-  const int64_t by_fill = std::max<int64_t>(1, 4096 / ((int64_t)p.nco_blk * p.nci_blk * kvol));
+  // ~2048 workgroups (8 per CU) when the level is large enough (as fast as 4096 with half the partial-block traffic;
+  // 1024 is 15-30 % slower: scripts/tile_sweep.sh), >= 512 rows per chunk, <= 128 MB partials
+  static const int64_t fill_env = getenv("EFG_WGRAD_FILL") ? atoll(getenv("EFG_WGRAD_FILL")) : 2048;
+  const int64_t by_fill = std::max<int64_t>(1, fill_env / ((int64_t)p.nco_blk * p.nci_blk * kvol));
   const int64_t by_rows = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), 512));
   const int64_t by_mem = std::max<int64_t>(1, (int64_t)((128ull << 20) / std::max<size_t>(per, 1)));
   int64_t s = std::min(std::min(by_fill, by_rows), by_mem);
@@ -684,8 +691,7 @@ extern "C" int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvo
   hipStream_t stream = (hipStream_t)stream_;
   EFG_CHECK_ARG(cout >= 1 && cin >= 1 && kvol >= 1, "spconv: bad weight shape");
   const size_t bytes = efg_spconv_packed_weight_bytes(cout, kvol, cin, for_dgrad);
-  EFG_HIP_TRY(hipMemsetAsync(packed, 0, bytes, stream));
-  const long long total = (long long)(bytes / sizeof(float)) - 16 * 256;
+  const long long total = (long long)(bytes / sizeof(float));
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256),
                      0, stream, weight, cout, kvol, cin, for_dgrad, packed);
   EFG_LAUNCH_CHECK();

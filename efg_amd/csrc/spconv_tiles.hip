@@ -1,0 +1,477 @@
+// Sparse convolution, second generation: MASK-SORTED ROW TILES.
+//
+// The output-stationary kernel of spconv_conv.hip takes 16 consecutive rows (canonical spatial order) per wave and
+// executes every kernel offset ANY of the 16 rows needs: measured x1.35 the useful MFMAs on the submanifold layers,
+// x2.1 on the strided forwards (scripts/ubench/tile_waste.py; profiles/r02_*).  Which offsets a row needs is its
+// 27-bit neighbour mask, and rows with equal masks are plentiful (ground, walls: a few hundred patterns cover a
+// level) but interleaved in space.  A *tile plan* therefore re-orders the rows of a neighbour table inside chunks of
+// 1024 consecutive rows by their mask (an LDS bitonic sort of {mask, row}), cuts the sorted sequence into 16-row
+// tiles and stores, per tile, the rows, the neighbour columns in tile-major order and the per-offset validity masks:
+// x1.10-1.15 instead of x1.35 / x2.1, with gather locality kept at chunk granularity (a chunk's gathers stay inside
+// three z-slabs of ~1k rows).  The plan depends only on geometry: it is built once per rulebook on the geometry
+// stream and shared by every convolution, direction and training step that uses the table (9 launches for a res18
+// submanifold key).  A row's sum runs over ITS offsets only; the plan is a pure function of the table, so results are
+// reproducible run to run (with KS > 1 the grouping of a row's partial sums follows its tile, as in generation one).
+//
+// Kernel (conv_tile_kernel): per wave R sub-tiles of 16 rows (R = 2: one B fragment load feeds two row tiles, which
+// halves the weight traffic through the vector L1 -- PMC: 52 % of the L1's peak bandwidth in generation one), NT
+// output-channel tiles, v_mfma_f32_16x16x4_f32, A through a wave-private LDS tile, next gather in flight during the
+// MFMAs; the offsets of a tile are split over the KS waves of its workgroup and summed through LDS (small levels).
+// The prologue is three coalesced loads (rows, neighbour block, masks) -- no ballots, no index arithmetic.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace efg {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunkRows = 1024;  // rows sorted together (one workgroup of the plan kernel)
+constexpr int kCKt = 64;          // channels per staged chunk
+constexpr int kAStr = kCKt + 2;   // LDS row stride of the A tile (conflict-free fragment reads)
+
+// ---- plan -------------------------------------------------------------------------------------------------
+// layout of the plan buffer for (m rows, kvol offsets), n_tiles = round_up(m, 1024) / 16:
+//   rows i32 [n_tiles][16] | nb i32 [n_tiles][kvol][16] | vm u32 [n_tiles][32]   (vm[.][31] = active offsets)
+struct PlanView {
+  int* rows;
+  int* nb;
+  unsigned* vm;
+  long long n_tiles;
+};
+
+__host__ __device__ inline long long plan_tiles(long long m) { return (m + kChunkRows - 1) / kChunkRows * (kChunkRows / 16); }
+
+inline size_t plan_bytes(long long m, int kvol) {
+  const long long t = plan_tiles(m);
+  return (size_t)t * 16 * 4 + (size_t)t * kvol * 16 * 4 + (size_t)t * 32 * 4;
+}
+
+inline PlanView plan_view(void* p, long long m, int kvol) {
+  PlanView v;
+  v.n_tiles = plan_tiles(m);
+  v.rows = static_cast<int*>(p);
+  v.nb = v.rows + v.n_tiles * 16;
+  v.vm = reinterpret_cast<unsigned*>(v.nb + v.n_tiles * kvol * 16);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) tile_plan_kernel(const int* __restrict__ nbr, long long m, int kvol, int* __restrict__ rows,
+                                                         int* __restrict__ nb, unsigned* __restrict__ vm) {
+  __shared__ unsigned long long keys[kChunkRows];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const long long c0 = (long long)blockIdx.x * kChunkRows;
+#pragma unroll
+  for (int q = 0; q < kChunkRows / 256; ++q) {
+    const int li = tid + 256 * q;
+    const long long r = c0 + li;
+    unsigned long long key = ~0ull;  // padding rows sort last
+    if (r < m) {
+      unsigned mask = 0;
+      for (int k = 0; k < kvol; ++k) mask |= (nbr[(long long)k * m + r] >= 0 ? 1u : 0u) << k;
+      key = ((unsigned long long)mask << 10) | (unsigned)li;
+    }
+    keys[li] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= kChunkRows; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int q = 0; q < kChunkRows / 512; ++q) {
+        const int t = tid + 256 * q;                                   // 512 compare-exchanges per stage
+        const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));  // lower element of pair t
+        const int j = i | stride;
+        const unsigned long long a = keys[i], b = keys[j];
+        const bool up = (i & size) == 0;
+        if ((a > b) == up) {
+          keys[i] = b;
+          keys[j] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kChunkRows / 256; ++q) {
+    const int p = tid + 256 * q;  // sorted position inside the chunk; 16 consecutive positions = one tile
+    const unsigned long long key = keys[p];
+    const long long r = (key == ~0ull) ? -1 : c0 + (long long)(key & 1023u);
+    const long long tile = (c0 + p) >> 4;
+    const int j = p & 15;
+    rows[tile * 16 + j] = (int)r;
+    unsigned active = 0;
+    for (int k = 0; k < kvol; ++k) {
+      const int v = (r >= 0) ? nbr[(long long)k * m + r] : -1;
+      nb[(tile * kvol + k) * 16 + j] = v;
+      const unsigned long long bal = __ballot(v >= 0);
+      const unsigned m16 = (unsigned)(bal >> (lane & 48)) & 0xffffu;
+      if (j == 0) vm[tile * 32 + k] = m16;
+      active |= (m16 ? 1u : 0u) << k;
+    }
+    if (j == 0) {
+      for (int k = kvol; k < 31; ++k) vm[tile * 32 + k] = 0;
+      vm[tile * 32 + 31] = active;
+    }
+  }
+}
+
+// ---- convolution over a plan -----------------------------------------------------------------------------------
+struct TileArgs {
+  const float* in;       // [m_in][cin]
+  const float* wp;       // packed weights (efg_spconv_pack_weight_f32 layout)
+  const float* bias;     // [cout] or null
+  const int* rows;       // plan
+  const int* nb;
+  const unsigned* vm;
+  float* out;            // [m_out][cout]
+  long long n_tiles;
+  int cin, cout, kvol;
+  int c16n, np;
+  int pipe, deal;        // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL)
+  int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
+                         // the transposed table of a symmetric window is the table with the offsets reversed)
+};
+
+template <int NT, int R, int KS>
+__global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
+  constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
+  __shared__ float a_tile[4][R * 16 * kAStr];        // wave-private A staging
+  __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wt = wv / KS, part = wv % KS;
+  // XCD-aware order: consecutive workgroups (neighbouring sorted chunks re-read the same input rows) on one XCD
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
+    if (per > 0 && lin < (per << 3)) {
+      const unsigned nl = (lin & 7) * per + (lin >> 3);
+      bx = nl % gridDim.x;
+      by = nl / gridDim.x;
+    }
+  }
+  const long long t0 = ((long long)bx * WT + wt) * R;  // first 16-row tile of this wave tile
+  const bool tile_ok = t0 < a.n_tiles;
+  if (KS == 1 && !tile_ok) return;
+  const int n_tile0 = by * NT;
+  float* at0 = a_tile[wv];
+  int* nbs = nb_tile[wt];
+
+  // masks: lane l of vmr[s] holds vm[t0 + s][l]  (l < kvol: rows of sub-tile s with a neighbour at table column l;
+  // l = 31: the sub-tile's active columns)
+  unsigned vmr[R];
+  int prow = -1;
+  if (tile_ok) {
+#pragma unroll
+    for (int s = 0; s < R; ++s) vmr[s] = (lane < 32) ? a.vm[(t0 + s) * 32 + lane] : 0u;
+    if (lane < R * 16) prow = a.rows[t0 * 16 + lane];
+    // neighbour block of the R sub-tiles: contiguous in the plan -> coalesced; row number -> byte offset
+    const int* src = a.nb + t0 * a.kvol * 16;
+    for (int e = lane + 64 * part; e < R * a.kvol * 16; e += 64 * KS) {
+      const int s = e / (a.kvol * 16), rem = e - s * (a.kvol * 16);
+      nbs[s * 512 + rem] = (int)((unsigned)max(src[e], 0) * (unsigned)a.cin * 4u);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < R; ++s) vmr[s] = 0u;
+  }
+  unsigned cols = 0;  // table columns any sub-tile of this wave tile needs
+#pragma unroll
+  for (int s = 0; s < R; ++s) cols |= (unsigned)__builtin_amdgcn_readlane((int)vmr[s], 31);
+  if (KS > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  f32x4 acc[R][NT];
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float b = 0.0f;
+      const int co = (n_tile0 + t) * 16 + (lane & 15);
+      if (a.bias && co < a.cout && part == 0) b = a.bias[co];
+      acc[s][t] = f32x4{b, b, b, b};
+    }
+
+  const int nchunk = (a.c16n * 16 + kCKt - 1) / kCKt;
+  float pre[R * 16];
+  unsigned pre_m[R];
+
+  auto gather = [&](int col, int ch) {
+    const unsigned cc4 = (unsigned)min(ch * kCKt + lane, a.cin - 1) * 4u;
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      pre_m[s] = (unsigned)__builtin_amdgcn_readlane((int)vmr[s], col);
+      if (pre_m[s]) {  // wave-uniform: a sub-tile without a neighbour at this column loads nothing
+        unsigned offs[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) offs[j] = (unsigned)nbs[s * 512 + col * 16 + j] + cc4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          pre[s * 16 + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
+      }
+    }
+  };
+  auto stash = [&](float* at) {
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+      if (pre_m[s]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) at[(s * 16 + j) * kAStr + lane] = ((pre_m[s] >> j) & 1u) ? pre[s * 16 + j] : 0.0f;
+      }
+  };
+  auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
+    const int k = a.flip ? (a.kvol - 1 - col) : col;  // weight offset of this table column
+    const int c16_lo = ch * (kCKt / 16);
+    const int m = lane & 15, kk = lane >> 4;
+    // packed weights of (k, c16, n-tile t): 16-byte fragment per lane, 1 KB per n-tile, np * 64 bytes per c16
+    const unsigned boff0 = ((((unsigned)k * (unsigned)a.c16n + (unsigned)c16_lo) * (unsigned)a.np + (unsigned)(n_tile0 * 16 + m)) * 16u +
+                            (unsigned)(kk * 4)) * 4u;
+    const unsigned bstep = (unsigned)a.np * 64u;
+    const int nc = min(kCKt / 16, a.c16n - c16_lo);  // 16-channel steps of this chunk (4 unless the tail)
+    auto load_b = [&](float4* b, int i) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
+    };
+    auto mfmas = [&](const float4* b, int i) {
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        if ((s == 0 ? m0 : m1) == 0) continue;  // wave-uniform: this sub-tile has no neighbour at the column
+        const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
+        const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t].x, acc[s][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[t].y, acc[s][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[t].z, acc[s][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[t].w, acc[s][t], 0, 0, 0);
+      }
+    };
+    // software pipeline over the (up to) four 16-channel steps: the weights of step i+1 are in flight during the
+    // MFMAs of step i (they come from L2: ~200+ cycles, a 16-MFMA step is 512)
+    float4 b0[NT], b1[NT];
+    load_b(b0, 0);
+    if (nc == 4 && a.pipe) {
+      load_b(b1, 1);
+      mfmas(b0, 0);
+      load_b(b0, 2);
+      mfmas(b1, 1);
+      load_b(b1, 3);
+      mfmas(b0, 2);
+      mfmas(b1, 3);
+    } else {
+      for (int i = 0; i < nc; ++i) {
+        if (i > 0) load_b(b0, i);
+        mfmas(b0, i);
+      }
+    }
+  };
+
+  // The (column, channel chunk) steps of the wave tile, in order, are dealt round-robin to its KS waves: every
+  // wave gets the same number of steps (+-1) whatever the number of active columns.
+  // deal = 1: the (column, channel chunk) steps of the wave tile, in order, go round-robin to its KS waves (equal
+  // step counts whatever the number of active columns); deal = 0: whole columns go round-robin (a wave reads the
+  // consecutive chunks of the same 16 rows)
+  unsigned mycols = cols;
+  if (!a.deal && KS > 1) {
+    mycols = 0;
+    unsigned r2 = cols;
+    int seen = 0;
+    while (r2) {
+      const int c = __ffs((int)r2) - 1;
+      r2 &= r2 - 1;
+      if (seen % KS == part) mycols |= 1u << c;
+      ++seen;
+    }
+  }
+  const int step_stride = a.deal ? KS : 1;
+  const int total_steps = __popc(mycols) * nchunk;
+  const int nsteps = a.deal ? (total_steps - part + KS - 1) / KS : total_steps;
+  if (nsteps > 0) {
+    unsigned rem = mycols;
+    int c_cur = __ffs((int)rem) - 1, ch_cur = 0;
+    auto advance = [&](int& c, int& ch, int n) {  // n steps forward in (column-major, chunk-minor) order
+      ch += n;
+      while (ch >= nchunk) {
+        ch -= nchunk;
+        rem &= rem - 1;
+        c = rem ? __ffs((int)rem) - 1 : 0;
+      }
+    };
+    if (a.deal) advance(c_cur, ch_cur, part);
+    gather(c_cur, ch_cur);
+    stash(at0);
+    unsigned cm0 = pre_m[0], cm1 = pre_m[R - 1];
+    for (int s = 0; s < nsteps; ++s) {
+      int c_nxt = c_cur, ch_nxt = ch_cur;
+      const bool more = (s + 1 < nsteps);
+      if (more) {
+        advance(c_nxt, ch_nxt, step_stride);
+        gather(c_nxt, ch_nxt);
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      compute(at0, c_cur, ch_cur, cm0, cm1);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more) {
+        stash(at0);
+        cm0 = pre_m[0];
+        cm1 = pre_m[R - 1];
+      }
+      c_cur = c_nxt;
+      ch_cur = ch_nxt;
+    }
+  }
+
+  if (KS > 1) {
+    // partial accumulators of the other waves of this wave tile, through the (idle) A tiles: 4 n-tiles per pass
+    __syncthreads();
+    float* red = a_tile[wv];
+#pragma unroll
+    for (int s = 0; s < R; ++s)
+      for (int tq = 0; tq < NT; tq += 4) {
+        if (part != 0) {
+#pragma unroll
+          for (int t = tq; t < NT && t < tq + 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((t - tq) * 4 + r) * 64 + lane] = acc[s][t][r];
+        }
+        __syncthreads();
+        if (part == 0) {
+          for (int p = 1; p < KS; ++p) {
+            const float* o = a_tile[wv + p];
+#pragma unroll
+            for (int t = tq; t < NT && t < tq + 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[s][t][r] += o[((t - tq) * 4 + r) * 64 + lane];
+          }
+        }
+        __syncthreads();
+      }
+    if (part != 0 || !tile_ok) return;
+  }
+  // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = (n_tile0 + t) * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = s * 16 + (lane >> 4) * 4 + r;
+        const int row = __shfl(prow, j, 64);
+        if (row >= 0 && co < a.cout) a.out[(long long)row * a.cout + co] = acc[s][t][r];
+      }
+    }
+}
+
+template <int NT, int R>
+void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
+  const long long wave_tiles = (a.n_tiles + R - 1) / R;
+  if (ks == 4) {
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 4>), dim3((unsigned)wave_tiles, ny), dim3(256), 0, stream, a);
+  } else if (ks == 2) {
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 2>), dim3((unsigned)ceil_div(wave_tiles, 2), ny), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 1>), dim3((unsigned)ceil_div(wave_tiles, 4), ny), dim3(256), 0, stream, a);
+  }
+}
+
+int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
+              const void* plan, int64_t m_out, float* out, int flip, hipStream_t stream) {
+  EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
+  EFG_CHECK_ARG(kvol >= 1 && kvol <= 31, "spconv tiled: kernel volume must be in [1,31], got %d", kvol);
+  if (m_out == 0) return EFG_OK;
+  EFG_CHECK_ARG(m_in >= 0 && (unsigned long long)m_in * (unsigned long long)cin * 4ull < (1ull << 32),
+                "spconv tiled: input features of %lld x %d floats exceed the 4 GB the gather addresses", (long long)m_in, cin);
+  const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
+  TileArgs a;
+  a.in = in;
+  a.wp = wp;
+  a.bias = bias;
+  a.rows = pv.rows;
+  a.nb = pv.nb;
+  a.vm = pv.vm;
+  a.out = out;
+  a.n_tiles = pv.n_tiles;
+  a.cin = cin;
+  a.cout = cout;
+  a.kvol = kvol;
+  a.c16n = (cin + 15) / 16;
+  a.np = (cout + 15) / 16 * 16;
+  a.flip = flip;
+  const int ntiles = a.np / 16;
+  // R = 2 sub-tiles per wave (weights loaded once for 32 rows) once the level has enough row tiles to fill the chip
+  // that way; n-tiles per wave as many as the grid allows (A reuse); offsets split over the 4 waves of a workgroup
+  // (KS) on the small levels, where a wave would otherwise walk ~20 offsets x 4 channel chunks alone.
+  // Launch shape (scripts/tile_sweep.sh, profiles/r02_tile_sweep.txt).  These kernels are latency-bound rather than
+  // MFMA-bound (PMC: matrix pipe 50-60 % busy with 2-4 waves per SIMD), so the shape maximises waves in flight:
+  //  * KS = 4: the (offset, chunk) steps of a row tile are dealt to the 4 waves of its workgroup (3x3x3 windows);
+  //  * R = 2 sub-tiles per wave + software-pipelined weight loads once a step is long enough to amortise the extra
+  //    registers (submanifold layers with cin >= 128; the strided layers' sparse tables lose with it), else R = 1;
+  //  * NT = min(4, n-tiles): 64 output channels per wave, wider outputs tile over grid.y (each re-gathers A).
+  static const int r_env = getenv("EFG_TILE_R") ? atoi(getenv("EFG_TILE_R")) : 0;
+  static const int ks_env = getenv("EFG_TILE_KS") ? atoi(getenv("EFG_TILE_KS")) : 0;
+  static const int nt_env = getenv("EFG_TILE_NT") ? atoi(getenv("EFG_TILE_NT")) : 0;
+  static const int pipe_env = getenv("EFG_TILE_PIPE") ? atoi(getenv("EFG_TILE_PIPE")) : -1;
+  static const int deal_env = getenv("EFG_TILE_DEAL") ? atoi(getenv("EFG_TILE_DEAL")) : 1;
+  const long long tiles16 = ceil_div(m_out, 16);
+  int nt = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+  if (nt_env > 0) nt = nt_env <= 1 ? 1 : (nt_env <= 2 ? 2 : 4);
+  const int ny = (ntiles + nt - 1) / nt;
+  int r = (cin >= 128 && nt >= 4 && kvol >= 8 && m_in == m_out) ? 2 : 1;  // (submanifold: dense tables)
+  if (r_env > 0) r = r_env >= 2 ? 2 : 1;
+  int ks = (kvol >= 8) ? 4 : 1;
+  if (ks_env > 0) ks = ks_env >= 4 ? 4 : (ks_env >= 2 ? 2 : 1);
+  a.pipe = pipe_env >= 0 ? pipe_env : (r == 2 ? 1 : 0);
+  a.deal = deal_env;
+  (void)tiles16;
+  if (r == 2) {
+    switch (nt) {
+      case 4: launch_tiles<4, 2>(a, ny, ks, stream); break;
+      case 2: launch_tiles<2, 2>(a, ny, ks, stream); break;
+      default: launch_tiles<1, 2>(a, ny, ks, stream); break;
+    }
+  } else {
+    switch (nt) {
+      case 4: launch_tiles<4, 1>(a, ny, ks, stream); break;
+      case 2: launch_tiles<2, 1>(a, ny, ks, stream); break;
+      default: launch_tiles<1, 1>(a, ny, ks, stream); break;
+    }
+  }
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" size_t efg_spconv_tile_plan_bytes(int64_t m, int kvol) {
+  if (m < 0 || kvol < 1 || kvol > 31) return 0;
+  return plan_bytes(m, kvol) + 256;
+}
+
+extern "C" int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, size_t plan_bytes_given,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(m >= 0 && m < (1ll << 31) && kvol >= 1 && kvol <= 31, "tile_plan: bad sizes (m=%lld, kvol=%d)", (long long)m, kvol);
+  if (m == 0) return EFG_OK;
+  EFG_CHECK_ARG(nbr && plan && plan_bytes_given >= plan_bytes(m, kvol), "tile_plan: null pointer / plan buffer too small");
+  const PlanView pv = plan_view(plan, m, kvol);
+  hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)ceil_div(m, kChunkRows)), dim3(256), 0, stream, nbr, (long long)m, kvol,
+                     pv.rows, pv.nb, pv.vm);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
+                                            const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
+                                            int flip_offsets, float* out_feat, void* stream) {
+  return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets,
+                   (hipStream_t)stream);
+}

@@ -72,6 +72,30 @@ def _build_rnbr(nbr, m_out, kvol, m_in):
     return (r[:, :m_in] if m_in > 0 else r[:, :0]).contiguous()
 
 
+def _tiled():
+    """Mask-sorted row tiles (csrc/spconv_tiles.hip) for forward / dgrad; EFG_CONV_TILED=0 = generation-one kernels."""
+    return os.environ.get("EFG_CONV_TILED", "1") != "0"
+
+
+def _tile_kernel_name(n_out_channels):
+    """Label of a tiled launch: the NT (16-column tiles per wave) instantiation, csrc/spconv_tiles.hip:run_tiles."""
+    ntiles = (n_out_channels + 15) // 16
+    return "conv_tile_kernel<%d>" % (4 if ntiles >= 4 else 2 if ntiles >= 2 else 1)
+
+
+def _build_plan(table, m, kvol):
+    """Tile plan (uint8 buffer) of a neighbour table int32 [kvol, m]; None for an empty table."""
+    if m == 0:
+        return None
+    lib = L.lib()
+    nbytes = lib.efg_spconv_tile_plan_bytes(m, kvol)
+    if nbytes == 0:
+        raise RuntimeError("efg_hip: tile plan needs kvol <= 31, got %d" % kvol)
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+    L.check(lib.efg_spconv_tile_plan(L.ptr(table), m, kvol, L.ptr(plan), nbytes, L.stream()))
+    return plan
+
+
 def _conv_forward(features, w, bias, rb):
     """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
     lib = L.lib()
@@ -80,6 +104,12 @@ def _conv_forward(features, w, bias, rb):
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
+    if _tiled() and kvol <= 31 and rb.m_out > 0:
+        plan = rb.plan_fwd()
+        with _prof.timed(_tile_kernel_name(cout), _Cost(rb, cin, cout, "fwd")):
+            L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout,
+                                                     kvol, L.ptr(plan), rb.m_out, 0, L.ptr(out), L.stream()))
+        return out
     with _prof.timed(_fwd_kernel_name(cout, rb.m_out, kvol), _Cost(rb, cin, cout, "fwd")):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
                                            L.ptr(rb.nbr), rb.m_out, L.ptr(out), L.stream()))
@@ -93,6 +123,12 @@ def _conv_dgrad(grad_out, w, rb):
                          device=grad_out.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
+    if _tiled() and kvol <= 31 and rb.m_in > 0:
+        plan, flip = rb.plan_dgrad()
+        with _prof.timed(_tile_kernel_name(cin), _Cost(rb, cin, cout, "dgrad")):
+            L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), None, cin, kvol,
+                                                     L.ptr(plan), rb.m_in, flip, L.ptr(grad_in), L.stream()))
+        return grad_in
     rnbr = rb.rnbr
     order = rb.dgrad_order()
     with _prof.timed(_fwd_kernel_name(cin, rb.m_in, kvol), _Cost(rb, cin, cout, "dgrad")):
@@ -247,6 +283,28 @@ class Rulebook:
         self._rnbr = None
         self._pairs = None
         self._order = None
+        self._plan_fwd = None
+        self._plan_dgrad = None
+
+    def plan_fwd(self):
+        """Tile plan of `nbr` (csrc/spconv_tiles.hip), built on first use on the geometry stream when one is active."""
+        if self._plan_fwd is None:
+            with _on_geometry_stream() as main:
+                self._plan_fwd = _build_plan(self.nbr, self.m_out, self.kvol)
+                _hand_over(main, self._plan_fwd)
+        return self._plan_fwd
+
+    def plan_dgrad(self):
+        """(plan, flip): submanifold -> the forward plan walked with reversed offsets (the transposed table of a
+        symmetric window is the table with its offsets reversed); strided -> the plan of `rnbr`."""
+        if self.subm:
+            return self.plan_fwd(), 1
+        if self._plan_dgrad is None:
+            rnbr = self.rnbr
+            with _on_geometry_stream() as main:
+                self._plan_dgrad = _build_plan(rnbr, self.m_in, self.kvol)
+                _hand_over(main, self._plan_dgrad)
+        return self._plan_dgrad, 0
 
     def dgrad_order(self):
         """int32 [m_in] row order for the dgrad of a strided geometry: input rows grouped by coordinate parity, so the

@@ -148,6 +148,22 @@ int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const fl
 int efg_spconv_dgrad_f32(const float* grad_out, int64_t m_out, int cout, const float* packed_weight, int cin,
                          int kvol, const int32_t* rnbr, int64_t m_in, const int32_t* row_order, float* grad_in,
                          void* stream);
+/* ---- mask-sorted row tiles (csrc/spconv_tiles.hip) ------------------------------------------------------------
+ * A tile plan of a neighbour table `nbr` [kvol][m]: the rows re-ordered inside chunks of 1024 consecutive rows by
+ * their kernel-offset mask, cut into 16-row tiles, with the neighbour columns in tile-major order and per-offset
+ * validity masks.  Geometry only (no features, no weights): build once per table, reuse for every convolution that
+ * walks it.  kvol <= 31.  Replaces spconv's "mask sort" of the implicit-GEMM rulebook (third-party, not in the
+ * reference tree; call sites efg/modeling/backbones/sparse_net.py:85-95,125-147). */
+size_t efg_spconv_tile_plan_bytes(int64_t m, int kvol);
+int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, size_t plan_bytes, void* stream);
+/* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:] over the plan of nbr.  flip_offsets = 1 pairs table column c
+ * with weight offset kvol-1-c: the dgrad of a submanifold conv on the FORWARD table's plan (packed: for_dgrad = 1,
+ * in = grad_out, cin/cout swapped by the caller), since the transposed table of a symmetric window is the table
+ * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0. */
+int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
+                                 const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
+                                 int flip_offsets, float* out_feat, void* stream);
+
 /* order[m]: the rows of `indices` (int32 [m][4] = b, z, y, x) grouped by the parity of (z, y, x) -- the rows of a
  * stride-2 layer's dgrad that share their set of reachable kernel offsets.  ws: 64 bytes. */
 int efg_spconv_parity_order(const int32_t* indices, int64_t m, int32_t* order, void* ws, size_t ws_bytes,
