@@ -2,9 +2,15 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A step = voxelize (GPU) -> sparse-conv backbone -> BEV/FPN -> box-attention DETR enc/dec -> losses ->
-backward -> (gradient all-reduce over RCCL) -> AdamW, on `--scenes` synthetic Waymo-shaped scenes per GPU
-that are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+A step = voxelize (GPU) -> sparse-conv backbone -> BEV/FPN -> box-attention DETR enc/dec -> 32 losses (device
+Hungarian matching) -> backward -> (gradient all-reduce over RCCL) -> AdamW + OneCycle schedule, on `--scenes`
+synthetic Waymo-shaped scenes per GPU that are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+The timed region is clean: no event records, no count read-backs for accounting.  The per-kernel numbers (`roofline`,
+`kernels`, `geometry`) come from `--profile-steps` EXTRA steps after the timed region, with HIP events on the launch
+stream around every launch of our kernels; `full_graph` is a second, shorter timing of the same step with the FPN
+levels / heads the reference evaluates and never reads; `cpu_baseline` is the reference / oracle on the
+host cores (N = 1 only).
 """
 import argparse
 import json
@@ -14,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -27,52 +34,117 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="conquer", choices=["conquer", "voxeldetr", "centerpoint"],
+                    help="conquer = BASELINE configs[1]/[2] (default); voxeldetr = the plain variant; centerpoint = "
+                         "configs[0]/[3] (VoxelNet: reader -> SpMiddleResNetFHD -> RPN -> CenterHead)")
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (configs[1]: batch 2; configs[2]: 16 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--sweeps", type=int, default=1, help="4 = the 720k-point multi-sweep cloud of configs[3] (6 features)")
     ap.add_argument("--queries", type=int, default=1000, help="reference YAML default (configs[2] names 900)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra, untimed steps with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-graph", action="store_true", help="also evaluate the unused FPN levels like the reference")
+    ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")
+    ap.add_argument("--full-graph", action="store_true", help="make the full reference graph the headline run")
     return ap.parse_args()
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json,
-    produced on the GPU box by scripts/round_profile.sh + scripts/pmc_to_json.py), or None."""
+    """HBM bytes per launch of `kernel` from this round's committed rocprofv3 --pmc passes over THIS command
+    (profiles/pmc_latest.json, written on the GPU box by scripts/round_profile.sh + scripts/pmc_to_json.py; counters
+    cannot be read from inside the process), or None when the file has no entry for the kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
-            kernels = json.load(f)["kernels"]
+            doc = json.load(f)
+        kernels = doc["kernels"]
         if kernel not in kernels and "+" in kernel:  # "a+b": a label that times two kernels together
             parts = kernel.split("+")
             if all(k in kernels for k in parts):
-                return sum(kernels[k]["hbm_bytes_per_launch"] for k in parts)
-        return kernels[kernel]["hbm_bytes_per_launch"]
+                return sum(kernels[k]["hbm_bytes_per_launch"] for k in parts), doc.get("source")
+        return kernels[kernel]["hbm_bytes_per_launch"], doc.get("source")
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(args):
-    """The same train step on the host cores with the ORACLE standing in for every HIP op
-    (oracle/cpu_backend.py) -- a bounded sample: ONE config-0 sized scene (16k points)."""
+    """Host-core baseline on the GPU box (bounded: ~20-30 s), same scene size as the GPU workload:
+      * value: the whole train step (fwd + bwd + AdamW) on ONE `--points`-point scene with the ORACLE standing in for
+        every HIP op (oracle/cpu_backend.py, OpenMP C) and PyTorch CPU dense layers -- kind "port";
+      * stages: the reference's own voxelizer (oracle/_ref = voxelization_cpu.cpp compiled in place, 1 thread, the
+        loop is serial) when it was built, the oracle voxelizer, and the oracle sparse backbone forward."""
+    import numpy as np
+
     import oracle  # noqa: F401  (test/bench-only checker)
     from oracle import cpu_backend
 
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
     from efg_amd.engine import Trainer, synthetic_batch
 
     cores = min(os.cpu_count() or 1, 16)  # more threads only add oversubscription on this workload
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
+    stages = {}
+    pts = make_scene(1000, n_points=args.points, n_sweeps=args.sweeps)[0]
+    cap = 120000 if args.sweeps == 1 else 200000
+    t0 = time.perf_counter()
+    v, c, n = oracle.hard_voxelize(pts, VOXEL_SIZE, PC_RANGE, 5, cap)
+    stages["hard_voxelize oracle (C, 1 thread) s/scene"] = round(time.perf_counter() - t0, 4)
+    if oracle.ref_available():
+        t0 = time.perf_counter()
+        oracle.hard_voxelize(pts, VOXEL_SIZE, PC_RANGE, 5, cap, use_ref=True)
+        stages["hard_voxelize REFERENCE voxelization_cpu.cpp (1 thread) s/scene"] = round(time.perf_counter() - t0, 4)
+    stages["voxels/scene"] = int(v.shape[0])
     tr = Trainer(device="cpu", overrides={"model.transformer.num_queries": args.queries}, seed=0, ddp=False)
-    batch = synthetic_batch(1000, 1, n_points=16000)
+    batch = synthetic_batch(1000, 1, n_points=args.points, n_sweeps=args.sweeps)
     with cpu_backend.install():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            tr.model.backbone.extractor.bottom_up(torch.from_numpy(oracle.voxel_mean(v, n)),
+                                                  torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), 1, [1504, 1504, 40])
+        stages["sparse backbone forward (oracle C, OpenMP) s/scene"] = round(time.perf_counter() - t0, 3)
         t0 = time.perf_counter()
         tr.step(batch)
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "1 train step (fwd+bwd+AdamW) on 1 synthetic scene of 16k points (BASELINE config 0 cloud), "
-                      "full ConQueR model (%d queries), oracle C ops (OpenMP) + PyTorch CPU dense layers, %.1f s" % (
-                          args.queries, dt)}
+    tr.close()
+    cpu = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port", "cpu": cpu,
+            "sample": "1 train step (fwd+bwd+AdamW) on 1 synthetic scene of %d points (the GPU workload's scene size), "
+                      "full ConQueR model (%d queries), oracle C ops (OpenMP) + PyTorch CPU dense layers, %.1f s"
+                      % (args.points, args.queries, dt),
+            "stages": stages}
+
+
+def _geometry_report(trainer, batch):
+    """N, M per level and pairs per sparse-conv table of one batch (SURVEY.md §8d asks for them beside every GB/s
+    figure).  One untimed forward of the backbone with a spy on the rulebook constructor."""
+    import efg_amd.spconv.core as core
+
+    seen = []
+    orig = core.Rulebook.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        seen.append(self)
+
+    core.Rulebook.__init__ = spy
+    try:
+        model = trainer.model
+        with torch.no_grad():
+            voxels, coords, npv, shape, mean = model._inputs(batch)
+            model.backbone(voxels, coords, npv, len(batch), shape, mean)
+    finally:
+        core.Rulebook.__init__ = orig
+    torch.cuda.synchronize()
+    n_points = int(sum(b[0]["points"].shape[0] for b in batch))
+    tables = [{"kind": "subm" if rb.subm else "strided", "kvol": rb.kvol, "m_in": rb.m_in, "m_out": rb.m_out,
+               "pairs": rb.num_pairs()} for rb in seen]
+    return {"points": n_points, "input_voxels": int(coords.shape[0]), "tables": tables}
 
 
 def main():
@@ -83,38 +155,46 @@ def main():
     rank, local_rank, world = init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    if args.model == "centerpoint":
+        from efg_amd.centerpoint.bench import run as run_centerpoint
+
+        return run_centerpoint(args, rank, local_rank, world, dev)
+    config = None if args.model == "conquer" else os.path.join(ROOT, "configs", "voxeldetr_waymo_res18.yaml")
     overrides = {"model.transformer.num_queries": args.queries}
     if args.full_graph:
         overrides["model.eval_unused_levels"] = True
-    trainer = Trainer(device=dev, overrides=overrides, seed=0)
+    trainer = Trainer(config=config, device=dev, overrides=overrides, seed=0)
     # rank-sharded scenes: scene ids are disjoint across ranks (weak scaling: fixed per-GPU work)
-    pool = [synthetic_batch(2000 + 100 * p + rank * args.scenes, args.scenes, n_points=args.points, device=dev)
-            for p in range(args.pool)]
+    pool = [synthetic_batch(2000 + 100 * p + rank * args.scenes, args.scenes, n_points=args.points, device=dev,
+                            n_sweeps=args.sweeps) for p in range(args.pool)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup == 0:
-        # lazy initialisation (code-object load, MIOpen find, TunableOp validation: ~8 s in the first step of a fresh
-        # process, scripts/ubench/first_steps.py) is start-up, not a step; with W >= 1 the warm-up absorbs it
-        trainer.step(pool[0])
-    for w in range(args.warmup):
-        trainer.step(pool[w % len(pool)])
-    barrier()
-    _prof.enable(True)
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        trainer.step(pool[s % len(pool)])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _prof.enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run(tr, steps, warmup):
+        if warmup == 0:
+            # lazy initialisation (code-object load, MIOpen find, TunableOp validation: ~8 s in the first step of a
+            # fresh process, scripts/ubench/first_steps.py) is start-up, not a step; with W >= 1 the warm-up absorbs it
+            tr.step(pool[0])
+        for w in range(warmup):
+            tr.step(pool[w % len(pool)])
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            tr.step(pool[s % len(pool)])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    elapsed = timed_run(trainer, args.steps, args.warmup)
     scenes_total = args.scenes * world * args.steps
+    graph = "full reference graph" if args.full_graph else "unused FPN levels not evaluated"
     line = {
         "metric": "scenes/sec ConQueR 1-frame Waymo train step",
         "value": scenes_total / elapsed,
@@ -129,23 +209,60 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "ConQueR/Voxel-DETR res18 p3, 1-frame Waymo-shaped scenes, %d pts/scene, 0.1 m voxels, "
-                        "%d scenes/GPU, %d queries, fwd+bwd+AdamW%s" % (args.points, args.scenes, args.queries,
-                                                                     ", full reference graph" if args.full_graph
-                                                                     else ", unused FPN levels not evaluated"),
+            "workload": "%s res18 p3, %d-sweep Waymo-shaped scenes, %d pts/scene, 0.1 m voxels, %d scenes/GPU, %d queries, "
+                        "fwd+bwd+AdamW+OneCycle, %s" % ({"conquer": "ConQueR", "voxeldetr": "Voxel-DETR"}[args.model],
+                                                        args.sweeps, args.points, args.scenes, args.queries, graph),
             "global_batch": args.scenes * world,
             "parallelism": "dp%d" % world,
         },
     }
+    # ---- per-kernel numbers: extra steps, outside the timed region ------------------------------------------------
+    if args.profile_steps > 0:
+        _prof.enable(True)
+        for s in range(args.profile_steps):
+            trainer.step(pool[s % len(pool)])
+        barrier()
+        _prof.enable(False)
     if rank == 0:
-        roof = _prof.roofline()
+        summ = _prof.summary() if args.profile_steps > 0 else {}
+        roof = _prof.roofline() if summ else None
         if roof is not None:
-            roof["traffic"] = _pmc_traffic(roof["kernel"])
+            roof["traffic"], roof["traffic_source"] = _pmc_traffic(roof["kernel"])
+            roof["measured"] = "HIP events on the launch stream, %d extra steps after the timed region" % args.profile_steps
         line["roofline"] = roof
-        line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
+        line["kernels"] = {k: {"launches_per_step": round(v["launches"] / max(args.profile_steps, 1), 1),
+                               "avg_us": round(v["avg_us"], 1),
                                "GBps_alg": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1),
                                "TFLOPs_alg": round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 2)}
-                           for k, v in sorted(_prof.summary().items())}
+                           for k, v in sorted(summ.items())}
+        # BASELINE's second metric: voxelize + spconv algorithmic HBM GB/s (fraction of the 8 TB/s roof)
+        vox = {k: v for k, v in summ.items() if k.startswith("hard_voxelize")}
+        conv = {k: v for k, v in summ.items() if k.startswith("conv_")}
+        for name, grp in (("voxelize", vox), ("spconv", conv)):
+            ms = sum(v["total_ms"] for v in grp.values())
+            if ms > 0:
+                gbs = sum(v["bytes"] for v in grp.values()) / ms / 1e6
+                line[name + "_hbm"] = {"GBps_alg": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
+                                       "ms_per_step": round(ms / max(args.profile_steps, 1), 3)}
+        try:
+            line["geometry"] = _geometry_report(trainer, pool[0])
+        except Exception as exc:  # accounting only
+            line["geometry"] = {"error": str(exc)}
+    trainer.close()
+    # ---- the same step with the reference's dead branches evaluated ----------------------------------
+    if not args.no_full_graph and not args.full_graph and world == 1:
+        del trainer
+        torch.cuda.empty_cache()
+        ov = dict(overrides)
+        ov["model.eval_unused_levels"] = True
+        full = Trainer(config=config, device=dev, overrides=ov, seed=0)
+        steps = max(5, args.steps // 2)
+        e2 = timed_run(full, steps, 3)
+        full.close()
+        line["full_graph"] = {"ms_per_step": 1000.0 * e2 / steps, "value": args.scenes * steps / e2, "steps": steps,
+                              "note": "also evaluates FPN p2 / p4-output / p5 and res2_out like the reference; "
+                                      "same losses and gradients"}
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))

@@ -221,6 +221,14 @@ class VoxelDETR(nn.Module):
                 feats_pos = self.backbone(voxels, coords, num_points_per_voxel, batch_size, input_shape, voxel_mean)
             features = [self._project(self.input_proj[i], fp[0]) for i, fp in enumerate(feats_pos)]
         pos_encodings = [fp[1] for fp in feats_pos]
+        watch = getattr(self, "grad_watch", None)
+        if watch is not None and self.training:
+            # data-parallel exchange in buckets (engine.BucketedGradientAllReduce): the gradient of these activations
+            # marks the moment backward has finished the transformer, resp. the neck
+            for f in features:
+                watch("transformer", f)
+            for t in getattr(self.backbone.extractor, "last_bottom_up", {}).values():
+                watch("neck", t)
         dn = self.config.model.dn if self.is_conquer else None
         if self.training and dn is not None and dn.enabled and dn.dn_number > 0:
             with record_function("efg::cdn"):

@@ -191,6 +191,108 @@ def build_one_cycle(cfg, optimizer, max_iters):
     return torch.optim.lr_scheduler.OneCycleLR(optimizer, cfg.solver.optimizer.lr, total_steps=int(max_iters), **kw)
 
 
+class BucketedGradientAllReduce:
+    """EFG_DDP_MODE=bucket: the gradient exchange in THREE flat buckets, each reduced as soon as backward has produced
+    it, on a communication stream that depends on the compute stream -- the overlap the reference gets from DDP's
+    reducer (efg/engine/trainer.py:191-198) without a hook per parameter (~300 Python callbacks and bucket copies on
+    the backward thread of a step that is host-bound already).
+
+    Buckets follow the order backward finishes them: [transformer + heads + contrastive MLPs] -> [input projection +
+    FPN] -> [sparse backbone].  The trigger for the first two is ONE tensor hook each, on the activation that enters
+    that part of the model (the projected BEV tokens; the dense BEV maps of the backbone): when its gradient exists,
+    every backward node of the part has run and so have their AccumulateGrad nodes (the engine gives those the highest
+    priority); should a gradient of the bucket be missing at that moment it is simply picked up by the final call.
+    `reduce()` after backward handles the last bucket and joins the communication stream."""
+
+    def __init__(self, model, world):
+        self.model, self.world = model, world
+        self.flat = FlatGradientAllReduce(model, world)  # (broadcasts the initial parameters)
+        self.avg = self.flat.avg
+        self.groups = None
+        self.comm = None
+        self.pending = []
+        self.done = set()
+
+    def _build(self):
+        names = {"transformer": [], "neck": [], "backbone": []}
+        for n, p in self.model.named_parameters():
+            if not p.requires_grad:
+                continue
+            if n.startswith("backbone.extractor.bottom_up."):
+                names["backbone"].append(p)
+            elif n.startswith("backbone.") or n.startswith("input_proj."):
+                names["neck"].append(p)
+            else:
+                names["transformer"].append(p)
+        self.groups = names
+
+    def _launch(self, key):
+        """Pack the gradients of bucket `key` that exist and all-reduce them on the communication stream."""
+        if key in self.done:
+            return
+        params = [p for p in self.groups[key] if p.grad is not None]
+        self.done.add(key)
+        if not params:
+            return
+        dev = params[0].device
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        total = sum(p.numel() for p in params)
+        buf = self.__dict__.setdefault("_bufs", {}).get(key)
+        if buf is None or buf.numel() != total:
+            buf = self._bufs[key] = torch.empty(total, dtype=params[0].dtype, device=dev)
+        views, off = [], 0
+        for p in params:
+            views.append(buf[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        torch._foreach_copy_(views, [p.grad for p in params])  # on the compute stream, right behind the producers
+        if main is not None:
+            if self.comm is None:
+                self.comm = torch.cuda.Stream(device=dev)
+            self.comm.wait_stream(main)
+            with torch.cuda.stream(self.comm):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
+        self.pending.append((work, buf, params, views))
+
+    def watch(self, key, tensor):
+        """Called by the model hooks installed in Trainer: `tensor` is the activation entering part `key`."""
+        if tensor.requires_grad:
+            tensor.register_hook(lambda g, key=key: (self._launch(key), None)[1])
+
+    @torch.no_grad()
+    def begin_step(self):
+        if self.groups is None:
+            self._build()
+        self.done.clear()
+        self.pending.clear()
+
+    @torch.no_grad()
+    def reduce(self):
+        for key in ("transformer", "neck", "backbone"):  # whatever the hooks did not launch (always: backbone)
+            self._launch(key)
+        # gradients that appeared after their bucket was packed (should not happen; correctness does not depend on it)
+        late = [p for key in self.groups for p in self.groups[key]
+                if p.grad is not None and not any(p is q for _, _, ps, _ in self.pending for q in ps)]
+        if late:
+            flat = torch.cat([p.grad.reshape(-1) for p in late])
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM)
+            if not self.avg:
+                flat.div_(self.world)
+            off = 0
+            for p in late:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        for work, buf, params, views in self.pending:
+            work.wait()  # orders the compute stream after the collective (device side)
+            if not self.avg:
+                buf.div_(self.world)
+            for p, v in zip(params, views):
+                p.grad = v
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
 class Trainer:
     """step() = the reference's `DefaultTrainer.step` + `Optimization.after_step` + `LRScheduler.after_step`
     (efg/engine/trainer.py:278-305, efg/engine/hooks.py:68-81,118-121): zero_grad, forward, sum of the differentiable
@@ -235,6 +337,9 @@ class Trainer:
             mode = os.environ.get("EFG_DDP_MODE", "flat")
             if mode == "flat":
                 self.grad_sync = FlatGradientAllReduce(self.model, world)
+            elif mode == "bucket":
+                self.grad_sync = BucketedGradientAllReduce(self.model, world)
+                self.model.grad_watch = self.grad_sync.watch
             else:
                 kw = {}
                 if mode == "find_unused":
@@ -242,7 +347,7 @@ class Trainer:
                 elif mode == "static":
                     kw["static_graph"] = True
                 elif mode != "plain":
-                    raise ValueError("EFG_DDP_MODE must be flat, static, find_unused or plain, got %r" % mode)
+                    raise ValueError("EFG_DDP_MODE must be flat, bucket, static, find_unused or plain, got %r" % mode)
                 dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
                 self.wrapped = torch.nn.parallel.DistributedDataParallel(
                     self.model, device_ids=dev_ids, broadcast_buffers=False,
@@ -306,6 +411,8 @@ class Trainer:
         if self._manual_gc:
             self._collect_garbage()
         self.optimizer.zero_grad(set_to_none=True)
+        if hasattr(self.grad_sync, "begin_step"):
+            self.grad_sync.begin_step()
         with record_function("efg::forward"):
             loss_dict = self.wrapped(batch)
             # one stack + sum instead of 31 chained scalar adds (and as many backward nodes)

@@ -14,6 +14,7 @@ from torch.autograd import Function
 from torch.nn.modules.utils import _pair
 
 from .. import _lib as L
+from .. import _prof
 
 
 def dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3):
@@ -137,9 +138,15 @@ def voxelize_concat(points, offsets, voxel_size, coors_range, max_points, max_vo
     npv = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, f), dtype=torch.float32, device=dev) if with_mean else None
     voxel_num = torch.zeros(batch, dtype=torch.int32, device=dev)
-    _hard_voxelize_launch(points, offsets, voxel_size, coors_range, max_points, max_voxels, voxels, coors, npv,
-                          voxel_num, mean)
+    box = {}
+    n_total = int(offsets[-1])
+    # algorithmic bytes: read 4F per point; write voxels + coordinates + count (+ mean) per voxel
+    cost = lambda: (4 * f * n_total + box.get("m", 0) * (4 * max_points * f + 16 + 4 + (4 * f if with_mean else 0)), 0)  # noqa: E731
+    with _prof.timed("hard_voxelize (all kernels, batched)", cost):
+        _hard_voxelize_launch(points, offsets, voxel_size, coors_range, max_points, max_voxels, voxels, coors, npv,
+                              voxel_num, mean)
     counts = voxel_num.tolist()  # the one sync
+    box["m"] = sum(counts)
     m = sum(counts)
     out = {
         "voxels": voxels[:m],

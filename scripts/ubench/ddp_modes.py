@@ -10,7 +10,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import efg_amd  # noqa: E402,F401  (GPU_MAX_HW_QUEUES default)
+from efg_amd.engine import configure_hip_runtime  # noqa: E402
+
+configure_hip_runtime()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -33,9 +33,10 @@ def _worker(rank, world, port, out, mode):
     ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
     tr = Trainer(device="cpu", overrides=ov, seed=0, ddp=True)
     tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
-    # three steps: the flat buffer is laid out in step 1; DDP's static_graph steady state starts at step 2
+    # two steps: the flat / bucket buffers are laid out in step 1 and reused in step 2; DDP's static_graph steady
+    # state starts at step 2
     with cpu_backend.install():
-        for it in range(3 if mode == "flat" else 2):
+        for it in range(2):
             batch = synthetic_batch(500 + 10 * it + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
             loss_dict, total = tr.step(batch)
     w = tr.model.backbone.extractor.bottom_up.stem.conv1[0].weight
@@ -50,13 +51,12 @@ def _worker(rank, world, port, out, mode):
         out["params_equal"] = bool(torch.equal(pw[0], pw[1]))                  # same update on every rank, every parameter
         out["finite"] = bool(torch.isfinite(total))
         out["grad_norm"] = float(g.norm())
-        out["mode"] = "flat" if tr.grad_sync is not None else ("static" if getattr(tr.wrapped, "static_graph", False) else "other")
+        out["loss"] = float(total)
+        out["mode"] = type(tr.grad_sync).__name__.replace("GradientAllReduce", "").lower().replace("bucketed", "bucket") if tr.grad_sync is not None else ("static" if getattr(tr.wrapped, "static_graph", False) else "other")
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["flat", "static"])
-def test_two_rank_ddp_step(oracle_mod, mode):
+def _run(mode):
     port = _free_port()
     with mp.Manager() as mgr:
         out = mgr.dict()
@@ -64,3 +64,16 @@ def test_two_rank_ddp_step(oracle_mod, mode):
         res = dict(out)
     assert res["finite"] and res["grads_equal"] and res["params_equal"] and res["grad_norm"] > 0
     assert res["mode"] == mode
+    return res
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_flat_and_bucketed_exchange_agree(oracle_mod):
+    flat, bucket = _run("flat"), _run("bucket")
+    assert bucket["grad_norm"] == pytest.approx(flat["grad_norm"], rel=1e-5)  # the same averaged gradient
+    assert bucket["loss"] == pytest.approx(flat["loss"], rel=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_torch_ddp_wrapper(oracle_mod):
+    _run("static")
