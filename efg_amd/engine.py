@@ -176,6 +176,24 @@ class FlatGradientAllReduce:
 REFERENCE_MAX_ITERS = 6 * (158081 // (6 * 8))
 
 
+def build_optimizer(cfg, model):
+    """`solver.optimizer.type`: AdamWMulti (ConQueR / Voxel-DETR: per-group rates, $CQ/modules/optimizer.py) or AdamW
+    (CenterPoint, efg/solver/optimizers.py:23-40); torch's fused multi-tensor update on the GPU."""
+    oc = dict(cfg.solver.optimizer)
+    kind = oc.pop("type", "AdamWMulti")
+    if kind == "AdamWMulti":
+        return build_adamw_multi(cfg, model)
+    if kind != "AdamW":
+        raise ValueError("optimizer %r is not mirrored (AdamWMulti | AdamW)" % kind)
+    oc["betas"] = tuple(oc["betas"])
+    params = [p for p in model.parameters() if p.requires_grad]
+    if all(p.is_cuda for p in params):
+        from .detection3d.optimizer import CachedFusedAdamW
+
+        return CachedFusedAdamW([{"params": params}], **oc)
+    return torch.optim.AdamW(params, **oc)
+
+
 def build_one_cycle(cfg, optimizer, max_iters):
     """`solver.lr_scheduler: {type: OneCycle, ...}` -> torch OneCycleLR exactly as efg/solver/lr_schedulers.py:222-237
     builds it: max_lr = solver.optimizer.lr for EVERY parameter group (the scalar overrides the per-group rates of
@@ -298,7 +316,7 @@ class Trainer:
     (efg/engine/trainer.py:278-305, efg/engine/hooks.py:68-81,118-121): zero_grad, forward, sum of the differentiable
     losses, non-finite check, backward, gradient exchange, optional clipping, optimizer step, scheduler step."""
 
-    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None):
+    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None, model_cls=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
         if str(cfg.model.device if device is None else device).startswith("cuda"):
             configure_hip_runtime()
@@ -313,9 +331,9 @@ class Trainer:
                 torch.backends.cudnn.benchmark = True
         torch.manual_seed(seed)
         self.cfg = cfg
-        self.model = VoxelDETR(cfg)
+        self.model = (model_cls or VoxelDETR)(cfg)
         self.model.train()
-        self.optimizer = build_adamw_multi(cfg, self.model)
+        self.optimizer = build_optimizer(cfg, self.model)
         self.lr_scheduler = build_one_cycle(cfg, self.optimizer, max_iters or REFERENCE_MAX_ITERS)
         gc_cfg = cfg.solver.get("grad_clipper") if hasattr(cfg.solver, "get") else None
         self.grad_clipper = gc_cfg if (gc_cfg and gc_cfg.get("enabled")) else None

@@ -1,0 +1,108 @@
+"""Golden vectors from the reference's OWN CenterPoint `VoxelNet.forward` (training: label assignment, SpMiddleResNetFHD
+wiring, RPN, CenterHead, focal + L1 losses, backward), run on CPU in the build container at a reduced grid -- the
+CenterPoint twin of scripts/make_golden_full.py (same import shims; `spconv.pytorch` is the dense-masked stand-in,
+points are voxelized by the reference's numba voxelizer).  Saves tests/golden/centerpoint_full_small.npz: label
+assignment arrays, BEV / RPN maps, the 4 loss terms, selected gradients.  Weights and inputs come from
+tests/golden_init.py on both sides."""
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import make_golden_full as G  # noqa: E402
+
+CP1 = G.REF + ("/playground/detection.3d/waymo/center_point/"
+               "centerpoint.waymo.voxelnet.gt_aug.ds_sample.onecycle.adam.bs48.36e")
+
+
+def main():
+    from golden_init import CENTERPOINT_OVERRIDES, deterministic_state, full_inputs
+
+    from efg_amd.config import load_config
+
+    G.install_shims(CP1)
+    misc = G._load("ref_data_misc", G.REF + "/efg/data/utils/misc.py")
+    G._mod("efg.data.augmentations3d", _dict_select=misc._dict_select)
+    G._pkg("efg.geometry")
+    G._load("efg.geometry.box_ops_torch", G.REF + "/efg/geometry/box_ops_torch.py")
+    import voxelnet  # the reference model, imported in place
+
+    ov = dict(CENTERPOINT_OVERRIDES)
+    ov["model.device"] = "cpu"
+    cfg = load_config(os.path.join(ROOT, "configs", "centerpoint_waymo_voxelnet.yaml"), ov)
+    torch.manual_seed(0)
+    model = voxelnet.VoxelNet(cfg)
+    state = deterministic_state(model.state_dict())
+    model.load_state_dict(state, strict=True)
+    model.train()
+    points_list, annos = full_inputs()
+    names = np.array(cfg.dataset.classes)
+    for a in annos:
+        a["gt_names"] = names[a["labels"] - 1]
+    batch = G.reference_samples(cfg, points_list, copy.deepcopy(annos))
+    cap = {}
+    model.backbone.register_forward_hook(lambda m, i, o: cap.update(bev=o.detach().clone()))
+    model.neck.register_forward_hook(lambda m, i, o: cap.update(rpn=o.detach().clone()))
+    orig_assign = model.label_assign
+
+    def spy(datas, infos):
+        t = orig_assign(datas, infos)
+        cap["targets"] = t
+        return t
+
+    model.label_assign = spy
+    losses = model(batch)
+    total = sum(v for k, v in losses.items() if k.endswith("_loss") and v.requires_grad)
+    total.backward()
+    params = dict(model.named_parameters())
+    # the same reference model in float64: how far is the reference's OWN fp32 gradient from the exact one?
+    model64 = voxelnet.VoxelNet(cfg)
+    model64.load_state_dict(state, strict=True)
+    model64.double().train()
+    batch64 = G.reference_samples(cfg, points_list, copy.deepcopy(annos))
+    for smp, _ in batch64:
+        smp["voxels"] = smp["voxels"].astype(np.float64)
+    orig_collate = voxelnet.collate
+
+    def collate64(batch_list, device):
+        ret = orig_collate(batch_list, device)
+        for k in ("hm", "anno_box"):
+            if k in ret:
+                ret[k] = [t.double() for t in ret[k]]
+        return ret
+
+    voxelnet.collate = collate64
+    losses64 = model64(batch64)
+    sum(v for k, v in losses64.items() if k.endswith("_loss") and v.requires_grad).backward()
+    voxelnet.collate = orig_collate
+    p64 = dict(model64.named_parameters())
+    save = {"bev": cap["bev"], "rpn_sub": cap["rpn"][:, ::8].contiguous(), "total": total.detach(),
+            "n_params": np.array(sum(p.numel() for p in params.values()))}
+    for k, v in losses.items():
+        save["loss::" + k] = v.detach()
+    for t in range(len(cfg.model.head.tasks)):
+        for key in ("hm", "anno_box", "ind", "mask", "cat"):
+            save["tgt::%s::%d" % (key, t)] = np.stack([s[key][t] for s in cap["targets"]])
+    for n in ("backbone.conv_input.0.weight", "backbone.conv3.0.weight", "backbone.extra_conv.0.weight",
+              "neck.blocks.0.1.weight", "neck.deblocks.1.0.weight", "center_head.shared_conv.0.weight",
+              "center_head.tasks.0.hm.3.weight", "center_head.tasks.0.dim.3.bias", "center_head.tasks.0.rot.0.weight",
+              "backbone.conv1.0.conv1.bias", "neck.blocks.1.4.weight"):
+        g = params[n].grad
+        save["grad::" + n] = g[:8].contiguous() if g.numel() > 65536 else g
+        e64 = float((g.double() - p64[n].grad).abs().max() / p64[n].grad.abs().max())
+        save["graderr64::" + n] = np.array(e64)
+        print("   grad %-45s %-20s max %.3e  reference fp32-vs-fp64 err/max %.2e" % (n, tuple(g.shape), float(g.abs().max()), e64))
+    out = os.path.join(ROOT, "tests", "golden", "centerpoint_full_small.npz")
+    np.savez_compressed(out, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in save.items()})
+    print("saved", out, os.path.getsize(out) // 1024, "KiB; losses", {k: round(float(v), 6) for k, v in losses.items()})
+
+
+if __name__ == "__main__":
+    main()

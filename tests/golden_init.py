@@ -88,3 +88,10 @@ def full_inputs(seed=77, n_points=1500):
         annos.append({"gt_boxes": np.array(boxes, np.float32), "labels": np.array(labels, np.int64),
                       "difficulty": np.zeros(k, np.int64), "num_points_in_gt": np.full(k, 50, np.int64)})
     return points_list, annos
+
+# CenterPoint at the same reduced range: grid 128 x 128 x 40, BEV 16 x 16 after the 8x reduction of the backbone
+CENTERPOINT_OVERRIDES = {
+    "dataset.pc_range": [-6.4, -6.4, -2.0, 6.4, 6.4, 4.0],
+    "model.loss.max_objs": 20,
+    "model.post_process.post_center_limit_range": [-8.0, -8.0, -10.0, 8.0, 8.0, 10.0],
+}

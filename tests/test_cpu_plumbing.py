@@ -94,3 +94,31 @@ def test_reference_input_format_is_accepted(oracle_mod):
             ld = tr.model(b)
         out.append(float(sum(v for v in ld.values() if v.requires_grad)))
     assert out[0] == pytest.approx(out[1], rel=1e-5)
+
+
+def test_config0_centerpoint_train_step_on_cpu(oracle_mod):
+    """BASELINE configs[0] as named: the CenterPoint graph (mean reader -> SpMiddleResNetFHD -> RPN -> CenterHead),
+    one 16k-point synthetic cloud, batch 1, no GPU -- forward, the reference's loss dict, backward, AdamW + OneCycle +
+    gradient clipping, through the same Trainer the GPU path uses."""
+    from oracle import cpu_backend
+
+    from efg_amd.centerpoint import VoxelNet
+    from efg_amd.engine import Trainer
+
+    torch.set_num_threads(8)
+    import os
+
+    from conftest import ROOT
+
+    tr = Trainer(config=os.path.join(ROOT, "configs", "centerpoint_waymo_voxelnet.yaml"), device="cpu",
+                 model_cls=VoxelNet, ddp=False, max_iters=10)
+    assert tr.grad_clipper is not None and tr.lr_scheduler is not None      # the experiment's solver block
+    names = {n for n, _ in tr.model.named_parameters()}
+    assert {"backbone.conv_input.0.weight", "neck.blocks.1.4.weight", "neck.deblocks.1.0.weight",
+            "center_head.shared_conv.0.weight", "center_head.tasks.0.hm.3.bias"} <= names   # reference state-dict names
+    with cpu_backend.install():
+        loss_dict, total = tr.step(_batch(n_points=16000))
+    assert set(loss_dict) == {"0_loss", "0_hm_loss", "0_loc_loss", "0_num_positive"} and torch.isfinite(total)
+    assert float(loss_dict["0_num_positive"]) == 6.0
+    assert all(p.grad is not None for p in tr.model.parameters())            # find_unused_parameters: False holds
+    tr.close()
