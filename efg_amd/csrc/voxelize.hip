@@ -8,14 +8,16 @@
 // Parallel, bit-exact formulation of the serial first-come-first-kept loop:
 //   K1 insert   one open-addressing hash insert per point on a 64-bit {cell, point} word:
 //               atomicMin keeps, per occupied cell, the LOWEST point index = first occurrence;
-//   K2 count    per 1024-point tile, count the points that are the first of their voxel;
+//   K2 count    per 1024-point tile, count the points that are the first of their voxel (+ per-scene totals);
 //   K3 assign   block-scan the first-flags in POINT ORDER: voxel id = rank of its first point;
-//               rank == max_voxels marks i_break (the reference's `break`);
+//               rank == max_voxels marks i_break (the reference's `break`); scene bases / voxel counts;
 //   K4 cascade  every later point of a kept voxel inserts its index into the voxel's sorted
 //               max_points-entry list with a chain of atomicMin (carry = max(old, mine));
 //               entry r ends up holding the (r+1)-th smallest point index of the voxel;
 //   K5 gather   copy the selected points, zero padding, counts and the fused per-voxel mean.
-// All scenes of a batch are processed by one launch per stage (blockIdx.y = scene).
+// All scenes of a batch are processed by one launch per stage (blockIdx.y = scene).  Scratch that must start
+// "empty" (hash table, per-voxel lists, i_break, per-scene totals) is one contiguous region cleared by ONE 0xff
+// fill: 5 kernels + 1 memset per call.
 #include "common.h"
 
 namespace efg {
@@ -24,7 +26,7 @@ namespace {
 constexpr int kMaxBatch = 64;
 constexpr int kTile = 1024;  // points per block in the ordered stages (256 threads x 4)
 constexpr unsigned long long kEmpty = ~0ull;
-constexpr int kInf = 0x7f7f7f7f;  // memset(0x7f) pattern: "no point"
+constexpr unsigned kInf = 0xffffffffu;  // memset(0xff) pattern: "no point" (lists / i_break are unsigned)
 constexpr int kFirstFlag = 1 << 30;
 
 struct VoxGeom {
@@ -102,7 +104,7 @@ vox_insert_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom
 // K2: tag first points (kFirstFlag in slot_of_point) and count them per tile.
 __global__ void __launch_bounds__(256)
 vox_count_kernel(SceneOffsets so, const unsigned long long* __restrict__ table, int* __restrict__ slot_of_point,
-                 int* __restrict__ tile_counts, int tiles_per_scene) {
+                 int* __restrict__ tile_counts, int tiles_per_scene, int* __restrict__ scene_total) {
   __shared__ int smem[17];
   const int scene = blockIdx.y;
   const long long beg = so.off[scene], end = so.off[scene + 1];
@@ -122,40 +124,37 @@ vox_count_kernel(SceneOffsets so, const unsigned long long* __restrict__ table, 
   cnt = wave_reduce_sum(cnt);
   if (lane_id() == 0) smem[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) tile_counts[scene * tiles_per_scene + blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
-}
-
-// K2b: per scene totals -> kept voxel count and output base row (one block per launch).
-__global__ void vox_totals_kernel(const int* __restrict__ tile_counts, int tiles_per_scene, int batch, int max_voxels,
-                                  int* __restrict__ scene_base /*[batch+1]*/, int* __restrict__ voxel_num) {
-  __shared__ int tot[kMaxBatch];
-  for (int b = threadIdx.x >> 6; b < batch; b += blockDim.x >> 6) {
-    int s = 0;
-    for (int t = lane_id(); t < tiles_per_scene; t += 64) s += tile_counts[b * tiles_per_scene + t];
-    s = wave_reduce_sum(s);
-    if (lane_id() == 0) tot[b] = min(s, max_voxels);
-  }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < batch; ++b) {
-      scene_base[b] = acc;
-      voxel_num[b] = tot[b];
-      acc += tot[b];
-    }
-    scene_base[batch] = acc;
+    const int c = smem[0] + smem[1] + smem[2] + smem[3];
+    tile_counts[scene * tiles_per_scene + blockIdx.x] = c;
+    if (c) atomicAdd(&scene_total[scene], c);  // starts at -1 (the common 0xff fill): readers add 1
   }
 }
 
 // K3: voxel ids in first-occurrence order; first point goes to list entry 0.
 __global__ void __launch_bounds__(256)
 vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table, const int* __restrict__ slot_of_point,
-                  const int* __restrict__ tile_counts, int tiles_per_scene, const int* __restrict__ scene_base,
+                  const int* __restrict__ tile_counts, int tiles_per_scene, const int* __restrict__ scene_total,
+                  int batch, int* __restrict__ scene_base, int* __restrict__ voxel_num,
                   int max_voxels, int max_points, unsigned vol, VoxGeom g, int* __restrict__ vid_of_slot,
-                  int* __restrict__ lists, int* __restrict__ i_break, int* __restrict__ coors, int coors_cols) {
+                  unsigned* __restrict__ lists, unsigned* __restrict__ i_break, int* __restrict__ coors, int coors_cols) {
   __shared__ int smem[17];
   __shared__ int s_prefix;
   const int scene = blockIdx.y;
+  // output base row of this scene = kept voxels of the scenes before it (<= 64 totals: every block sums them itself;
+  // block (0, 0) publishes the table the gather kernel and the caller read)
+  int out_base = 0;
+  for (int b = 0; b < scene; ++b) out_base += min(scene_total[b] + 1, max_voxels);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < batch; ++b) {
+      const int t = min(scene_total[b] + 1, max_voxels);
+      scene_base[b] = acc;
+      voxel_num[b] = t;
+      acc += t;
+    }
+    scene_base[batch] = acc;
+  }
   const long long beg = so.off[scene], end = so.off[scene + 1];
   // firsts in earlier tiles of this scene
   int pre = 0;
@@ -176,7 +175,6 @@ vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table,
   }
   int total;
   int rank = block_exclusive_scan(cnt, smem, &total) + s_prefix;
-  const int out_base = scene_base[scene];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (slot[j] >= 0 && (slot[j] & kFirstFlag)) {
@@ -185,7 +183,7 @@ vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table,
       if (rank < max_voxels) {
         const int vid = out_base + rank;
         vid_of_slot[s] = vid;
-        lists[(long long)vid * max_points] = (int)i;
+        lists[(long long)vid * max_points] = (unsigned)i;
         unsigned cell = (unsigned)(table[s] >> 32) - (unsigned)scene * vol;
         const int cx = cell % g.grid[0];
         cell /= g.grid[0];
@@ -198,7 +196,7 @@ vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table,
         c[2] = cx;
       } else {
         vid_of_slot[s] = -1;
-        if (rank == max_voxels) i_break[scene] = (int)i;  // the point at which the reference breaks
+        if (rank == max_voxels) i_break[scene] = (unsigned)i;  // the point at which the reference breaks
       }
       ++rank;
     }
@@ -208,7 +206,7 @@ vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table,
 // K4: later points of kept voxels; sorted-list insertion by atomicMin chain.
 __global__ void __launch_bounds__(256)
 vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const int* __restrict__ vid_of_slot,
-                   const int* __restrict__ i_break, int max_points, int* __restrict__ lists) {
+                   const unsigned* __restrict__ i_break, int max_points, unsigned* __restrict__ lists) {
   const int scene = blockIdx.y;
   const long long beg = so.off[scene];
   const long long end = min(so.off[scene + 1], (long long)i_break[scene]);
@@ -218,10 +216,10 @@ vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const
     if (s < 0 || (s & kFirstFlag)) continue;
     const int vid = vid_of_slot[s];
     if (vid < 0) continue;
-    int* lst = lists + (long long)vid * max_points;
-    int carry = (int)i;
+    unsigned* lst = lists + (long long)vid * max_points;
+    unsigned carry = (unsigned)i;
     for (int r = 1; r < max_points; ++r) {
-      const int old = atomicMin(&lst[r], carry);
+      const unsigned old = atomicMin(&lst[r], carry);
       if (old == kInf) break;          // landed in an empty entry
       carry = max(old, carry);         // the larger index moves on
     }
@@ -230,7 +228,7 @@ vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const
 
 // K5: one thread per (voxel, feature): copy the <= max_points selected rows, zero pad, mean.
 __global__ void __launch_bounds__(256)
-vox_gather_kernel(const float* __restrict__ pts, int f, const int* __restrict__ lists, int max_points,
+vox_gather_kernel(const float* __restrict__ pts, int f, const unsigned* __restrict__ lists, int max_points,
                   const int* __restrict__ scene_base, int batch, float* __restrict__ voxels, int* __restrict__ npv,
                   float* __restrict__ mean) {
   const long long m = scene_base[batch];
@@ -238,11 +236,11 @@ vox_gather_kernel(const float* __restrict__ pts, int f, const int* __restrict__ 
   if (e >= m * f) return;
   const long long vid = e / f;
   const int k = (int)(e - vid * f);
-  const int* lst = lists + vid * max_points;
+  const unsigned* lst = lists + vid * max_points;
   float sum = 0.0f;
   int cnt = 0;
   for (int r = 0; r < max_points; ++r) {
-    const int idx = lst[r];
+    const unsigned idx = lst[r];
     float v = 0.0f;
     if (idx != kInf) {
       v = pts[(long long)idx * f + k];
@@ -291,7 +289,7 @@ HardLayout hard_layout(int64_t n_total, int64_t max_scene_pts, int batch, int ma
   L.vid_b = align_up((size_t)t * 4, 256);
   L.lists_b = align_up((size_t)batch * max_voxels * max_points * 4, 256);
   L.tiles_b = align_up((size_t)batch * L.tiles_per_scene * 4, 256);
-  L.small_b = align_up((size_t)(2 * kMaxBatch + 2) * 4, 256);
+  L.small_b = align_up((size_t)(2 * kMaxBatch) * 4, 256) + align_up((size_t)(kMaxBatch + 2) * 4, 256);
   return L;
 }
 
@@ -352,22 +350,24 @@ extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, i
   EFG_CHECK_ARG(n_total < (1ll << 29), "too many points");
   HardLayout L = hard_layout(n_total, max_scene, batch, max_points, max_voxels);
   Workspace w(ws, ws_bytes);
+  // [table | lists | i_break + scene_total] are contiguous: one 0xff fill makes all of them "empty"
   auto* table = w.take<unsigned long long>(L.tsize);
+  unsigned* lists = w.take<unsigned>((size_t)batch * max_voxels * max_points);
+  unsigned* cleared_small = w.take<unsigned>(2 * kMaxBatch);
   int* slot_of_point = w.take<int>(std::max<int64_t>(n_total, 1));
   int* vid_of_slot = w.take<int>(L.tsize);
-  int* lists = w.take<int>((size_t)batch * max_voxels * max_points);
   int* tile_counts = w.take<int>((size_t)batch * L.tiles_per_scene);
-  int* small = w.take<int>(2 * kMaxBatch + 2);
+  int* small = w.take<int>(kMaxBatch + 2);
   if (!w.ok) {
     set_error("hard_voxelize workspace too small: need %zu bytes, got %zu",
               efg_hard_voxelize_workspace_bytes(n_total, batch, max_points, max_voxels), ws_bytes);
     return EFG_E_WORKSPACE;
   }
-  int* scene_base = small;               // [batch+1]
-  int* i_break = small + kMaxBatch + 1;  // [batch]
-  EFG_HIP_TRY(hipMemsetAsync(table, 0xff, (size_t)L.tsize * 8, stream));
-  EFG_HIP_TRY(hipMemsetAsync(lists, 0x7f, (size_t)batch * max_voxels * max_points * 4, stream));
-  EFG_HIP_TRY(hipMemsetAsync(i_break, 0x7f, kMaxBatch * 4, stream));
+  int* scene_base = small;                                   // [batch+1]
+  unsigned* i_break = cleared_small;                         // [batch]  0xffffffff = no break
+  int* scene_total = reinterpret_cast<int*>(cleared_small + kMaxBatch);  // [batch]  -1 + number of first points
+  EFG_HIP_TRY(hipMemsetAsync(table, 0xff, reinterpret_cast<char*>(cleared_small + 2 * kMaxBatch) - reinterpret_cast<char*>(table),
+                             stream));
   const dim3 blk(256);
   if (n_total > 0) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
@@ -376,14 +376,11 @@ extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, i
     EFG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(vox_count_kernel, dim3(L.tiles_per_scene, batch), blk, 0, stream, so, table, slot_of_point,
-                     tile_counts, L.tiles_per_scene);
-  EFG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vox_totals_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, L.tiles_per_scene, batch,
-                     max_voxels, scene_base, voxel_num);
+                     tile_counts, L.tiles_per_scene, scene_total);
   EFG_LAUNCH_CHECK();
   hipLaunchKernelGGL(vox_assign_kernel, dim3(L.tiles_per_scene, batch), blk, 0, stream, so, table, slot_of_point,
-                     tile_counts, L.tiles_per_scene, scene_base, max_voxels, max_points, (unsigned)vol, g,
-                     vid_of_slot, lists, i_break, coors, coors_cols);
+                     tile_counts, L.tiles_per_scene, scene_total, batch, scene_base, voxel_num, max_voxels, max_points,
+                     (unsigned)vol, g, vid_of_slot, lists, i_break, coors, coors_cols);
   EFG_LAUNCH_CHECK();
   if (n_total > 0 && max_points > 1) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);

@@ -19,12 +19,18 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             m = re.match(r"conv_fwd_kernel<(\d+), \d+(, \d+)?>$", name)
             if m:
                 name = "conv_fwd_kernel<%s>" % m.group(1)
+            m = re.match(r"conv_tile_kernel<(\d+), \d+, \d+>$", name)  # <NT, R, KS>: bench.py labels by NT
+            if m:
+                name = "conv_tile_kernel<%s>" % m.group(1)
             v = vals.setdefault(name, {})
             n, mean = int(row["launches"]), float(row["mean_" + ctr])
             tot = v.get("launches_" + ctr, 0)
             v[ctr] = (v.get(ctr, 0.0) * tot + mean * n) / (tot + n)
             v["launches_" + ctr] = tot + n
-out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
+       "source": "%s/{FETCH_SIZE,WRITE_SIZE}.summary.csv: rocprofv3 --kernel-trace --pmc <ctr> -- python bench.py --steps 2 "
+                 "--warmup 1 --no-cpu-baseline --no-full-graph (scripts/round_profile.sh)" % src.rstrip("/").split("/")[-1],
+       "kernels": {}}
 for name, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         out["kernels"][name] = {"hbm_bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
