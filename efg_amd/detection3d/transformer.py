@@ -210,6 +210,9 @@ class Transformer(nn.Module):
                 with torch.cuda.graph(graph):
                     out = self.decoder_gt(None, None, static[0], static[1], static[2], static[3], static[4])
             except Exception as exc:  # noqa: BLE001 -- any capture problem: run eagerly from now on, say so once
+                if os.environ.get("EFG_GT_GRAPH_STRICT", "0") == "1":  # tests: a failed capture is a failure
+                    _prof._enabled = was_on
+                    raise
                 import warnings
                 warnings.warn("efg_amd: HIP-graph capture of the momentum decoder failed (%s); running it eagerly" % exc)
                 self._gt_graph_off = True

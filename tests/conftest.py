@@ -9,6 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# a HIP-graph capture that silently falls back to eager launches would hide a regression of the host-side path
+os.environ.setdefault("EFG_GT_GRAPH_STRICT", "1")
 
 
 def pytest_configure(config):
