@@ -1,9 +1,9 @@
 #!/bin/bash
-out=gpurun_out/wgrad_sweep.txt; : > $out
+out=gpurun_out/wg_sweep.txt; : > $out
 for lvl in res2 res3 res4; do for kind in subm down; do
-  for fill in 512 1024 2048 4096; do
-    EFG_WGRAD_FILL=$fill python scripts/ubench/conv_layer.py --level $lvl --kind $kind --pass wgrad 2>&1 | grep "^res" | sed "s/^/fill$fill  /" >> $out
+  EFG_CONV_WG=0 python scripts/ubench/conv_layer.py --level $lvl --kind $kind --pass all 2>&1 | grep "^res" | sed 's/^/tiled      /' >> $out
+  for shape in 81 41 42 22 24; do
+    EFG_WG_MIN_TILES=0 EFG_WG_SHAPE=$shape python scripts/ubench/conv_layer.py --level $lvl --kind $kind --pass all 2>&1 | grep "^res" | sed "s/^/wg $shape      /" >> $out
   done
 done; done
 cat $out
-python scripts/bench_ops.py spconv --detail > gpurun_out/spconv_detail_r02b.txt 2>&1; tail -12 gpurun_out/spconv_detail_r02b.txt
