@@ -128,7 +128,7 @@ struct TileArgs {
   long long n_tiles;
   int cin, cout, kvol;
   int c16n, np;
-  int pipe, deal;        // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL)
+  int pipe, deal, xcd;   // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL, EFG_TILE_XCD)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
                          // the transposed table of a symmetric window is the table with the offsets reversed)
 };
@@ -144,10 +144,17 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
   unsigned bx = blockIdx.x, by = blockIdx.y;
   {
     const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
-    if (per > 0 && lin < (per << 3)) {
+    if (a.xcd == 1 && per > 0 && lin < (per << 3)) {          // one contiguous range of workgroups per XCD
       const unsigned nl = (lin & 7) * per + (lin >> 3);
       bx = nl % gridDim.x;
       by = nl / gridDim.x;
+    } else if (a.xcd == 2 && per > 0 && lin < (per << 3)) {   // ranges of 64 workgroups dealt round-robin to the XCDs
+      const unsigned blk = lin >> 9, in = lin & 511;           // 512 consecutive ids = 8 XCDs x 64
+      const unsigned nl = blk * 512 + (in & 7) * 64 + (in >> 3);
+      if (blk * 512 + 512 <= (per << 3)) {
+        bx = nl % gridDim.x;
+        by = nl / gridDim.x;
+      }
     }
   }
   const long long t0 = ((long long)bx * WT + wt) * R;  // first 16-row tile of this wave tile
@@ -428,6 +435,8 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   if (ks_env > 0) ks = ks_env >= 4 ? 4 : (ks_env >= 2 ? 2 : 1);
   a.pipe = pipe_env >= 0 ? pipe_env : (r == 2 ? 1 : 0);
   a.deal = deal_env;
+  static const int xcd_env = getenv("EFG_TILE_XCD") ? atoi(getenv("EFG_TILE_XCD")) : 1;
+  a.xcd = xcd_env;
   (void)tiles16;
   if (r == 2) {
     switch (nt) {
