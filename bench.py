@@ -34,11 +34,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="conquer", choices=["conquer", "voxeldetr", "centerpoint"],
+    ap.add_argument("--model", default="conquer", choices=["conquer", "voxeldetr", "centerpoint", "trajectoryformer"],
                     help="conquer = BASELINE configs[1]/[2] (default); voxeldetr = the plain variant; centerpoint = "
                          "configs[0]/[3] (VoxelNet: reader -> SpMiddleResNetFHD -> RPN -> CenterHead)")
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (configs[1]: batch 2; configs[2]: 16 / 8 GPUs)")
     ap.add_argument("--points", type=int, default=180000)
+    ap.add_argument("--objects", type=int, default=60, help="trajectoryformer: annotated objects per sample")
     ap.add_argument("--sweeps", type=int, default=1, help="4 = the 720k-point multi-sweep cloud of configs[3] (6 features)")
     ap.add_argument("--queries", type=int, default=1000, help="reference YAML default (configs[2] names 900)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
@@ -155,6 +156,10 @@ def main():
     rank, local_rank, world = init_distributed()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    if args.model == "trajectoryformer":
+        from efg_amd.tracking.bench import run as run_tracking
+
+        return run_tracking(args, rank, local_rank, world, dev)
     if args.model == "centerpoint":
         from efg_amd.centerpoint.bench import run as run_centerpoint
 

@@ -1,0 +1,181 @@
+"""Box / trajectory geometry of the TrajectoryFormer training path.
+
+Counterpart of $TF/modules/utils.py ($TF = playground/tracking.3d/waymo/trajectoryformer/trajectoryformer.centerpoint):
+same function names, argument meaning and results for the entry points the model calls, written batch-first for the
+GPU: no per-ROI Python loop and no per-frame `.cuda()` allocations; the point crop synchronises only for its boolean
+selections and for the occupancy counts of crowded ROIs (the reference sub-samples those with NumPy's generator).
+
+Boxes are (x, y, z, dx, dy, dz, heading[, t]); trajectories are [batch, frame, track, hypothesis, 8].
+"""
+import numpy as np
+import torch
+
+
+def rotate_points_along_z(points, angle):
+    """points [B, N, 3+C] (or [B, N, 2]), angle [B] -> rotated about +z, angle grows x -> y (utils.py:13-38)."""
+    c, s = torch.cos(angle), torch.sin(angle)
+    if points.shape[-1] == 2:
+        rot = torch.stack((c, s, -s, c), dim=1).view(-1, 2, 2).float()
+        return torch.matmul(points, rot)
+    o, z = torch.ones_like(angle), torch.zeros_like(angle)
+    rot = torch.stack((c, s, z, -s, c, z, z, z, o), dim=1).view(-1, 3, 3).float()
+    xyz = torch.matmul(points[..., 0:3], rot)
+    return torch.cat((xyz, points[..., 3:]), dim=-1)
+
+
+def encode_boxes_res_torch(boxes, anchors):
+    """Residual box code of `boxes` w.r.t. `anchors`, both (N, 7+C) (utils.py:41-73).  Unlike the reference this does
+    not clamp its arguments in place; callers here pass temporaries, so nothing observable changes."""
+    a_size = torch.clamp_min(anchors[:, 3:6], 1e-5)
+    g_size = torch.clamp_min(boxes[:, 3:6], 1e-5)
+    diagonal = torch.sqrt(a_size[:, 0:1] ** 2 + a_size[:, 1:2] ** 2)
+    planar = (boxes[:, 0:2] - anchors[:, 0:2]) / diagonal
+    zt = (boxes[:, 2:3] - anchors[:, 2:3]) / a_size[:, 2:3]
+    size = torch.log(g_size / a_size)
+    rest = boxes[:, 6:] - anchors[:, 6:]            # heading residual and any extra code
+    return torch.cat([planar, zt, size, rest], dim=-1)
+
+
+def decode_torch(box_encodings, anchors):
+    """Inverse of `encode_boxes_res_torch` (utils.py:76-104 / losses.py:133-159)."""
+    a_size = anchors[..., 3:6]
+    diagonal = torch.sqrt(a_size[..., 0:1] ** 2 + a_size[..., 1:2] ** 2)
+    planar = box_encodings[..., 0:2] * diagonal + anchors[..., 0:2]
+    z = box_encodings[..., 2:3] * a_size[..., 2:3] + anchors[..., 2:3]
+    size = torch.exp(box_encodings[..., 3:6]) * a_size
+    rest = box_encodings[..., 6:] + anchors[..., 6:]
+    return torch.cat([planar, z, size, rest], dim=-1)
+
+
+_CORNER_TEMPLATE = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
+
+
+def boxes_to_corners_3d(boxes3d):
+    """(N, 7) -> (N, 8, 3) corners, bottom face first (utils.py:107-144)."""
+    template = boxes3d.new_tensor(_CORNER_TEMPLATE) / 2
+    corners = boxes3d[:, None, 3:6].repeat(1, 8, 1) * template[None]
+    corners = rotate_points_along_z(corners, boxes3d[:, 6])
+    return corners + boxes3d[:, None, 0:3]
+
+
+def _rotate_sequence(seq, angle):
+    """seq [B, T, N, H, C] rotated per (b, n, h) by angle [B, 1, N, H] -- the permute/reshape round trip of
+    utils.py:172-181 folded into one helper."""
+    b, t, n, h, c = seq.shape
+    flat = seq.permute(0, 2, 3, 1, 4).reshape(b * n * h, t, c)
+    return rotate_points_along_z(flat, angle.reshape(-1)).reshape(b, n, h, t, c).permute(0, 3, 1, 2, 4)
+
+
+def transform_trajs_to_local_coords(box_seq, center_xyz, center_heading, pred_vel_hypo=None, heading_index=8,
+                                    rot_vel_index=(6, 7)):
+    """Trajectories into the frame of their newest box (utils.py:147-199).  Entries whose anchor centre or own size is
+    all-zero (padding) come back as zeros."""
+    t = box_seq.shape[1]
+    valid = torch.logical_and((center_xyz[..., :2].sum(-1) != 0).repeat(1, t, 1, 1), box_seq[..., 3:6].sum(-1) != 0)
+    local = box_seq.clone()
+    local[..., 0:2] = local[..., 0:2] - center_xyz[..., :2]
+    local = _rotate_sequence(local, -center_heading).clone()
+    local[..., heading_index] = local[..., heading_index] - center_heading
+    keep = valid.unsqueeze(-1)
+    vel = None
+    if pred_vel_hypo is not None:
+        vel = _rotate_sequence(pred_vel_hypo, -center_heading)
+        vel = torch.where(keep, vel, torch.zeros_like(vel))
+    return torch.where(keep, local, torch.zeros_like(local)), vel
+
+
+def transform_trajs_to_global_coords(box_seq, center_xyz, center_heading, pred_vel_repeat=None, heading_index=6):
+    """Inverse of the above (utils.py:202-240)."""
+    out = _rotate_sequence(box_seq, center_heading).clone()
+    d = center_xyz.shape[-1]
+    out[..., 0:d] = out[..., 0:d] + center_xyz
+    out[..., heading_index] = out[..., heading_index] + center_heading
+    vel = None if pred_vel_repeat is None else _rotate_sequence(pred_vel_repeat, center_heading)
+    return out, vel
+
+
+def get_corner_points_of_roi(rois):
+    """(..., 7+) -> (global [R, 8, 3], local [R, 8, 3]) corners in the order (z fastest) of `ones(2,2,2).nonzero()`
+    (utils.py:301-325)."""
+    rois = rois.reshape(-1, rois.shape[-1])
+    size = rois[:, 3:6].unsqueeze(1)
+    bits = torch.tensor([[i >> 2 & 1, i >> 1 & 1, i & 1] for i in range(8)], dtype=rois.dtype, device=rois.device)
+    local = bits[None] * size - size / 2
+    local = rotate_points_along_z(local, rois[:, 6])
+    return local + rois[:, None, 0:3], local
+
+
+def spherical_coordinate(src, diag_dist):
+    """[.., 27] offsets to 8 corners + centre -> [.., 27] (range / diagonal, azimuth, inclination) blocks
+    (utils.py:328-343)."""
+    assert src.shape[-1] == 27
+    x, y, z = src[..., 0::3], src[..., 1::3], src[..., 2::3]
+    dis = (x ** 2 + y ** 2 + z ** 2) ** 0.5
+    phi = torch.atan(y / (x + 1e-5))
+    the = torch.acos(z / (dis + 1e-5))
+    return torch.cat([dis / (diag_dist + 1e-5), phi, the], dim=-1)
+
+
+def reorder_rois(pred_bboxes):
+    """List of [n_i, C] -> zero-padded [len, max(n_i, 1), C] and its validity mask (utils.py:346-358)."""
+    width = max(1, max(len(b) for b in pred_bboxes))
+    first = pred_bboxes[0]
+    out = first.new_zeros((len(pred_bboxes), width, first.shape[-1]), dtype=torch.float32)
+    valid = torch.zeros(out.shape, dtype=torch.bool, device=out.device)
+    for i, b in enumerate(pred_bboxes):
+        out[i, :len(b)] = b
+        valid[i, :len(b)] = True
+    return out, valid
+
+
+def _crowded_choice(count, k):
+    """The reference re-seeds NumPy with 0 before every sub-sampling draw (utils.py:409-413), so the selection is a
+    pure function of the ROI's point count.  Drawn through the global generator exactly as there, so that the
+    generator is left in the same state for whatever draws from it next (the hypothesis augmentation)."""
+    np.random.seed(0)
+    return torch.from_numpy(np.random.choice(count, k, replace=False).astype(np.int64))
+
+
+def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
+    """Points of the current sweep inside the 1.2 x half-diagonal cylinder of every frame-0 hypothesis box.
+
+    trajectory_rois [B, T, N, H, 8]; `points` either the reference's collated [P, 1+6] tensor (batch index first,
+    utils.py:361-431) or a list of per-scene [P_b, 6] tensors.  Returns [B, N*H, num_lidar_points, 6]: the ROI's
+    points in cloud order, padded with its first point; an empty ROI gets its own centre with zero features; a ROI
+    with more than `num_lidar_points` points is sub-sampled with the reference's fixed NumPy draw.
+
+    One pass per scene: distance matrix -> membership -> ranks by prefix sum -> one gather.
+    """
+    batch, _, n_track, n_hypo, _ = trajectory_rois.shape
+    n_rois = n_track * n_hypo
+    first = trajectory_rois[:, 0].reshape(batch, n_rois, 8)
+    k = num_lidar_points
+    out = first.new_zeros(batch, n_rois, k, 6)
+    slot = torch.arange(k, device=first.device)
+    for b in range(batch):
+        cloud = points[b] if isinstance(points, (list, tuple)) else points[points[:, 0] == b][:, 1:]
+        cloud = cloud[cloud[:, -1] < 1]
+        boxes = first[b, :, :7]
+        radius = torch.sqrt((boxes[:, 3] / 2) ** 2 + (boxes[:, 4] / 2) ** 2) * 1.2
+        centre_fill = torch.cat([boxes[:, None, :3].expand(-1, k, -1), boxes.new_zeros(n_rois, k, 3)], -1)
+        if cloud.shape[0] == 0:
+            out[b] = centre_fill
+            continue
+        dist = torch.norm(cloud[None, :, :2] - boxes[:, None, :2], dim=2)
+        inside = dist <= radius[:, None]
+        count = inside.sum(1)
+        pairs = inside.nonzero()                      # (roi, point) in roi-major, cloud order
+        start = torch.cumsum(count, 0) - count
+        pick = torch.where(slot[None] < count[:, None], slot[None].expand(n_rois, -1), torch.zeros_like(slot)[None])
+        crowded = (count > k).nonzero().flatten()
+        if crowded.numel():
+            host = count[crowded].tolist()
+            rows = torch.stack([_crowded_choice(c, k) for c in host]).to(first.device)
+            pick = pick.index_copy(0, crowded, rows)
+        flat = (start[:, None] + pick).clamp(max=max(pairs.shape[0] - 1, 0))
+        if pairs.shape[0] == 0:
+            out[b] = centre_fill
+            continue
+        gathered = cloud[pairs[:, 1][flat]]
+        out[b] = torch.where((count == 0)[:, None, None], centre_fill, gathered)
+    return out

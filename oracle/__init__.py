@@ -264,6 +264,18 @@ def boxes_bev(boxes_a, boxes_b, mode="iou"):
     return out
 
 
+def boxes_iou3d(boxes_a, boxes_b):
+    """[N,7] x [M,7] -> [N,M] 3-D IoU: BEV overlap x height overlap over the union volume, composed in fp32 in the
+    order of efg/operators/iou3d_nms.py:54-87."""
+    a, b = _f(boxes_a), _f(boxes_b)
+    top = np.minimum((a[:, 2] + a[:, 5] / 2)[:, None], (b[:, 2] + b[:, 5] / 2)[None, :])
+    bottom = np.maximum((a[:, 2] - a[:, 5] / 2)[:, None], (b[:, 2] - b[:, 5] / 2)[None, :])
+    overlap = boxes_bev(a, b, "overlap") * np.maximum(top - bottom, np.float32(0))
+    vol_a = (a[:, 3] * a[:, 4] * a[:, 5])[:, None]
+    vol_b = (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return (overlap / np.maximum(vol_a + vol_b - overlap, np.float32(1e-6))).astype(np.float32)
+
+
 def nms(boxes_sorted, thresh, rotated=True):
     """Greedy NMS over boxes already sorted by descending score -> kept indices (int64)."""
     b = _f(boxes_sorted)

@@ -147,6 +147,23 @@ def install():
         i = x.indices.long()
         return grad_dense[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
 
+    # ---- rotated IoU / NMS (TrajectoryFormer's target assignment and linking) -------------------
+    import efg_amd.operators.iou3d_nms as iou
+
+    def pairwise(boxes_a, boxes_b, mode):
+        return torch.from_numpy(oracle.boxes_iou3d(_np(boxes_a), _np(boxes_b)) if mode == "iou3d"
+                                else oracle.boxes_bev(_np(boxes_a), _np(boxes_b), mode))
+
+    def nms(boxes, scores, thresh, pre_maxsize, rotated):
+        order = scores.sort(0, descending=True)[1]
+        if pre_maxsize is not None:
+            order = order[:pre_maxsize]
+        keep = torch.from_numpy(oracle.nms(_np(boxes[order]), thresh, rotated))
+        return order[keep].contiguous(), None
+
+    patch(iou, "_pairwise", pairwise)
+    patch(iou, "_nms", nms)
+
     patch(core, "_site_index_from_indices", site_index)
     patch(core, "_downsample_geometry", downsample)
     patch(core, "_build_nbr", build_nbr)

@@ -95,3 +95,12 @@ CENTERPOINT_OVERRIDES = {
     "model.loss.max_objs": 20,
     "model.post_process.post_center_limit_range": [-8.0, -8.0, -10.0, 8.0, 8.0, 10.0],
 }
+
+# TrajectoryFormer: the reference configuration as is (hidden 256, 3 + 3 encoder layers); small scenes
+TRACKING_SAMPLE = {"n_points": 40000, "n_objects": 10, "n_false": 4}
+
+
+def tracking_inputs(seed=500, scenes=2):
+    from efg_amd.tracking.synthetic import make_tracking_sample
+
+    return [make_tracking_sample(seed + i, **TRACKING_SAMPLE) for i in range(scenes)]

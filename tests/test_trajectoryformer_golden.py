@@ -1,0 +1,157 @@
+"""TrajectoryFormer (BASELINE configs[4]) training step vs the reference's own `forward_train`
+(tests/golden/trajectoryformer_small.npz, made by scripts/make_golden_trajectoryformer.py from the reference code
+imported in place).  Same deterministic weights, same inputs, same NumPy generator seed on both sides.
+
+CPU variant: our host code over the oracle's rotated IoU / NMS (oracle/cpu_backend.py).  GPU variant: the product
+path -- HIP IoU / NMS kernels, everything else on PyTorch-ROCm.
+
+Tolerances: integer / boolean results (masks, kept boxes, point selections) exact; fp32 activations 5e-5 of the
+tensor's scale; losses 1e-4 relative; gradients 1e-3 of their maximum (sums over 1e4..1e5 fp32 terms in a different
+order than the reference's [token, batch]-major attention).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, golden
+from golden_init import deterministic_state, tracking_inputs
+
+FIXTURE = "trajectoryformer_small.npz"
+
+
+def _build(device):
+    from efg_amd.config import load_config
+    from efg_amd.tracking import TrajectoryFormer
+
+    cfg = load_config(os.path.join(ROOT, "configs", "trajectoryformer_waymo_centerpoint.yaml"),
+                      {"model.device": str(device)})
+    torch.manual_seed(0)
+    model = TrajectoryFormer(cfg)
+    model.load_state_dict(deterministic_state(model.state_dict()))
+    model.train()
+    return model
+
+
+def _close(name, got, want, tol):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max()) if got.size else 0.0
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3g, tol %.1e)" % (name, err, scale, tol)
+
+
+def _exact(name, got, want):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    assert got.shape == want.shape and (got == want).all(), "%s differs in %d places" % (name, int((got != want).sum()))
+
+
+def _run(model, g, grad_tol):
+    import efg_amd.tracking.geometry as geo
+    import efg_amd.tracking.trajectoryformer as tfm
+
+    seen = {}
+    for name in ("organize_proposals", "hypotheses_augment", "generate_trajectory_hypothses",
+                 "get_trajcetory_point_feature", "get_trajectory_boxes_feature", "get_trajectory_hypotheses_feat",
+                 "get_cls_targets", "get_reg_targets"):
+        fn = getattr(model, name)
+
+        def wrapped(*a, _fn=fn, _name=name, **k):
+            r = _fn(*a, **k)
+            seen[_name] = r
+            return r
+
+        setattr(model, name, wrapped)
+    crop = tfm.crop_current_frame_points
+
+    def crop_wrapped(*a, **k):
+        seen["crop"] = crop(*a, **k)
+        return seen["crop"]
+
+    tfm.crop_current_frame_points = crop_wrapped
+    try:
+        batch = tracking_inputs()
+        for i, (sample, info) in enumerate(batch):                    # the generator is deterministic; make sure
+            for k in ("gt_boxes", "pred_boxes3d", "pred_scores", "pred_labels"):
+                _exact("in.%s.%d" % (k, i), info["annotations"][k], g["in.%s.%d" % (k, i)])
+            assert float(np.abs(sample[0]["points"]).sum(dtype=np.float64)) == float(g["in.points_abs_sum"][i])
+        np.random.seed(1234)
+        losses = model(batch)
+    finally:
+        tfm.crop_current_frame_points = crop
+    _exact("numpy generator state after the step", np.random.get_state()[1][:8].astype(np.int64), g["rng_after"])
+
+    # proposals -> trajectories -> hypotheses: pure selection + a little fp32 geometry
+    for i, tol in enumerate((5e-5, 0, 0, 0)):
+        got, want = seen["organize_proposals"][i], g["organize_proposals.%d" % i]
+        _close("organize_proposals.%d" % i, got, want, tol) if tol else _exact("organize_proposals.%d" % i, got, want)
+    _close("hypotheses_augment", seen["hypotheses_augment"], g["hypotheses_augment"], 1e-6)
+    for i in range(2):
+        _close("hypotheses.%d" % i, seen["generate_trajectory_hypothses"][i], g["generate_trajectory_hypothses.%d" % i],
+               5e-5)
+    _exact("cropped points", seen["crop"], g["crop_current_frame_points"])
+    for i in range(3):
+        _close("point token %d" % i, seen["get_trajcetory_point_feature"][i],
+               g["get_trajcetory_point_feature.%d" % i], 5e-5)
+    _close("box-sequence feature", seen["get_trajectory_boxes_feature"], g["get_trajectory_boxes_feature"], 5e-5)
+    _close("hypothesis feature", seen["get_trajectory_hypotheses_feat"], g["get_trajectory_hypotheses_feat"], 5e-5)
+    _exact("fg_iou_mask", seen["get_cls_targets"][0], g["get_cls_targets.0"])
+    _exact("fg_reg_mask", seen["get_cls_targets"][1], g["get_cls_targets.1"])
+    _close("ious_targets", seen["get_cls_targets"][2], g["get_cls_targets.2"], 5e-5)
+    _exact("gt_boxes", seen["get_cls_targets"][3], g["get_cls_targets.3"])
+    _close("reg_targets", seen["get_reg_targets"], g["get_reg_targets"], 5e-5)
+    assert bool(g["get_cls_targets.0"].any()) and bool(g["get_cls_targets.1"].any())      # the fixture has foreground
+    for k in ("loss_cls", "loss_reg"):
+        assert float(losses[k].detach()) == pytest.approx(float(g["loss." + k]), rel=1e-4), k
+
+    sum(v.sum() for v in losses.values()).backward()
+    params = dict(model.named_parameters())
+    assert sorted(n for n, p in params.items() if p.grad is None) == sorted(g["no_grad"].tolist())
+    for key in g:
+        if key.startswith("grad."):
+            rows = g["rows." + key[5:]]
+            got = params[key[5:]].grad.detach().cpu().double().numpy()
+            full_scale = float(g["gradmax." + key[5:]])
+            err = float(np.abs(got[rows] - g[key]).max())
+            assert err <= grad_tol * full_scale, "%s: %.3e vs scale %.3e" % (key, err, full_scale)
+            assert float(np.abs(got).max()) == pytest.approx(full_scale, rel=1e-2)
+    _close("BatchNorm running mean", model.seqboxembed.feat.bn1.running_mean, g["bn_running_mean"], 5e-5)
+
+
+def test_trajectoryformer_forward_train_matches_reference_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    torch.set_num_threads(8)
+    with cpu_backend.install():
+        _run(_build("cpu"), golden(FIXTURE), 1e-3)
+
+
+@pytest.mark.gpu
+def test_trajectoryformer_forward_train_matches_reference_gpu(dev):
+    _run(_build(dev), golden(FIXTURE), 1e-3)
+
+
+def test_trajectoryformer_trainer_step_cpu(oracle_mod):
+    """The experiment's solver block (AdamW, OneCycle, gradient-norm clipping) around the model, through the same
+    Trainer as the detectors; degenerate input (no proposals) gives the reference's zero losses."""
+    from oracle import cpu_backend
+
+    from efg_amd.engine import Trainer
+    from efg_amd.tracking import TrajectoryFormer
+    from efg_amd.tracking.synthetic import synthetic_tracking_batch
+
+    torch.set_num_threads(8)
+    np.random.seed(5)
+    tr = Trainer(config=os.path.join(ROOT, "configs", "trajectoryformer_waymo_centerpoint.yaml"), device="cpu",
+                 model_cls=TrajectoryFormer, ddp=False, max_iters=10)
+    assert tr.grad_clipper is not None and tr.lr_scheduler is not None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tr.step(synthetic_tracking_batch(40, 1, n_points=3000, n_objects=4, n_false=1))
+    before = tr.model.point_reg.layers[0].weight.detach().clone()
+    with cpu_backend.install():
+        loss_dict, total = tr.step(synthetic_tracking_batch(40, 2, n_points=6000, n_objects=6, n_false=2))
+    assert set(loss_dict) == {"loss_cls", "loss_reg"} and torch.isfinite(total)
+    assert not torch.equal(before, tr.model.point_reg.layers[0].weight)
+    assert not tr.model.velboxembed.training and tr.model.seqboxembed.training       # the forecast module stays frozen
+    tr.close()
