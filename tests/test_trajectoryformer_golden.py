@@ -44,7 +44,10 @@ def _close(name, got, want, tol):
 
 def _exact(name, got, want):
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
-    assert got.shape == want.shape and (got == want).all(), "%s differs in %d places" % (name, int((got != want).sum()))
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, "%s differs in %d places, first at %s: %s vs %s" % (
+        name, len(bad), bad[0].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
 
 
 def _run(model, g, grad_tol):
@@ -90,7 +93,8 @@ def _run(model, g, grad_tol):
     for i in range(2):
         _close("hypotheses.%d" % i, seen["generate_trajectory_hypothses"][i], g["generate_trajectory_hypothses.%d" % i],
                5e-5)
-    _exact("cropped points", seen["crop"], g["crop_current_frame_points"])
+    # same points in the same slots; an EMPTY ROI is filled with its own (fp32, forecast-derived) centre, hence not `==`
+    _close("cropped points", seen["crop"], g["crop_current_frame_points"], 1e-6)
     for i in range(3):
         _close("point token %d" % i, seen["get_trajcetory_point_feature"][i],
                g["get_trajcetory_point_feature.%d" % i], 5e-5)
