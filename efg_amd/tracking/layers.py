@@ -150,7 +150,10 @@ class TransformerEncoderGlobalLocal(nn.Module):
 
 
 class PointNetfeat(nn.Module):
-    """Four 1x1 conv + BN stages, max over the sequence (pointnet.py:136-160)."""
+    """Four 1x1 conv + BN stages, max over the sequence (pointnet.py:136-160).  Kernel-size-1 convolutions are
+    row-wise linear maps: the [S, C, T] input is handled as S*T rows through four GEMMs (BatchNorm over rows = over
+    (S, T) per channel, the same statistics), which keeps MIOpen's convolution solver search -- triggered anew for
+    every track count under `cudnn.benchmark` -- out of the step.  Parameters keep their Conv1d shapes [Cout, Cin, 1]."""
 
     def __init__(self, input_dim, x=1, outchannel=512):
         super().__init__()
@@ -161,11 +164,21 @@ class PointNetfeat(nn.Module):
         for i in range(4):
             setattr(self, "bn%d" % (i + 1), nn.BatchNorm1d(widths[i + 1]))
 
-    def forward(self, x):
+    def _stage(self, rows, i):
+        conv = getattr(self, "conv%d" % i)
+        return getattr(self, "bn%d" % i)(F.linear(rows, conv.weight.squeeze(-1), conv.bias))
+
+    def forward_rows(self, rows, steps):
+        """rows [S * steps, C] (sequence-major) -> (pooled [S, out], per-step [S, steps, out])."""
         for i in (1, 2, 3):
-            x = F.relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(x)))
-        per_step = self.bn4(self.conv4(x))
-        return per_step.max(dim=2)[0].view(-1, self.output_channel), per_step
+            rows = F.relu(self._stage(rows, i))
+        per_step = self._stage(rows, 4).view(-1, steps, self.output_channel)
+        return per_step.max(dim=1)[0], per_step
+
+    def forward(self, x):
+        s, c, t = x.shape
+        pooled, per_step = self.forward_rows(x.transpose(1, 2).reshape(s * t, c), t)
+        return pooled, per_step.transpose(1, 2)
 
 
 class PointNet(nn.Module):
@@ -194,9 +207,11 @@ class PointNet(nn.Module):
         self.init_weights()
 
     def forward(self, x, feat=None):
-        pooled, per_step = self.feat(self.pre_bn(x))
+        """x [S, C, T] -> (embedding [S, channels], per-step features [S, 512, T])."""
+        s, c, t = x.shape
+        pooled, per_step = self.feat.forward_rows(self.pre_bn(x.transpose(1, 2).reshape(s * t, c)), t)
         hidden = F.relu(self.bn1(self.fc1(pooled)))
-        return F.relu(self.bn2(self.fc2(hidden))), per_step
+        return F.relu(self.bn2(self.fc2(hidden))), per_step.transpose(1, 2)
 
     def init_weights(self):
         for m in self.modules():
