@@ -37,8 +37,11 @@ __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 // ---- weight packing -----------------------------------------------------------------------
 // packed[((k*R16 + r16)*NP + n)*16 + kk*4 + j] = W(red = r16*16 + 4*j + kk, n) for offset k,
 // where (red, n) = (ci, co) forward, (co, ci) dgrad; zero padded to multiples of 16.
+// for_dgrad bit 1 ("natural order", the 16-byte-gather tile kernel): red = r16*16 + 4*kk + j instead.
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin,
                                                            int for_dgrad, float* __restrict__ packed) {
+  const int natural = for_dgrad & 2;
+  for_dgrad &= 1;
   const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
   const int r16n = round16(red) / 16, np = round16(nn);
   const long long total = (long long)kvol * r16n * np * 16;
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     q /= np;
     const int r16 = (int)(q % r16n);
     const int k = (int)(q / r16n);
-    const int r = r16 * 16 + 4 * j + kk;
+    const int r = natural ? r16 * 16 + 4 * kk + j : r16 * 16 + 4 * j + kk;
     float v = 0.0f;
     if (r < red && n < nn) {
       const int co = for_dgrad ? r : n, ci = for_dgrad ? n : r;
@@ -681,6 +684,7 @@ using namespace efg;
 
 extern "C" size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad) {
   if (cout < 1 || cin < 1 || kvol < 1) return 0;
+  for_dgrad &= 1;  // (bit 1 selects the natural channel order, same size)
   const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
   // + one tile row of slack: kernels with NT > tiles read (zero-weight) past the last n-tile
   return ((size_t)kvol * ((red + 15) / 16) * ((nn + 15) / 16 * 16) * 16 + 16 * 256) * sizeof(float);

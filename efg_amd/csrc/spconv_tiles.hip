@@ -29,7 +29,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChunkRows = 1024;  // rows sorted together (one workgroup of the plan kernel)
 constexpr int kCKt = 64;          // channels per staged chunk
-constexpr int kAStr = kCKt + 2;   // LDS row stride of the A tile (conflict-free fragment reads)
 
 // ---- plan -------------------------------------------------------------------------------------------------
 // layout of the plan buffer for (m rows, kvol offsets), n_tiles = round_up(m, 1024) / 16:
@@ -129,14 +128,24 @@ struct TileArgs {
   int cin, cout, kvol;
   int c16n, np;
   int pipe, deal, xcd;   // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL, EFG_TILE_XCD)
+  long long zero_off;    // byte offset from `in` of 16 zero bytes (absent rows / channel pieces past cin gather those)
+  int v4;                // 1: 16-byte gathers, natural-order packed weights (cin % 4 == 0)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
                          // the transposed table of a symmetric window is the table with the offsets reversed)
 };
 
-template <int NT, int R, int KS>
+// 16 zero bytes every absent neighbour row (and every channel piece past cin) of the 16-byte gather points at
+__device__ float4 g_zero_piece;  // (zero-initialised, never written; not const: keeps the select in the global address space)
+
+// V4 = 1 (reduction channels a multiple of 4; weights packed in natural order): the gather is 16 bytes per lane
+// (4 rows x 16 pieces per instruction instead of one row), the A tile is stored as 16-byte pieces at slot
+// piece ^ row (conflict-free 16-byte writes and fragment reads without padding) and a lane's four A operands of a
+// 16-channel step come from ONE ds_read_b128.  V4 = 0: the 4-byte path (any channel count).
+template <int NT, int R, int KS, int V4>
 __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
-  __shared__ float a_tile[4][R * 16 * kAStr];        // wave-private A staging
+  constexpr int kAStr = V4 ? kCKt : kCKt + 2;        // LDS row stride of the A tile (V4: swizzled pieces, no padding)
+  __shared__ __attribute__((aligned(16))) float a_tile[4][R * 16 * kAStr];  // wave-private A staging
   __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wt = wv / KS, part = wv % KS;
@@ -200,10 +209,33 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
     }
 
   const int nchunk = (a.c16n * 16 + kCKt - 1) / kCKt;
-  float pre[R * 16];
+  float pre[V4 ? 1 : R * 16];
   unsigned pre_m[R];
 
+  f32x4 pre4[V4 ? R * 4 : 1];
   auto gather = [&](int col, int ch) {
+    if (V4) {
+      const int piece = lane & 15, sub = lane >> 4;
+      const unsigned c0 = (unsigned)(ch * kCKt + piece * 4);
+      const bool c_ok = c0 < (unsigned)a.cin;
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        pre_m[s] = (unsigned)__builtin_amdgcn_readlane((int)vmr[s], col);
+        if (pre_m[s]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = q * 4 + sub;
+            const bool ok = c_ok && ((pre_m[s] >> j) & 1u);
+            // one base, two offsets (select on the offset, not on the pointer: stays a v_cndmask pair, no branch)
+            const long long row_off = (long long)((unsigned)nbs[s * 512 + col * 16 + j] + c0 * 4u);
+            const long long sel = -(long long)ok;  // bit select: the compiler turns `ok ? row_off : zero_off` into branches
+            const long long off = (row_off & sel) | (a.zero_off & ~sel);
+            pre4[s * 4 + q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.in) + off);
+          }
+        }
+      }
+      return;
+    }
     const unsigned cc4 = (unsigned)min(ch * kCKt + lane, a.cin - 1) * 4u;
 #pragma unroll
     for (int s = 0; s < R; ++s) {
@@ -219,6 +251,19 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
     }
   };
   auto stash = [&](float* at) {
+    if (V4) {
+      const int piece = lane & 15, sub = lane >> 4;
+#pragma unroll
+      for (int s = 0; s < R; ++s)
+        if (pre_m[s]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = q * 4 + sub;
+            *reinterpret_cast<f32x4*>(at + (s * 16 + j) * kAStr + ((piece ^ j) << 2)) = pre4[s * 4 + q];
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < R; ++s)
       if (pre_m[s]) {
@@ -244,8 +289,14 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
 #pragma unroll
       for (int s = 0; s < R; ++s) {
         if ((s == 0 ? m0 : m1) == 0) continue;  // wave-uniform: this sub-tile has no neighbour at the column
-        const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
-        const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+        float a0, a1, a2, a3;
+        if (V4) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(at + (s * 16 + m) * kAStr + (((i * 4 + kk) ^ m) << 2));
+          a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3];
+        } else {
+          const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
+          a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t].x, acc[s][t], 0, 0, 0);
 #pragma unroll
@@ -375,20 +426,26 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
     }
 }
 
-template <int NT, int R>
-void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
+template <int NT, int R, int V4>
+void launch_tiles_v(const TileArgs& a, int ny, int ks, hipStream_t stream) {
   const long long wave_tiles = (a.n_tiles + R - 1) / R;
   if (ks == 4) {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 4>), dim3((unsigned)wave_tiles, ny), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 4, V4>), dim3((unsigned)wave_tiles, ny), dim3(256), 0, stream, a);
   } else if (ks == 2) {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 2>), dim3((unsigned)ceil_div(wave_tiles, 2), ny), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 2, V4>), dim3((unsigned)ceil_div(wave_tiles, 2), ny), dim3(256), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 1>), dim3((unsigned)ceil_div(wave_tiles, 4), ny), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 1, V4>), dim3((unsigned)ceil_div(wave_tiles, 4), ny), dim3(256), 0, stream, a);
   }
 }
 
+template <int NT, int R>
+void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
+  if (a.v4) launch_tiles_v<NT, R, 1>(a, ny, ks, stream);
+  else launch_tiles_v<NT, R, 0>(a, ny, ks, stream);
+}
+
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
-              const void* plan, int64_t m_out, float* out, int flip, hipStream_t stream) {
+              const void* plan, int64_t m_out, float* out, int flip, int natural_order, hipStream_t stream) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
   EFG_CHECK_ARG(kvol >= 1 && kvol <= 31, "spconv tiled: kernel volume must be in [1,31], got %d", kvol);
   if (m_out == 0) return EFG_OK;
@@ -410,6 +467,21 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.c16n = (cin + 15) / 16;
   a.np = (cout + 15) / 16 * 16;
   a.flip = flip;
+  a.v4 = natural_order ? 1 : 0;
+  a.zero_off = 0;
+  if (a.v4) {
+    static const char* zero_piece[64] = {};  // per device: address of g_zero_piece
+    int dev = 0;
+    EFG_HIP_TRY(hipGetDevice(&dev));
+    EFG_CHECK_ARG(dev >= 0 && dev < 64, "spconv tiled: device ordinal %d out of range", dev);
+    if (!zero_piece[dev]) {
+      void* p = nullptr;
+      EFG_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_piece)));
+      zero_piece[dev] = static_cast<const char*>(p);
+    }
+    a.zero_off = (long long)(zero_piece[dev] - reinterpret_cast<const char*>(in));
+  }
+  EFG_CHECK_ARG(!natural_order || cin % 4 == 0, "spconv tiled: natural-order weights need cin %% 4 == 0, got %d", cin);
   const int ntiles = a.np / 16;
   // R = 2 sub-tiles per wave (weights loaded once for 32 rows) once the level has enough row tiles to fill the chip
   // that way; n-tiles per wave as many as the grid allows (A reuse); offsets split over the 4 waves of a workgroup
@@ -481,6 +553,6 @@ extern "C" int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, voi
 extern "C" int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                             const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                             int flip_offsets, float* out_feat, void* stream) {
-  return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets,
+  return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets & 1, (flip_offsets >> 1) & 1,
                    (hipStream_t)stream);
 }

@@ -126,6 +126,15 @@ def _conv_wg(inp, m_in, cin, w, bias, cout, kvol, plan, m_out, flip, for_dgrad, 
     return out
 
 
+def _natural_order(reduce_channels):
+    """2 when the tile kernel should take its 16-byte-gather path for this reduction width (weights packed in natural
+    channel order), else 0.  OFF by default: measured 3-13 % SLOWER than the 4-byte path on every res18 layer
+    (profiles/r02_v4_sweep.txt) -- 4x fewer gather / LDS instructions buy nothing (the vector L1 moves 64 B/clk either
+    way and the kernel is not issue-bound) while the 16 extra VGPRs cost a wave per SIMD.  EFG_TILE_V4=1 enables it
+    (a tested A/B arm, tests/test_spconv_dense_gpu.py)."""
+    return 2 if reduce_channels % 4 == 0 and os.environ.get("EFG_TILE_V4", "0") == "1" else 0
+
+
 def _conv_forward(features, w, bias, rb):
     """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
     lib = L.lib()
@@ -135,15 +144,17 @@ def _conv_forward(features, w, bias, rb):
         if shape is not None:
             return _conv_wg(features, rb.m_in, cin, w, bias, cout, kvol, rb.plan_fwd(), rb.m_out, 0, 0, shape,
                             _Cost(rb, cin, cout, "fwd"))
+    tiled = _tiled() and kvol <= 31 and rb.m_out > 0
+    nat = _natural_order(cin) if tiled else 0
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
                          device=features.device)
-    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0, L.ptr(packed), L.stream()))
+    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0 | nat, L.ptr(packed), L.stream()))
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
-    if _tiled() and kvol <= 31 and rb.m_out > 0:
+    if tiled:
         plan = rb.plan_fwd()
         with _prof.timed(_tile_kernel_name(cout), _Cost(rb, cin, cout, "fwd")):
             L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout,
-                                                     kvol, L.ptr(plan), rb.m_out, 0, L.ptr(out), L.stream()))
+                                                     kvol, L.ptr(plan), rb.m_out, 0 | nat, L.ptr(out), L.stream()))
         return out
     with _prof.timed(_fwd_kernel_name(cout, rb.m_out, kvol), _Cost(rb, cin, cout, "fwd")):
         L.check(lib.efg_spconv_forward_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
@@ -160,15 +171,17 @@ def _conv_dgrad(grad_out, w, rb):
             plan, flip = rb.plan_dgrad()
             return _conv_wg(grad_out, rb.m_out, cout, w, None, cin, kvol, plan, rb.m_in, flip, 1, shape,
                             _Cost(rb, cin, cout, "dgrad"))
+    tiled = _tiled() and kvol <= 31 and rb.m_in > 0
+    nat = _natural_order(cout) if tiled else 0
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8,
                          device=grad_out.device)
-    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1, L.ptr(packed), L.stream()))
+    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1 | nat, L.ptr(packed), L.stream()))
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
-    if _tiled() and kvol <= 31 and rb.m_in > 0:
+    if tiled:
         plan, flip = rb.plan_dgrad()
         with _prof.timed(_tile_kernel_name(cin), _Cost(rb, cin, cout, "dgrad")):
             L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), None, cin, kvol,
-                                                     L.ptr(plan), rb.m_in, flip, L.ptr(grad_in), L.stream()))
+                                                     L.ptr(plan), rb.m_in, flip | nat, L.ptr(grad_in), L.stream()))
         return grad_in
     rnbr = rb.rnbr
     order = rb.dgrad_order()

@@ -133,7 +133,9 @@ int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m
 /* Weights arrive in the spconv 2.x parameter layout f32 [cout][kvol][cin] ([Cout,kd,kh,kw,Cin]) and
  * are re-packed once per call site into MFMA B-operand order (one 16-byte load per lane feeds four
  * v_mfma_f32_16x16x4_f32):  for_dgrad = 0: packed[k][cin/16][cout_pad][16]  (reduce over cin)
- *                           for_dgrad = 1: packed[k][cout/16][cin_pad][16]  (reduce over cout). */
+ *                           for_dgrad = 1: packed[k][cout/16][cin_pad][16]  (reduce over cout).
+ * Within a 16-channel group the lane kk's fragment holds channels {kk, kk+4, kk+8, kk+12}; for_dgrad | 2 ("natural
+ * order", what efg_spconv_forward_tiled_f32 takes with flip_offsets | 2) holds {4kk .. 4kk+3} instead. */
 size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad);
 int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad, float* packed,
                                void* stream);
@@ -159,7 +161,9 @@ int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, si
 /* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:] over the plan of nbr.  flip_offsets = 1 pairs table column c
  * with weight offset kvol-1-c: the dgrad of a submanifold conv on the FORWARD table's plan (packed: for_dgrad = 1,
  * in = grad_out, cin/cout swapped by the caller), since the transposed table of a symmetric window is the table
- * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0. */
+ * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0.
+ * flip_offsets | 2: `packed_weight` is in natural channel order (for_dgrad | 2) and cin % 4 == 0: the kernel gathers
+ * 16 bytes per lane and reads its A fragments with one 16-byte LDS load per 16-channel step. */
 int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);

@@ -167,3 +167,12 @@ def test_workgroup_cooperative_variant_equals_dense(dev, shape, monkeypatch):
     for geom in ("res18 subm k3", "res18 stem/stage conv k3 s2 p1", "centerpoint conv4 k3 s2 p(0,1,1)"):
         for cin, cout in ((64, 64), (64, 128), (256, 256)):
             test_sparse_conv_equals_fp64_dense_conv3d(dev, geom, cin, cout)
+
+
+def test_16_byte_gather_variant_equals_dense(dev, monkeypatch):
+    """EFG_TILE_V4=1 (16-byte gathers, swizzled A tile, natural-order packed weights; an A/B arm, off by default:
+    profiles/r02_v4_sweep.txt) computes the same convolution, forward and both gradients."""
+    monkeypatch.setenv("EFG_TILE_V4", "1")
+    for geom in ("res18 subm k3", "res18 stem/stage conv k3 s2 p1", "centerpoint conv4 k3 s2 p(0,1,1)"):
+        for cin, cout in ((16, 32), (64, 64), (64, 128), (256, 256), (20, 36)):
+            test_sparse_conv_equals_fp64_dense_conv3d(dev, geom, cin, cout)
