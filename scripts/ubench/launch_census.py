@@ -1,0 +1,58 @@
+"""Census of one steady-state ConQueR training step (GPU box): host ops by name and thread (forward / autograd), the
+kernels each launches, and host self-time -- where the ~2000 launches and the ~30 ms of host work come from.
+
+    python scripts/ubench/launch_census.py [--model conquer]"""
+import collections
+import os
+import sys
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from efg_amd.engine import Trainer, synthetic_batch  # noqa: E402
+
+dev = torch.device("cuda:0")
+tr = Trainer(device=dev, seed=0)
+pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
+for s in range(6):
+    tr.step(pool[s % 2])
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.step(pool[0])
+    torch.cuda.synchronize()
+ev = [e for e in prof.events()]
+main_thread = ev[0].thread
+ops = collections.defaultdict(lambda: [0, 0, 0.0, 0.0])  # count, kernels, self cpu us, kernel us
+for e in ev:
+    if e.device_type != torch.autograd.DeviceType.CPU:
+        continue
+    key = (("fwd" if e.thread == main_thread else "bwd"), e.name)
+    ops[key][0] += 1
+    ops[key][1] += len(e.kernels or [])
+    ops[key][2] += e.self_cpu_time_total
+    ops[key][3] += sum(k.duration for k in (e.kernels or []))
+tot = collections.defaultdict(lambda: [0, 0, 0.0, 0.0])
+for (th, name), v in ops.items():
+    for i in range(4):
+        tot[th][i] += v[i]
+for th, v in tot.items():
+    print("%s: %d ops, %d kernel launches, self cpu %.2f ms, kernel %.2f ms" % (th, v[0], v[1], v[2] / 1e3, v[3] / 1e3))
+print("\n-- by launches")
+for (th, name), v in sorted(ops.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%s %-55s %5d ops %5d launches  self cpu %7.2f ms  kernels %7.3f ms" % (th, name[:55], v[0], v[1], v[2] / 1e3, v[3] / 1e3))
+print("\n-- by host self time")
+for (th, name), v in sorted(ops.items(), key=lambda kv: -kv[1][2])[:35]:
+    print("%s %-55s %5d ops %5d launches  self cpu %7.2f ms" % (th, name[:55], v[0], v[1], v[2] / 1e3))
+print("\n-- by kernel time")
+for (th, name), v in sorted(ops.items(), key=lambda kv: -kv[1][3])[:40]:
+    print("%s %-55s %5d ops %5d launches  kernels %7.3f ms" % (th, name[:55], v[0], v[1], v[3] / 1e3))
+print("\n-- GEMM shapes by kernel time")
+g = collections.defaultdict(lambda: [0, 0.0])
+for e in ev:
+    if e.device_type == torch.autograd.DeviceType.CPU and e.name in ("aten::mm", "aten::addmm", "aten::bmm", "aten::baddbmm") and e.kernels:
+        key = (("fwd" if e.thread == main_thread else "bwd"), e.name, str(e.input_shapes)[:90])
+        g[key][0] += 1
+        g[key][1] += sum(k.duration for k in e.kernels)
+for (th, name, shp), (n, us) in sorted(g.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%s %-12s %3d x %8.1f us total  %s" % (th, name, n, us, shp))
