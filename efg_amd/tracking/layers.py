@@ -12,6 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..operators.linear import linear  # F.linear; on long GPU matrices: split weight gradient + HIP bias gradient
+
 
 class MLP(nn.Module):
     """Linear/ReLU stack, no activation after the last layer (blocks.py:5-19)."""
@@ -24,8 +26,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for layer in self.layers[:-1]:
-            x = F.relu(layer(x))
-        return self.layers[-1](x)
+            x = linear(x, layer.weight, layer.bias, relu=True)
+        return linear(x, self.layers[-1].weight, self.layers[-1].bias)
 
 
 def attend(mha, query, memory):
@@ -34,16 +36,16 @@ def attend(mha, query, memory):
     c, h = mha.embed_dim, mha.num_heads
     b, lq, _ = query.shape
     if query is memory:
-        q, k, v = F.linear(query, mha.in_proj_weight, mha.in_proj_bias).chunk(3, dim=-1)
+        q, k, v = linear(query, mha.in_proj_weight, mha.in_proj_bias).chunk(3, dim=-1)
     else:
-        q = F.linear(query, mha.in_proj_weight[:c], mha.in_proj_bias[:c])
-        k, v = F.linear(memory, mha.in_proj_weight[c:], mha.in_proj_bias[c:]).chunk(2, dim=-1)
+        q = linear(query, mha.in_proj_weight[:c], mha.in_proj_bias[:c])
+        k, v = linear(memory, mha.in_proj_weight[c:], mha.in_proj_bias[c:]).chunk(2, dim=-1)
 
     def heads(t):
         return t.reshape(b, t.shape[1], h, c // h).transpose(1, 2)
 
     out = F.scaled_dot_product_attention(heads(q), heads(k), heads(v))
-    return mha.out_proj(out.transpose(1, 2).reshape(b, lq, c))
+    return linear(out.transpose(1, 2).reshape(b, lq, c), mha.out_proj.weight, mha.out_proj.bias)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -65,7 +67,8 @@ class TransformerEncoderLayer(nn.Module):
 
     def _mix(self, x, update):
         x = self.norm1(x + self.dropout1(update))
-        return self.norm2(x + self.dropout2(self.linear2(self.dropout(self.activation(self.linear1(x))))))
+        hidden = self.dropout(linear(x, self.linear1.weight, self.linear1.bias, relu=True))   # activation = ReLU
+        return self.norm2(x + self.dropout2(linear(hidden, self.linear2.weight, self.linear2.bias)))
 
     def forward(self, token, src, pos=None):
         src = self._mix(src, attend(self.point_attn, src, src))
@@ -108,7 +111,11 @@ class FFN(nn.Module):
 
     def forward(self, tgt, tgt_input):
         tgt = self.norm2(tgt + self.dropout2(tgt_input))
-        return self.norm3(tgt + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(tgt))))))
+        if self.activation is F.relu:
+            hidden = linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
+        else:
+            hidden = self.activation(linear(tgt, self.linear1.weight, self.linear1.bias))
+        return self.norm3(tgt + self.dropout3(linear(self.dropout(hidden), self.linear2.weight, self.linear2.bias)))
 
 
 class TransformerEncoderLayerGlobalLocal(nn.Module):

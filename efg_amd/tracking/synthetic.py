@@ -60,5 +60,8 @@ def synthetic_tracking_batch(seed_base, scenes, device=None, **kw):
         sample, info = make_tracking_sample(seed_base + i, **kw)
         if device is not None:
             sample[0]["points"] = torch.from_numpy(sample[0]["points"]).to(device)
+            if sample[0]["points"].is_cuda:  # "the upload is complete once this fires" (see engine.synthetic_batch)
+                sample[0]["ready_event"] = torch.cuda.Event()
+                sample[0]["ready_event"].record(torch.cuda.current_stream(sample[0]["points"].device))
         batch.append((sample, info))
     return batch

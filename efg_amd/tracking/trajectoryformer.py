@@ -15,6 +15,8 @@ numbers are kept and marked "(reference behaviour)".
 
 Not mirrored here: the online tracker (`forward_inference` and its track bank, :244-438, :974-1407).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -125,34 +127,71 @@ class TrajectoryFormer(nn.Module):
 
     def forward_train(self, batched_inputs):
         self.batch_size = len(batched_inputs)
-        clouds, targets, load_boxes3d, load_scores, load_labels = self._inputs(batched_inputs)
-        pred_boxes3d, pred_labels, det_boxes3d, traj = self.organize_proposals(load_boxes3d, load_scores, load_labels)
-        self.num_track = pred_boxes3d.shape[1]
-        zero = pred_boxes3d.new_zeros(1, 1)
-        if self.num_track == 0 or det_boxes3d.shape[1] == 0:
+        prep = self._on_prep_stream(self._prepare, batched_inputs)
+        zero = torch.zeros(1, 1, device=self.device)
+        if prep is None:
             return {"loss_cls": zero, "loss_reg": zero.clone()}
-
-        hypotheses_aug = self.hypotheses_augment(pred_boxes3d, targets)
-        hypotheses, candidates = self.generate_trajectory_hypothses(pred_boxes3d, det_boxes3d, traj,
-                                                                    self.num_hypo_det, hypotheses_aug)
-        tokens = self.get_trajcetory_point_feature(hypotheses, clouds)
+        hypotheses, rois, points = prep["hypotheses"], prep["rois"], prep["points"]
+        tokens = self.get_trajcetory_point_feature(hypotheses, points)
         all_tokens = torch.cat(tokens, 0)
         point_cls = self.point_cls(all_tokens).squeeze(-1)
         boxes_feat = self.get_trajectory_boxes_feature(hypotheses)
         boxes_cls = self.boxes_cls(boxes_feat).reshape(-1, self.num_hypo_train)
-        hypotheses_feat = self.get_trajectory_hypotheses_feat(tokens, boxes_feat, pred_labels)
+        hypotheses_feat = self.get_trajectory_hypotheses_feat(tokens, boxes_feat, prep["pred_labels"])
         joint_cls = torch.cat([self.joint_cls(f).squeeze(-1).reshape(-1, self.num_hypo_train)
                                for f in self.encoder_globallocal(hypotheses_feat)], 0)
         point_reg = self.point_reg(all_tokens).reshape(1, -1, 7)
-
-        fg_iou_mask, fg_reg_mask, ious_targets, gt_boxes = self.get_cls_targets(pred_boxes3d, candidates, targets)
-        rois = candidates[..., :7].reshape(-1, 7)
-        reg_targets = self.get_reg_targets(rois, gt_boxes)
-        loss_cls, loss_reg = self.get_loss(rois, gt_boxes, point_cls, joint_cls, boxes_cls, point_reg, ious_targets,
-                                           reg_targets, fg_reg_mask, fg_iou_mask)
-        if gt_boxes.shape[0] > 0:
+        loss_cls, loss_reg = self.get_loss(rois, prep["gt_boxes"], point_cls, joint_cls, boxes_cls, point_reg,
+                                           prep["ious_targets"], prep["reg_targets"], prep["fg_reg_mask"],
+                                           prep["fg_iou_mask"])
+        if prep["gt_boxes"].shape[0] > 0:
             return {"loss_cls": loss_cls, "loss_reg": loss_reg}
         return {"loss_cls": loss_cls, "loss_reg": zero}
+
+    def _prepare(self, batched_inputs):
+        """Everything of the step that involves no trainable parameter (:141-172, :204-209): NMS, linking, forecast,
+        hypotheses, the point crop, targets.  Returns None for the reference's degenerate case (no track / no
+        detection)."""
+        clouds, targets, load_boxes3d, load_scores, load_labels = self._inputs(batched_inputs)
+        pred_boxes3d, pred_labels, det_boxes3d, traj = self.organize_proposals(load_boxes3d, load_scores, load_labels)
+        self.num_track = pred_boxes3d.shape[1]
+        if self.num_track == 0 or det_boxes3d.shape[1] == 0:
+            return None
+        hypotheses_aug = self.hypotheses_augment(pred_boxes3d, targets)
+        hypotheses, candidates = self.generate_trajectory_hypothses(pred_boxes3d, det_boxes3d, traj,
+                                                                    self.num_hypo_det, hypotheses_aug)
+        points = crop_current_frame_points(self.num_lidar_points, hypotheses, clouds)
+        fg_iou_mask, fg_reg_mask, ious_targets, gt_boxes = self.get_cls_targets(pred_boxes3d, candidates, targets)
+        rois = candidates[..., :7].reshape(-1, 7)
+        return {"hypotheses": hypotheses, "rois": rois, "points": points, "pred_labels": pred_labels,
+                "fg_iou_mask": fg_iou_mask, "fg_reg_mask": fg_reg_mask, "ious_targets": ious_targets,
+                "gt_boxes": gt_boxes, "reg_targets": self.get_reg_targets(rois, gt_boxes)}
+
+    def _on_prep_stream(self, fn, batched_inputs):
+        """Run the parameter-free preparation on a side stream (GPU only, `EFG_TF_PREP_STREAM=0` disables): its ~250
+        host read-backs (kept counts of 11 NMS passes per sample, boolean selections, the augmentation's accept
+        flags) then wait for THAT stream only, so the host prepares step n+1 while the main stream still runs the
+        backward of step n.  The side stream starts from the samples' `ready_event`s when they carry one (the point
+        upload), else from the main stream's current position."""
+        if self.device.type != "cuda" or os.environ.get("EFG_TF_PREP_STREAM", "1") == "0":
+            return fn(batched_inputs)
+        if getattr(self, "_prep_stream", None) is None:
+            self._prep_stream = torch.cuda.Stream(self.device)
+        main, side = torch.cuda.current_stream(self.device), self._prep_stream
+        events = [s[0].get("ready_event") if isinstance(s, (list, tuple)) else s.get("ready_event")
+                  for s, _ in batched_inputs]
+        if all(e is not None for e in events):
+            for e in events:
+                side.wait_event(e)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            prep = fn(batched_inputs)
+        main.wait_stream(side)
+        for v in (prep or {}).values():
+            if torch.is_tensor(v):
+                v.record_stream(main)
+        return prep
 
     # ---- proposals -> trajectories -----------------------------------------------------------------------------
     def class_agnostic_nms(self, pred_boxes3d, pred_scores, nms_thresh=0.1, score_thresh=None, nms_pre_maxsize=4096,
@@ -327,10 +366,10 @@ class TrajectoryFormer(nn.Module):
         feat = torch.cat([torch.cat(blocks, dim=1), src[:, :, 3:]], dim=-1)
         return self.up_dimension_geometry(feat)
 
-    def get_trajcetory_point_feature(self, global_trajectory_hypothses, clouds):
-        """Summary token of each hypothesis' current-frame points after every point-encoder layer (:572-592)."""
+    def get_trajcetory_point_feature(self, global_trajectory_hypothses, pts):
+        """Summary token of each hypothesis' current-frame points after every point-encoder layer (:572-592); `pts` =
+        the cropped points of `crop_current_frame_points` [B, N*H, K, 6]."""
         n_hypo = global_trajectory_hypothses.shape[-2]
-        pts = crop_current_frame_points(self.num_lidar_points, global_trajectory_hypothses, clouds)
         feat = self.get_proposal_aware_point_feature(
             pts.reshape(-1, pts.shape[-2], pts.shape[-1]),
             global_trajectory_hypothses[:, 0].reshape(self.batch_size, 1, -1, 8), self.num_track * n_hypo)

@@ -13,8 +13,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from efg_amd.engine import Trainer, synthetic_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
-tr = Trainer(device=dev, seed=0)
-pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
+if "--model" in sys.argv and sys.argv[sys.argv.index("--model") + 1] == "trajectoryformer":
+    import numpy as np
+
+    from efg_amd.tracking import TrajectoryFormer
+    from efg_amd.tracking.synthetic import synthetic_tracking_batch
+
+    np.random.seed(1000)
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tr = Trainer(config=os.path.join(root, "configs", "trajectoryformer_waymo_centerpoint.yaml"), device=dev, seed=0,
+                 model_cls=TrajectoryFormer, max_iters=1000)
+    pool = [synthetic_tracking_batch(7000 + 100 * p, 4, device=dev, n_points=180000, n_objects=60, n_false=20)
+            for p in range(2)]
+else:
+    tr = Trainer(device=dev, seed=0)
+    pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
 for s in range(6):
     tr.step(pool[s % 2])
 torch.cuda.synchronize()
