@@ -36,11 +36,12 @@ def init_distributed():
     return rank, local_rank, world
 
 
-def synthetic_batch(seed_base, scenes, n_points=180000, n_sweeps=1, device=None, n_boxes=40):
+def synthetic_batch(seed_base, scenes, n_points=180000, n_sweeps=1, device=None, n_boxes=40, clutter=0.0):
     """`scenes` (points on `device`, Waymo-style annotations) pairs in the model's input format."""
     batch = []
     for i in range(scenes):
-        pts, boxes, labels = make_scene(seed_base + i, n_points=n_points, n_sweeps=n_sweeps, n_boxes=n_boxes)
+        pts, boxes, labels = make_scene(seed_base + i, n_points=n_points, n_sweeps=n_sweeps, n_boxes=n_boxes,
+                                        clutter=clutter)
         pts = torch.from_numpy(pts)
         if device is not None:
             pts = pts.to(device)
