@@ -266,11 +266,25 @@ __global__ __launch_bounds__(kPairThreads) void boxes_pair_kernel(const float* _
 // mask[i][cb] bit t  <=>  IoU(box i, box cb*64+t) > thresh, for cb >= i/64 and (cb*64+t) > i.
 // Tiles below the diagonal are never written nor read.  Lane <-> row of the tile; rotated tiles go through the
 // candidate queue and set their bits with ds_or_b64.
+// seg (nullable): segment id of every box, ascending; boxes of different segments never suppress each other
+// (batched NMS of independent sets in one launch).  Tiles whose segment ranges do not meet write zeros and leave.
 template <bool kRotated>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thresh,
-                                                      int col_blocks, unsigned long long* __restrict__ mask) {
+                                                      int col_blocks, unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ seg) {
   const int cb = blockIdx.x, rb = blockIdx.y;
   if (cb < rb) return;
+  __shared__ int seg_c[64];
+  int seg_r = 0;
+  if (seg) {
+    const int row = min(rb * 64 + (int)threadIdx.x, n - 1), col = min(cb * 64 + (int)threadIdx.x, n - 1);
+    seg_r = seg[row];
+    seg_c[threadIdx.x] = seg[col];
+    if (seg[min(rb * 64 + 63, n - 1)] < seg[cb * 64]) {  // sorted ids: the whole tile pairs different segments
+      if (rb * 64 + (int)threadIdx.x < n) mask[((int64_t)rb * 64 + threadIdx.x) * col_blocks + cb] = 0ULL;
+      return;
+    }
+  }
   __shared__ float cols[64 * 7];
   __shared__ float rws[64 * 7];
   __shared__ float pts[kRotated ? 3 * kMaxPts * 64 : 1];
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     unsigned long long bits = 0;
     const int start = (rb == cb) ? lane + 1 : 0;
     for (int t = start; t < ncol; ++t)
-      if (iou_normal(a, cols + t * 7) > thresh) bits |= 1ULL << t;
+      if ((!seg || seg_c[t] == seg_r) && iou_normal(a, cols + t * 7) > thresh) bits |= 1ULL << t;
     if (lane < nrow) mask[((int64_t)rb * 64 + lane) * col_blocks + cb] = bits;
     return;
   } else {
@@ -307,7 +321,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       const float* b = cols + t * 7;
       const float rbb = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
       const float dx = a[0] - b[0], dy = a[1] - b[1], rr = ra + rbb + 0.05f;  // == far_apart(a, b)
-      const bool cand = lane < nrow && (rb != cb || t > lane) && !(dx * dx + dy * dy > rr * rr);
+      const bool cand = lane < nrow && (rb != cb || t > lane) && !(dx * dx + dy * dy > rr * rr) &&
+                        (!seg || seg_c[t] == seg_r);
       if (q.push(cand, lane, t)) drain();
     }
     if (q.n > 0) drain();
@@ -437,8 +452,22 @@ extern "C" size_t efg_nms_workspace_bytes(int n) {
   return align_up((size_t)(n > 0 ? n : 1) * cb * sizeof(unsigned long long), 256);
 }
 
+static int nms_run(const float* boxes_sorted, const int* seg, int n, float thresh, int rotated, int64_t* keep,
+                   int* num_keep, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int rotated, int64_t* keep, int* num_keep,
                            void* ws, size_t ws_bytes, void* stream) {
+  return nms_run(boxes_sorted, nullptr, n, thresh, rotated, keep, num_keep, ws, ws_bytes, stream);
+}
+
+extern "C" int efg_nms_segmented_f32(const float* boxes_sorted, const int32_t* segment, int n, float thresh, int rotated,
+                                     int64_t* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream) {
+  EFG_CHECK_ARG(segment || n == 0, "efg_nms_segmented_f32: segment ids are null");
+  return nms_run(boxes_sorted, segment, n, thresh, rotated, keep, num_keep, ws, ws_bytes, stream);
+}
+
+static int nms_run(const float* boxes_sorted, const int* seg, int n, float thresh, int rotated, int64_t* keep,
+                   int* num_keep, void* ws, size_t ws_bytes, void* stream) {
   EFG_CHECK_ARG(n >= 0, "efg_nms_f32: negative box count %d", n);
   EFG_CHECK_ARG(num_keep, "efg_nms_f32: num_keep is null");
   hipStream_t st = (hipStream_t)stream;
@@ -454,10 +483,10 @@ extern "C" int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int r
   auto* mask = static_cast<unsigned long long*>(ws);
   if (rotated)
     hipLaunchKernelGGL((nms_mask_kernel<true>), dim3(col_blocks, col_blocks), dim3(64), 0, st, boxes_sorted, n, thresh,
-                       col_blocks, mask);
+                       col_blocks, mask, seg);
   else
     hipLaunchKernelGGL((nms_mask_kernel<false>), dim3(col_blocks, col_blocks), dim3(64), 0, st, boxes_sorted, n, thresh,
-                       col_blocks, mask);
+                       col_blocks, mask, seg);
   EFG_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(kReduceThreads),
                      (size_t)(col_blocks + 2) * sizeof(unsigned long long), st, mask, n, col_blocks, keep, num_keep);

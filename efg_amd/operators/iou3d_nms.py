@@ -66,6 +66,47 @@ def _nms(boxes, scores, thresh, pre_maxsize, rotated):
     return order[keep[:num_out]].contiguous(), None
 
 
+def _nms_segmented(boxes_sorted, segment, thresh, rotated):
+    """boxes_sorted [n, 7] (segment-major, score-descending inside a segment), segment int32 [n] ascending ->
+    (keep int64 [n] device buffer, kept count int32 [1] device)."""
+    _check_boxes(boxes_sorted)
+    b = boxes_sorted.contiguous().float()
+    n = b.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    num = torch.empty((1,), dtype=torch.int32, device=b.device)
+    ws_bytes = _lib.lib().efg_nms_workspace_bytes(n)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=b.device)
+    seg = segment.contiguous().to(torch.int32)
+    _lib.check(_lib.lib().efg_nms_segmented_f32(_lib.ptr(b), _lib.ptr(seg), n, float(thresh), 1 if rotated else 0,
+                                                _lib.ptr(keep), _lib.ptr(num), _lib.ptr(ws), ws_bytes, _lib.stream()))
+    return keep, num
+
+
+def nms_gpu_batched(boxes, scores, thresh, score_thresh=None, rotated=True):
+    """`nms_gpu` over S independent sets of M boxes each in one launch (ours; the reference loops in Python).
+
+    boxes [S, M, 7], scores [S, M].  Returns (set_id int64 [K], index int64 [K], counts int64 [S]): the kept boxes set
+    by set, inside a set in the order `nms_gpu(boxes[s][valid], scores[s][valid])` returns them, `index` pointing
+    into the set's M boxes; boxes with score < score_thresh are dropped.  One device->host read (K)."""
+    s, m = scores.shape
+    order = scores.sort(dim=1, descending=True)[1]                       # per set, as nms_gpu sorts (iou3d_nms.py:98)
+    sorted_boxes = torch.gather(boxes, 1, order[..., None].expand(-1, -1, 7)).reshape(s * m, 7)
+    set_id = torch.arange(s, device=scores.device).repeat_interleave(m)
+    keep, num = _nms_segmented(sorted_boxes, set_id, thresh, rotated)
+    n = s * m
+    live = torch.arange(n, device=scores.device) < num                    # the first `num` entries of `keep` are valid
+    keep = keep.clamp(0, n - 1)
+    if score_thresh is not None:
+        # a box below the score threshold sorts behind every valid box of its set, so it cannot have suppressed one;
+        # it only has to be dropped from the result
+        live = live & (torch.gather(scores, 1, order).reshape(-1)[keep] >= score_thresh)
+    kept = keep[live]                                                     # the one compaction (device->host size)
+    kept_set = torch.div(kept, m, rounding_mode="floor")
+    index = order.reshape(-1)[kept]
+    counts = torch.zeros(s, dtype=torch.int64, device=scores.device).index_add_(0, kept_set, torch.ones_like(kept_set))
+    return kept_set, index, counts
+
+
 def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     """Rotated NMS (iou3d_nms.py:90-106): returns (indices into ``boxes`` of the kept ones, None)."""
     return _nms(boxes, scores, thresh, pre_maxsize, True)

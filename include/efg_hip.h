@@ -265,6 +265,12 @@ size_t efg_nms_workspace_bytes(int n);
  * num_to_keep and fills a CPU LongTensor; here nothing leaves the GPU until the caller asks. */
 int efg_nms_f32(const float* boxes_sorted, int n, float thresh, int rotated, int64_t* keep, int* num_keep,
                 void* ws, size_t ws_bytes, void* stream);
+/* The same over several independent sets in one launch: segment i32 [n] = set id of every box, ascending; inside
+ * a set the boxes are ordered by descending score; boxes of different sets never suppress each other.  Replaces a
+ * Python loop of nms_gpu calls (TrajectoryFormer runs 11 per sample per step, $TF/trajectoryformer.py:666-676);
+ * the kept row numbers come back ascending, i.e. set by set in score order.  Workspace: efg_nms_workspace_bytes(n). */
+int efg_nms_segmented_f32(const float* boxes_sorted, const int32_t* segment, int n, float thresh, int rotated,
+                          int64_t* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the

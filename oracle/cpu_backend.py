@@ -161,8 +161,20 @@ def install():
         keep = torch.from_numpy(oracle.nms(_np(boxes[order]), thresh, rotated))
         return order[keep].contiguous(), None
 
+    def nms_segmented(boxes_sorted, segment, thresh, rotated):
+        seg = _np(segment)
+        keep = []
+        for sid in np.unique(seg):
+            rows = np.nonzero(seg == sid)[0]
+            keep.append(rows[oracle.nms(_np(boxes_sorted)[rows], thresh, rotated)])
+        keep = np.concatenate(keep) if keep else np.zeros((0,), np.int64)
+        out = torch.zeros(max(boxes_sorted.shape[0], 1), dtype=torch.int64)
+        out[:len(keep)] = torch.from_numpy(keep.astype(np.int64))
+        return out, torch.tensor([len(keep)], dtype=torch.int32)
+
     patch(iou, "_pairwise", pairwise)
     patch(iou, "_nms", nms)
+    patch(iou, "_nms_segmented", nms_segmented)
 
     patch(core, "_site_index_from_indices", site_index)
     patch(core, "_downsample_geometry", downsample)

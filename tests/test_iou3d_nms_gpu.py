@@ -115,3 +115,27 @@ def test_nms_all_duplicates_and_all_disjoint():
     grid[:, 3:6] = 2
     keep, _ = ops.nms_gpu(torch.from_numpy(grid).cuda(), torch.linspace(1, 0, 150).cuda(), 0.1)
     assert keep.tolist() == list(range(150))
+
+
+@pytest.mark.parametrize("sets,m,extent", [(1, 40, 4.0), (7, 128, 10.0), (44, 128, 14.0), (5, 300, 14.0)])
+@pytest.mark.parametrize("rotated", [True, False])
+def test_batched_nms_equals_per_set_nms(sets, m, extent, rotated):
+    """efg_nms_segmented_f32 (one launch over independent sets, what TrajectoryFormer's 11 per-frame NMS passes per
+    sample become) == a loop of single-set NMS calls against the oracle; zero-padded sets and a score threshold."""
+    ops = _ops()
+    rng = np.random.default_rng(sets * 1000 + m)
+    boxes = np.stack([random_boxes(rng, m, extent) for _ in range(sets)])
+    scores = rng.uniform(0.05, 1.0, (sets, m)).astype(np.float32)
+    for s in range(0, sets, 3):                       # some sets end in zero padding, as the tracker's frames do
+        boxes[s, m // 2:] = 0
+        scores[s, m // 2:] = 0
+    score_thresh = 0.2
+    set_id, index, counts = ops.nms_gpu_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.25,
+                                                score_thresh=score_thresh, rotated=rotated)
+    set_id, index, counts = set_id.cpu().numpy(), index.cpu().numpy(), counts.cpu().numpy()
+    assert len(set_id) == counts.sum()
+    for s in range(sets):
+        valid = np.nonzero(scores[s] >= score_thresh)[0]
+        ref = valid[_nms_ref(boxes[s][valid], scores[s][valid], 0.25, None, rotated)]
+        np.testing.assert_array_equal(index[set_id == s], ref)
+        assert counts[s] == len(ref)
