@@ -82,13 +82,16 @@ def _nms_segmented(boxes_sorted, segment, thresh, rotated):
     return keep, num
 
 
-def nms_gpu_batched(boxes, scores, thresh, score_thresh=None, rotated=True):
+def nms_gpu_batched(boxes, scores, thresh, score_thresh=None, rotated=True, valid=None):
     """`nms_gpu` over S independent sets of M boxes each in one launch (ours; the reference loops in Python).
 
     boxes [S, M, 7], scores [S, M].  Returns (set_id int64 [K], index int64 [K], counts int64 [S]): the kept boxes set
     by set, inside a set in the order `nms_gpu(boxes[s][valid], scores[s][valid])` returns them, `index` pointing
-    into the set's M boxes; boxes with score < score_thresh are dropped.  One device->host read (K)."""
+    into the set's M boxes; boxes with score < score_thresh are dropped, and so are the entries where `valid`
+    (bool [S, M], e.g. padding of ragged sets) is False.  One device->host read (K)."""
     s, m = scores.shape
+    if valid is not None:
+        scores = torch.where(valid, scores, torch.full_like(scores, -float("inf")))   # pads sort behind everything
     order = scores.sort(dim=1, descending=True)[1]                       # per set, as nms_gpu sorts (iou3d_nms.py:98)
     sorted_boxes = torch.gather(boxes, 1, order[..., None].expand(-1, -1, 7)).reshape(s * m, 7)
     set_id = torch.arange(s, device=scores.device).repeat_interleave(m)
@@ -96,10 +99,12 @@ def nms_gpu_batched(boxes, scores, thresh, score_thresh=None, rotated=True):
     n = s * m
     live = torch.arange(n, device=scores.device) < num                    # the first `num` entries of `keep` are valid
     keep = keep.clamp(0, n - 1)
-    if score_thresh is not None:
-        # a box below the score threshold sorts behind every valid box of its set, so it cannot have suppressed one;
-        # it only has to be dropped from the result
-        live = live & (torch.gather(scores, 1, order).reshape(-1)[keep] >= score_thresh)
+    if score_thresh is not None or valid is not None:
+        # a box below the score threshold (or a pad) sorts behind every valid box of its set, so it cannot have
+        # suppressed one; it only has to be dropped from the result
+        floor = -float("inf") if score_thresh is None else score_thresh
+        sorted_scores = torch.gather(scores, 1, order).reshape(-1)[keep]
+        live = live & (sorted_scores >= floor) & (sorted_scores > -float("inf"))
     kept = keep[live]                                                     # the one compaction (device->host size)
     kept_set = torch.div(kept, m, rounding_mode="floor")
     index = order.reshape(-1)[kept]

@@ -154,7 +154,6 @@ def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
     slot = torch.arange(k, device=first.device)
     for b in range(batch):
         cloud = points[b] if isinstance(points, (list, tuple)) else points[points[:, 0] == b][:, 1:]
-        cloud = cloud[cloud[:, -1] < 1]
         boxes = first[b, :, :7]
         radius = torch.sqrt((boxes[:, 3] / 2) ** 2 + (boxes[:, 4] / 2) ** 2) * 1.2
         centre_fill = torch.cat([boxes[:, None, :3].expand(-1, k, -1), boxes.new_zeros(n_rois, k, 3)], -1)
@@ -162,20 +161,23 @@ def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
             out[b] = centre_fill
             continue
         dist = torch.norm(cloud[None, :, :2] - boxes[:, None, :2], dim=2)
-        inside = dist <= radius[:, None]
+        # (points of older sweeps, dt >= 1, are excluded by the membership test instead of a compaction of the cloud:
+        # same points in the same order, one host read-back less)
+        inside = (dist <= radius[:, None]) & (cloud[:, -1] < 1)[None]
         count = inside.sum(1)
-        pairs = inside.nonzero()                      # (roi, point) in roi-major, cloud order
-        start = torch.cumsum(count, 0) - count
-        pick = torch.where(slot[None] < count[:, None], slot[None].expand(n_rois, -1), torch.zeros_like(slot)[None])
-        crowded = (count > k).nonzero().flatten()
-        if crowded.numel():
-            host = count[crowded].tolist()
-            rows = torch.stack([_crowded_choice(c, k) for c in host]).to(first.device)
-            pick = pick.index_copy(0, crowded, rows)
-        flat = (start[:, None] + pick).clamp(max=max(pairs.shape[0] - 1, 0))
-        if pairs.shape[0] == 0:
+        count_host = count.tolist()                   # the scene's one read-back: sizes everything below
+        total = sum(count_host)
+        if total == 0:
             out[b] = centre_fill
             continue
+        pairs = torch.nonzero_static(inside, size=total)   # (roi, point) in roi-major, cloud order
+        start = torch.cumsum(count, 0) - count
+        pick = torch.where(slot[None] < count[:, None], slot[None].expand(n_rois, -1), torch.zeros_like(slot)[None])
+        crowded = [i for i, c in enumerate(count_host) if c > k]
+        if crowded:
+            rows = torch.stack([_crowded_choice(count_host[i], k) for i in crowded]).to(first.device)
+            pick = pick.index_copy(0, torch.as_tensor(crowded, device=first.device), rows)
+        flat = (start[:, None] + pick).clamp(max=total - 1)
         gathered = cloud[pairs[:, 1][flat]]
         out[b] = torch.where((count == 0)[:, None, None], centre_fill, gathered)
     return out

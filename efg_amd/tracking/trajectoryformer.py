@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..operators.iou3d_nms import boxes_iou3d_gpu, nms_gpu
+from ..operators.iou3d_nms import boxes_iou3d_gpu, nms_gpu, nms_gpu_batched
 from .geometry import (crop_current_frame_points, encode_boxes_res_torch, get_corner_points_of_roi, reorder_rois,
                        rotate_points_along_z, spherical_coordinate, transform_trajs_to_global_coords,
                        transform_trajs_to_local_coords)
@@ -216,39 +216,80 @@ class TrajectoryFormer(nn.Module):
         b, t, n, _ = proposals_list.shape
         frames = [proposals_list[:, 0]]
         valid = [torch.ones(b, n, dtype=torch.bool, device=proposals_list.device)]
+        scene = torch.arange(b, device=proposals_list.device)
         for i in range(1, t):
-            last = frames[-1]
+            last, cand = frames[-1], proposals_list[:, i]
             moved = torch.cat([last[..., 0:2] - 0.1 * last[..., 6:8], last[..., 2:]], -1)
-            linked, hit = [], []
-            for s in range(b):
-                iou = boxes_iou3d_gpu(moved[s][:, _XYZLWHR], proposals_list[s, i][:, _XYZLWHR])
-                best, arg = iou.max(dim=1)
-                ok = best >= 0.5
-                linked.append(torch.where(ok[:, None], proposals_list[s, i][arg], torch.zeros_like(moved[s])))
-                hit.append(ok)
-            frames.append(torch.stack(linked))
-            valid.append(torch.stack(hit))
+            # one IoU launch for all scenes; a scene's trajectories only see its own proposals (diagonal blocks)
+            iou = boxes_iou3d_gpu(moved.reshape(b * n, 9)[:, _XYZLWHR], cand.reshape(b * n, 9)[:, _XYZLWHR])
+            iou = iou.view(b, n, b, n)[scene, :, scene, :]
+            best, arg = iou.max(dim=2)
+            ok = best >= 0.5
+            picked = torch.gather(cand, 1, arg.unsqueeze(-1).expand(-1, -1, 9))
+            frames.append(torch.where(ok.unsqueeze(-1), picked, torch.zeros_like(picked)))
+            valid.append(ok)
         return torch.stack(frames, 1), torch.stack(valid, 1)
 
-    def organize_proposals(self, pred_boxes3d, pred_scores, pred_labels):
-        """Per-frame NMS, padding, linking and the one-step forecast (:652-717).  Returns the forecast boxes
-        [B, N, 8], their labels [B, N, 1], the current detections [B, M, 7] and the history [B, T-1, N, 8]."""
+    def _organize_loop(self, pred_boxes3d, pred_scores, pred_labels):
+        """Per-frame NMS and padding exactly as the reference loops them (:652-690)."""
         t1 = self.traj_length + 1
-        per_scene = {"box": [], "score": [], "label": []}
+        per_scene = {"box": [], "label": []}
         for boxes, scores, labels in zip(pred_boxes3d, pred_scores, pred_labels):
             boxes, scores, labels = boxes.reshape(t1, -1, 9), scores.reshape(t1, -1), labels.reshape(t1, -1)
-            kept = {"box": [], "score": [], "label": []}
+            kept = {"box": [], "label": []}
             for j in range(t1):
                 sel = self.class_agnostic_nms(boxes[j][:, [0, 1, 2, 3, 4, 5, 8]], scores[j].reshape(-1),
                                               nms_thresh=self.train_nms_thresh, score_thresh=self.train_score_thresh)
                 kept["box"].append(boxes[j][sel])
-                kept["score"].append(scores[j][sel].reshape(-1, 1))
                 kept["label"].append(labels[j][sel].reshape(-1, 1))
             for key in kept:
                 padded, _ = reorder_rois(kept[key])
                 per_scene[key].append(padded.reshape(-1, padded.shape[-1]))
         frames = reorder_rois(per_scene["box"])[0].reshape(self.batch_size, t1, -1, 9)
         labels = reorder_rois(per_scene["label"])[0].reshape(self.batch_size, t1, -1, 1)
+        return frames, labels
+
+    def _organize_batched(self, pred_boxes3d, pred_scores, pred_labels, width):
+        """The same result from ONE segmented NMS launch over all (scene, frame) sets and one scatter: a scene's
+        frames are padded to its widest frame and flattened, the scenes padded to the longest and re-cut into
+        (traj_length + 1) frames -- including the reference's frame misalignment for scenes narrower than the widest
+        (reference behaviour: it pads the FLATTENED scene, :681-690)."""
+        t1, b, dev = self.traj_length + 1, self.batch_size, pred_boxes3d[0].device
+        boxes = pred_boxes3d[0].new_zeros(b, t1, width, 9)
+        scores = pred_boxes3d[0].new_zeros(b, t1, width)
+        labels = pred_boxes3d[0].new_zeros(b, t1, width)
+        real = torch.zeros(b, t1, width, dtype=torch.bool, device=dev)
+        for i, (bx, sc, lb) in enumerate(zip(pred_boxes3d, pred_scores, pred_labels)):
+            m = bx.shape[0] // t1
+            boxes[i, :, :m], scores[i, :, :m], labels[i, :, :m] = bx.reshape(t1, m, 9), sc.reshape(t1, m), lb.reshape(t1, m)
+            real[i, :, :m] = True
+        set_id, index, counts = nms_gpu_batched(boxes.reshape(b * t1, width, 9)[..., [0, 1, 2, 3, 4, 5, 8]],
+                                                scores.reshape(b * t1, width), self.train_nms_thresh,
+                                                score_thresh=self.train_score_thresh, valid=real.reshape(b * t1, width))
+        count = np.asarray(counts.tolist(), np.int64).reshape(b, t1)
+        per_scene = np.maximum(count.max(axis=1), 1)                     # frames of a scene padded to its widest
+        length = int((per_scene * t1).max())                             # scenes padded to the longest, flattened
+        start = np.concatenate([[0], np.cumsum(count.reshape(-1))[:-1]])
+        start_t = torch.as_tensor(start, device=dev)
+        stride_t = torch.as_tensor(np.repeat(per_scene, t1), device=dev)
+        rank = torch.arange(set_id.shape[0], device=dev) - start_t[set_id]
+        scene, frame = torch.div(set_id, t1, rounding_mode="floor"), set_id % t1
+        dest = frame * stride_t[set_id] + rank
+        frames = boxes.new_zeros(b, length, 9)
+        out_labels = boxes.new_zeros(b, length, 1)
+        frames[scene, dest] = boxes.reshape(b * t1, width, 9)[set_id, index]
+        out_labels[scene, dest, 0] = labels.reshape(b * t1, width)[set_id, index]
+        return frames.reshape(b, t1, -1, 9), out_labels.reshape(b, t1, -1, 1)
+
+    def organize_proposals(self, pred_boxes3d, pred_scores, pred_labels):
+        """Per-frame NMS, padding, linking and the one-step forecast (:652-717).  Returns the forecast boxes
+        [B, N, 8], their labels [B, N, 1], the current detections [B, M, 7] and the history [B, T-1, N, 8]."""
+        t1 = self.traj_length + 1
+        width = max(b.shape[0] // t1 for b in pred_boxes3d)
+        if width > 500:      # beyond nms_post_maxsize the per-set truncation matters: the reference's loop, literally
+            frames, labels = self._organize_loop(pred_boxes3d, pred_scores, pred_labels)
+        else:
+            frames, labels = self._organize_batched(pred_boxes3d, pred_scores, pred_labels, width)
         det_boxes3d = frames[:, 0][..., _XYZLWHR]
         pred_vel = frames[:, 1:2][..., [6, 7]]
         traj, _ = self.generate_trajectory(frames[:, 1:])
