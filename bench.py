@@ -204,7 +204,7 @@ def main():
     scenes_total = args.scenes * world * args.steps
     graph = "full reference graph" if args.full_graph else "unused FPN levels not evaluated"
     line = {
-        "metric": "scenes/sec ConQueR 1-frame Waymo train step",
+        "metric": "scenes/sec %s 1-frame Waymo train step" % {"conquer": "ConQueR", "voxeldetr": "Voxel-DETR"}[args.model],
         "value": scenes_total / elapsed,
         "unit": "scenes/s",
         "n_gpus": world,
