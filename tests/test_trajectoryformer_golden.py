@@ -159,3 +159,107 @@ def test_trajectoryformer_trainer_step_cpu(oracle_mod):
     assert not torch.equal(before, tr.model.point_reg.layers[0].weight)
     assert not tr.model.velboxembed.training and tr.model.seqboxembed.training       # the forecast module stays frozen
     tr.close()
+
+
+def _ragged_detections(seed, widths, t1=11):
+    rng = np.random.default_rng(seed)
+    boxes, scores, labels = [], [], []
+    for m in widths:
+        centre = rng.uniform(-20, 20, (m, 2))
+        tab = np.zeros((t1, m, 9), np.float32)
+        for f in range(t1):
+            tab[f, :, 0:2] = centre + rng.normal(0, 0.15, (m, 2)) + (rng.uniform(size=(m, 1)) < 0.3) * rng.normal(0, 0.6, (m, 2))
+            tab[f, :, 2] = rng.normal(-0.8, 0.1, m)
+            tab[f, :, 3:6] = rng.uniform(0.6, 4.5, (m, 3))
+            tab[f, :, 6:8] = rng.normal(0, 1.0, (m, 2))
+            tab[f, :, 8] = rng.uniform(-np.pi, np.pi, m)
+            tab[f, 1::5] = tab[f, 0::5][: len(tab[f, 1::5])]          # near-duplicates: NMS has something to suppress
+            tab[f, 1::5, 0] += 0.05
+        sc = rng.uniform(0.05, 0.95, (t1, m)).astype(np.float32)
+        drop = rng.uniform(size=(t1, m)) < 0.25                      # zero padding inside frames, as the loader leaves it
+        tab[drop] = 0
+        sc[drop] = 0
+        boxes.append(tab.reshape(-1, 9))
+        scores.append(sc.reshape(-1))
+        labels.append(rng.integers(1, 4, t1 * m).astype(np.float32) * (~drop.reshape(-1)))
+    return boxes, scores, labels
+
+
+def _organisation_case(model, device):
+    """Ragged scenes (different widths, duplicated / overlapping boxes, zero padding): the one-launch organisation must
+    equal the reference's per-frame loop, and the scene-batched linking a per-scene loop."""
+    import efg_amd.tracking.trajectoryformer as tfm
+
+    widths = (9, 4, 14)
+    boxes, scores, labels = _ragged_detections(3, widths)
+    model.batch_size = len(widths)
+    to = lambda xs: [torch.from_numpy(x).to(device) for x in xs]  # noqa: E731
+    frames_a, labels_a = model._organize_batched(to(boxes), to(scores), to(labels), max(widths))
+    frames_b, labels_b = model._organize_loop(to(boxes), to(scores), to(labels))
+    assert frames_a.shape == frames_b.shape and frames_a.shape[2] < max(widths) + 1
+    # kept boxes are the same sets in the same order except among exact score ties of all-zero padding rows
+    assert torch.equal(frames_a, frames_b) and torch.equal(labels_a, labels_b)
+    assert int((frames_a[..., 3:6].sum(-1) > 0).sum()) < sum(11 * w for w in widths) * 0.75      # NMS removed boxes
+    traj, valid = model.generate_trajectory(frames_a[:, 1:])
+    for s in range(len(widths)):                                     # per-scene restatement of the linking
+        prop = frames_a[s, 1:]
+        cur = prop[0]
+        for i in range(1, prop.shape[0]):
+            moved = torch.cat([cur[:, 0:2] - 0.1 * cur[:, 6:8], cur[:, 2:]], -1)
+            iou = tfm.boxes_iou3d_gpu(moved[:, [0, 1, 2, 3, 4, 5, -1]], prop[i][:, [0, 1, 2, 3, 4, 5, -1]])
+            best, arg = iou.max(1)
+            cur = torch.where((best >= 0.5)[:, None], prop[i][arg], torch.zeros_like(cur))
+            assert torch.equal(traj[s, i], cur) and torch.equal(valid[s, i], best >= 0.5)
+    assert bool(valid[:, 1:].any()) and not bool(valid[:, 1:].all())
+
+
+def test_batched_organisation_equals_reference_loop_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    with cpu_backend.install():
+        _organisation_case(_build("cpu"), "cpu")
+
+
+@pytest.mark.gpu
+def test_batched_organisation_equals_reference_loop_gpu(dev):
+    _organisation_case(_build(dev), dev)
+
+
+def _edge_batches():
+    from efg_amd.tracking.synthetic import make_tracking_sample
+
+    a = make_tracking_sample(900, n_points=20000, n_objects=6, n_false=2)
+    b = make_tracking_sample(901, n_points=20000, n_objects=5, n_false=1)
+    no_gt = make_tracking_sample(902, n_points=20000, n_objects=4, n_false=2)
+    for k in ("gt_boxes", "labels", "difficulty", "num_points_in_gt"):
+        no_gt[1]["annotations"][k] = no_gt[1]["annotations"][k][:0]
+    no_points = make_tracking_sample(903, n_points=20000, n_objects=4, n_false=2)
+    no_points[0][0]["points"] = no_points[0][0]["points"][:0]
+    return {"one scene without ground truth": [a, no_gt], "one scene without points": [b, no_points]}
+
+
+def _edge_case(model, install):
+    """Edge inputs of the reference's branches (:768-802 no ground truth in a scene; utils.py:415-420 no points in a
+    ROI): finite losses, gradients for every trained parameter."""
+    for name, batch in _edge_batches().items():
+        np.random.seed(7)
+        model.zero_grad(set_to_none=True)
+        with install():
+            losses = model(batch)
+            total = sum(v.sum() for v in losses.values())
+            total.backward()
+        assert torch.isfinite(total), name
+        assert model.point_reg.layers[0].weight.grad is not None and torch.isfinite(model.point_reg.layers[0].weight.grad).all()
+
+
+def test_trajectoryformer_edge_inputs_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    _edge_case(_build("cpu"), cpu_backend.install)
+
+
+@pytest.mark.gpu
+def test_trajectoryformer_edge_inputs_gpu(dev):
+    import contextlib
+
+    _edge_case(_build(dev), contextlib.nullcontext)
