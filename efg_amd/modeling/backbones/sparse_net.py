@@ -214,13 +214,13 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = out.replace_feature(bn_act(out.features, self.bn1, relu=True))
         out = self.conv2(out)
-        out = out.replace_feature(self.bn2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
-        out = out.replace_feature(out.features + identity.features)
-        return out.replace_feature(self.relu(out.features))
+        # relu(bn2(.) + identity) in one pass (HIP BatchNorm + residual + ReLU on the GPU in training; the PyTorch
+        # modules otherwise)
+        return out.replace_feature(bn_act(out.features, self.bn2, relu=True, residual=identity.features))
 
 
 class SpMiddleResNetFHD(nn.Module):

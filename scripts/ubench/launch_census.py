@@ -25,6 +25,13 @@ if "--model" in sys.argv and sys.argv[sys.argv.index("--model") + 1] == "traject
                  model_cls=TrajectoryFormer, max_iters=1000)
     pool = [synthetic_tracking_batch(7000 + 100 * p, 4, device=dev, n_points=180000, n_objects=60, n_false=20)
             for p in range(2)]
+elif "--model" in sys.argv and sys.argv[sys.argv.index("--model") + 1] == "centerpoint":
+    from efg_amd.centerpoint import VoxelNet
+
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tr = Trainer(config=os.path.join(root, "configs", "centerpoint_waymo_voxelnet.yaml"), device=dev, seed=0,
+                 model_cls=VoxelNet, max_iters=1000)
+    pool = [synthetic_batch(3000 + 100 * p, 2, device=dev) for p in range(2)]
 else:
     tr = Trainer(device=dev, seed=0)
     pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
