@@ -65,3 +65,57 @@ def synthetic_tracking_batch(seed_base, scenes, device=None, **kw):
                 sample[0]["ready_event"].record(torch.cuda.current_stream(sample[0]["points"].device))
         batch.append((sample, info))
     return batch
+
+
+def make_tracking_sequence(seed, frames=8, n_objects=10, n_ground=4000, per_object=160):
+    """A short drive for the online tracker ($TF/trajectoryformer.py:forward_inference): objects with constant global
+    velocity, an ego pose that advances and yaws a little every 0.1 s, and per frame the detector's boxes in the
+    vehicle frame (jitter, misses, a few low-score ghosts), a small current-sweep cloud (ground + object surfaces,
+    columns x y z intensity elongation dt) and the reference's frame token.  Returns a list of `(sample, info)`."""
+    rng = np.random.default_rng(seed)
+    labels = rng.choice([1, 1, 1, 2, 3], n_objects).astype(np.float32)
+    size = np.array([{1: (4.6, 2.0, 1.7), 2: (0.9, 0.8, 1.8), 3: (1.8, 0.7, 1.7)}[int(c)] for c in labels])
+    size = size * rng.uniform(0.9, 1.1, (n_objects, 1))
+    pos0 = np.concatenate([rng.uniform(-35, 35, (n_objects, 2)), -1.8 + size[:, 2:3] / 2], 1)
+    vel = rng.normal(0, 3.0, (n_objects, 2)) * (labels[:, None] == 1) + rng.normal(0, 0.8, (n_objects, 2))
+    yaw = np.arctan2(vel[:, 1], vel[:, 0])
+    out = []
+    for f in range(frames):
+        t = 0.1 * f
+        ego_yaw, ego_xy = 0.02 * f, np.array([6.0 * t, 0.4 * t])
+        c, s = np.cos(ego_yaw), np.sin(ego_yaw)
+        pose = np.array([[c, -s, 0, ego_xy[0]], [s, c, 0, ego_xy[1]], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+        rot = pose[:2, :2]
+        centre = (pos0[:, :2] + vel * t - ego_xy) @ rot                       # R^T (p - t) for row vectors
+        det = np.zeros((n_objects, 9))
+        det[:, 0:2] = centre + rng.normal(0, 0.06, (n_objects, 2))
+        det[:, 2] = pos0[:, 2] + rng.normal(0, 0.03, n_objects)
+        det[:, 3:6] = size * (1 + rng.normal(0, 0.02, (n_objects, 3)))
+        det[:, 6:8] = vel @ rot + rng.normal(0, 0.2, (n_objects, 2))
+        det[:, 8] = yaw - ego_yaw + rng.normal(0, 0.03, n_objects)
+        score = rng.uniform(0.55, 0.97, n_objects)
+        seen = rng.uniform(size=n_objects) > 0.15
+        n_ghost = 3
+        ghost = np.zeros((n_ghost, 9))
+        ghost[:, 0:2] = rng.uniform(-35, 35, (n_ghost, 2))
+        ghost[:, 2] = -0.9
+        ghost[:, 3:6] = rng.uniform(0.6, 4.0, (n_ghost, 3))
+        ghost[:, 8] = rng.uniform(-np.pi, np.pi, n_ghost)
+        boxes = np.concatenate([det[seen], ghost]).astype(np.float32)
+        scores = np.concatenate([score[seen], rng.uniform(0.05, 0.9, n_ghost)]).astype(np.float32)
+        lab = np.concatenate([labels[seen], rng.integers(1, 4, n_ghost).astype(np.float32)]).astype(np.float32)
+        ground = np.concatenate([rng.uniform(-40, 40, (n_ground, 2)), rng.normal(-1.8, 0.03, (n_ground, 1))], 1)
+        surf = []
+        for k in range(n_objects):
+            u = rng.uniform(-0.5, 0.5, (per_object, 3)) * size[k]
+            cy, sy = np.cos(det[k, 8]), np.sin(det[k, 8])
+            surf.append(np.stack([centre[k, 0] + cy * u[:, 0] - sy * u[:, 1], centre[k, 1] + sy * u[:, 0] + cy * u[:, 1],
+                                  pos0[k, 2] + u[:, 2]], 1))
+        xyz = np.concatenate([ground] + surf)
+        pts = np.concatenate([xyz, np.tanh(rng.uniform(0, 2, (len(xyz), 1))), rng.uniform(0, 1.5, (len(xyz), 1)),
+                              np.zeros((len(xyz), 1))], 1).astype(np.float32)
+        pts = pts[rng.permutation(len(pts))]
+        info = {"token": "segment-%d_frame_%d.npy" % (seed, f), "veh_to_global": pose,
+                "annotations": {"pred_boxes3d": boxes, "pred_scores": scores, "pred_labels": lab}}
+        out.append(([{"points": np.ascontiguousarray(pts)}], info))
+    return out

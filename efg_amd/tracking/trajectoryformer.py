@@ -13,7 +13,7 @@ NMS calls (hypothesis targets, linking, augmentation rejection, per-frame NMS) a
 augmentation's rejection loop evaluated in one IoU launch per scene.  Behavioural quirks of the reference that change
 numbers are kept and marked "(reference behaviour)".
 
-Not mirrored here: the online tracker (`forward_inference` and its track bank, :244-438, :974-1407).
+The online tracker (`forward_inference` and its track bank, :244-438, :974-1407) lives in `online.py` and is mixed in.
 """
 import os
 
@@ -29,6 +29,7 @@ from .geometry import (crop_current_frame_points, encode_boxes_res_torch, get_co
 from .layers import (MLP, MotionEncoder, PointNet, TransformerEncoder, TransformerEncoderGlobalLocal,
                      TransformerEncoderLayer, TransformerEncoderLayerGlobalLocal)
 from .losses import WeightedSmoothL1Loss, get_corner_loss
+from .online import OnlineTrackingMixin
 
 _XYZLWHR = [0, 1, 2, 3, 4, 5, -1]
 
@@ -38,7 +39,7 @@ _AUG_LEVELS = ((0.5, 0.1, np.pi / 12), (0.5, 0.15, np.pi / 12), (0.5, 0.15, np.p
 _AUG_TRIES = 20
 
 
-class TrajectoryFormer(nn.Module):
+class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
     def __init__(self, config):
         super().__init__()
         m, d = config.model, config.dataset
@@ -78,6 +79,8 @@ class TrajectoryFormer(nn.Module):
         self.train_nms_thresh = d.nms_thresh
         self.train_score_thresh = d.score_thresh
         self.load_motion_module = False
+        if hasattr(m, "num_hypo_pred_eval"):      # the tracker's thresholds (eval-only keys of the reference YAML)
+            self._init_online(config)
         self.to(self.device)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -103,7 +106,7 @@ class TrajectoryFormer(nn.Module):
         if not self.load_motion_module:
             self.load_pretrain_motionencoder()
         if not self.is_train:
-            raise NotImplementedError("efg_amd.tracking covers the training step; the online tracker is not mirrored")
+            return self.forward_inference(batched_inputs)
         return self.forward_train(batched_inputs)
 
     # ------------------------------------------------------------------------------------------------------------

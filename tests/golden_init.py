@@ -104,3 +104,6 @@ def tracking_inputs(seed=500, scenes=2):
     from efg_amd.tracking.synthetic import make_tracking_sample
 
     return [make_tracking_sample(seed + i, **TRACKING_SAMPLE) for i in range(scenes)]
+
+# the online tracker: 8 frames of a 10-object drive
+ONLINE_SEQUENCE = {"seed": 321, "frames": 8, "n_objects": 10}

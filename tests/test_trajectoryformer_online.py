@@ -1,0 +1,59 @@
+"""TrajectoryFormer's online tracker vs the reference's own `forward_inference`
+(tests/golden/trajectoryformer_online.npz, scripts/make_golden_tracker.py): eight frames of a synthetic drive, frame by
+frame -- track births, survivals through association, survivals through forecast confidence, deaths.  Track ids and
+labels must be identical; boxes / scores within 1e-4 (fp32, decisions are thresholded so a flip would change the ids)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, golden
+from golden_init import ONLINE_SEQUENCE, deterministic_state
+
+
+def _run(device, install):
+    from efg_amd.config import load_config
+    from efg_amd.tracking import TrajectoryFormer
+    from efg_amd.tracking.synthetic import make_tracking_sequence
+
+    g = golden("trajectoryformer_online.npz")
+    cfg = load_config(os.path.join(ROOT, "configs", "trajectoryformer_waymo_centerpoint.yaml"),
+                      {"model.device": str(device), "task": "val", "model.eval_class": "VEHICLE"})
+    torch.manual_seed(0)
+    model = TrajectoryFormer(cfg)
+    model.load_state_dict(deterministic_state(model.state_dict()))
+    model.eval()
+    seq = make_tracking_sequence(**ONLINE_SEQUENCE)
+    for f, (sample, info) in enumerate(seq):
+        check = float(np.abs(sample[0]["points"]).sum(dtype=np.float64)) + \
+            float(np.abs(info["annotations"]["pred_boxes3d"]).sum(dtype=np.float64))
+        assert check == float(g["in.checksum"][f])
+    births = deaths = 0
+    previous = set()
+    with install():
+        for f, item in enumerate(seq):
+            res = model([item])[0]
+            ids = res["track_ids"].numpy().astype(np.int64)
+            assert ids.tolist() == g["frame%d.track_ids" % f].tolist(), "frame %d: %s vs %s" % (
+                f, ids.tolist(), g["frame%d.track_ids" % f].tolist())
+            np.testing.assert_array_equal(res["track_labels"].numpy(), g["frame%d.track_labels" % f])
+            np.testing.assert_allclose(res["track_boxes3d"].numpy(), g["frame%d.track_boxes3d" % f], rtol=0, atol=2e-4)
+            np.testing.assert_allclose(res["track_scores"].numpy(), g["frame%d.track_scores" % f], rtol=0, atol=1e-4)
+            births += len(set(ids.tolist()) - previous) if f else 0
+            deaths += len(previous - set(ids.tolist()))
+            previous = set(ids.tolist())
+    assert births >= 5 and deaths >= 5          # the fixture exercises both
+
+
+def test_online_tracker_matches_reference_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    torch.set_num_threads(8)
+    _run("cpu", cpu_backend.install)
+
+
+@pytest.mark.gpu
+def test_online_tracker_matches_reference_gpu(dev):
+    import contextlib
+
+    _run(dev, contextlib.nullcontext)
