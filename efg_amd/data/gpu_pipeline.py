@@ -8,8 +8,8 @@ the reference's order, so a numpy seed produces the same augmentation as the ref
 arithmetic is deferred into an op list and executed by ONE kernel when the cloud is filtered or materialised
 (efg_points_transform_filter_f32), instead of one numpy pass per processor on DataLoader workers.
 
-DatabaseSampling (GT paste from an on-disk database) and the CPU Voxelization processor are not mirrored: the
-model voxelizes on the GPU (operators/voxelize.py).
+`DatabaseSampling` (ground-truth paste) is in gt_database.py, with the object database resident in HBM; the CPU
+`Voxelization` processor is not mirrored: the model voxelizes on the GPU (operators/voxelize.py).
 """
 import ctypes
 

@@ -33,7 +33,7 @@ def column_sum(x2):
 
 
 _SPLIT_MIN_ROWS = 32768
-_FUSED_MIN_ROWS = 16384  # linear(): rows from which the custom backward is used
+_FUSED_MIN_ROWS = int(os.environ.get("EFG_LINEAR_MIN_ROWS", "16384"))  # linear(): rows from which the custom backward is used
 _SPLITS = 16
 
 

@@ -27,7 +27,7 @@ class _Stub(types.ModuleType):
         return None
 
 
-def load_reference_processors():
+def install_stubs():
     for name in ["cv2", "numba", "PIL", "PIL.Image", "portalocker", "tabulate", "termcolor", "omegaconf", "pycocotools",
                  "pycocotools.mask", "shapely", "shapely.geometry", "torchvision", "torchvision.ops",
                  "torchvision.ops.boxes", "torchvision.transforms", "fvcore", "fvcore.transforms",
@@ -49,6 +49,10 @@ def load_reference_processors():
         m = types.ModuleType(pkg)
         m.__path__ = [REF + "/" + pkg.replace(".", "/")]
         sys.modules[pkg] = m
+
+
+def load_reference_processors():
+    install_stubs()
     return importlib.import_module("efg.data.augmentations.extend_3d")
 
 
