@@ -211,10 +211,17 @@ class PointShuffle:
         return points, info
 
 
-def build_train_pipeline(pc_range, p_flip=0.5, rotation=0.78539816, min_scale=0.8, max_scale=1.2, p_shuffle=1.0):
-    """The ConQueR train chain of $CQ/config.yaml:32-42 without DatabaseSampling / Voxelization."""
-    return [RandomFlip3D(p_flip), GlobalRotation(rotation), GlobalScaling(min_scale, max_scale),
-            FilterByRange(pc_range), PointShuffle(p_shuffle)]
+def build_train_pipeline(pc_range, p_flip=0.5, rotation=0.78539816, min_scale=0.8, max_scale=1.2, p_shuffle=1.0,
+                         database=None):
+    """The ConQueR train chain of $CQ/config.yaml:24-42 (Voxelization happens inside the model, on the GPU);
+    `database`: a `gt_database.DeviceGTDatabase` for the leading DatabaseSampling processor, or None to skip it."""
+    chain = [RandomFlip3D(p_flip), GlobalRotation(rotation), GlobalScaling(min_scale, max_scale),
+             FilterByRange(pc_range), PointShuffle(p_shuffle)]
+    if database is not None:
+        from .gt_database import DatabaseSampling
+
+        chain.insert(0, DatabaseSampling(database))
+    return chain
 
 
 def run(pipeline, points, info):

@@ -67,3 +67,39 @@ def test_pasted_cloud_matches_reference_gpu(dev):
         assert cloud.is_cuda
         np.testing.assert_array_equal(cloud.cpu().numpy(), g["case%d.points" % case])
         np.testing.assert_array_equal(info["annotations"]["gt_boxes"].astype(np.float32), g["case%d.gt_boxes" % case])
+
+
+@pytest.mark.gpu
+def test_device_pipeline_feeds_the_training_step(dev):
+    """The whole loader-side chain of $CQ/config.yaml:24-42 on the device -- ground-truth paste from the HBM-resident
+    database, flip, rotation, scaling, range filter, shuffle -- straight into one ConQueR training step: no host copy of
+    the cloud anywhere between the raw sweep and the loss."""
+    from efg_amd.data.gpu_pipeline import DevicePoints, build_train_pipeline, run
+    from efg_amd.data.synthetic import PC_RANGE, make_scene
+    from efg_amd.data.synthetic_db import make_database
+    from efg_amd.engine import Trainer
+
+    from efg_amd.data.gt_database import DeviceGTDatabase
+
+    np.random.seed(5)
+    infos, clouds = make_database(seed=7)
+    db = DeviceGTDatabase(infos, clouds, [{"VEHICLE": 15}, {"PEDESTRIAN": 10}, {"CYCLIST": 10}], min_points=5, device=dev)
+    chain = build_train_pipeline(PC_RANGE, database=db)
+    names = np.array(["VEHICLE", "PEDESTRIAN", "CYCLIST"])
+    batch = []
+    for s in range(2):
+        pts, boxes, labels = make_scene(9000 + s, n_points=40000, n_boxes=8)
+        info = {"annotations": {"gt_boxes": boxes[:, [0, 1, 2, 3, 4, 5, 8]].copy(), "gt_names": names[labels - 1],
+                                "difficulty": np.zeros(len(labels), np.int64),
+                                "num_points_in_gt": np.full(len(labels), 50, np.int64)}}
+        cloud, info = run(chain, DevicePoints(torch.from_numpy(pts).to(dev)), info)
+        ann = info["annotations"]
+        assert cloud.is_cuda and len(ann["gt_boxes"]) > 8 and cloud.shape[0] > 30000      # objects were pasted
+        ann["labels"] = np.array([list(names).index(n) + 1 for n in ann["gt_names"]], np.int64)
+        ann["gt_boxes"] = ann["gt_boxes"].astype(np.float32)
+        batch.append(({"points": cloud}, {"annotations": ann}))
+    tr = Trainer(device=dev, seed=0, overrides={"model.transformer.num_queries": 100, "model.transformer.enc_layers": 1},
+                 ddp=False)
+    loss_dict, total = tr.step(batch)
+    assert torch.isfinite(total) and len(loss_dict) == 32
+    tr.close()
