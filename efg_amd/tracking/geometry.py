@@ -136,6 +136,39 @@ def _crowded_choice(count, k):
     return torch.from_numpy(np.random.choice(count, k, replace=False).astype(np.int64))
 
 
+def _crop_select_gpu(first, clouds, k):
+    """Membership of every (box, point) through csrc/crop.hip: per scene the boxes' cylinders against its points, all
+    scenes in one launch.  Returns (cloud [sum P, 6], point_base [B], count [B, R] (host list), start [B, R] tensor,
+    index [total] -- scene-local rows of the inside points, box by box in cloud order)."""
+    from .. import _lib as L
+
+    batch, n_rois = first.shape[:2]
+    dev = first.device
+    padded = (n_rois + 15) // 16 * 16
+    sizes = [c.shape[0] for c in clouds]
+    base = np.concatenate([[0], np.cumsum(sizes)])
+    cloud = torch.cat([c.contiguous() for c in clouds], 0) if batch > 1 else clouds[0].contiguous()
+    radius = torch.sqrt((first[..., 3] / 2) ** 2 + (first[..., 4] / 2) ** 2) * 1.2
+    xyr = first.new_full((batch, padded, 3), -1.0)
+    xyr[:, :n_rois, 0:2] = first[..., 0:2]
+    xyr[:, :n_rois, 2] = radius
+    rng = torch.as_tensor(np.repeat(np.stack([base[:-1], base[1:]], 1)[:, None, :], padded, 1), device=dev).contiguous()
+    counts = torch.zeros(batch * padded, dtype=torch.int32, device=dev)
+    lib = L.lib()
+    L.check(lib.efg_cylinder_select_f32(L.ptr(cloud), cloud.shape[0], cloud.shape[1], cloud.shape[1] - 1, 1.0, L.ptr(rng),
+                                        L.ptr(xyr), batch * padded, None, L.ptr(counts), None, L.stream()))
+    host = counts.view(batch, padded)[:, :n_rois].tolist()          # the step's one read-back for the crop
+    flat_counts = counts.view(batch, padded).long()
+    starts = (torch.cumsum(flat_counts.reshape(-1), 0) - flat_counts.reshape(-1)).contiguous()
+    total = int(sum(sum(h) for h in host))
+    index = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    if total:
+        L.check(lib.efg_cylinder_select_f32(L.ptr(cloud), cloud.shape[0], cloud.shape[1], cloud.shape[1] - 1, 1.0,
+                                            L.ptr(rng), L.ptr(xyr), batch * padded, L.ptr(starts), None, L.ptr(index),
+                                            L.stream()))
+    return cloud, base, host, starts.view(batch, padded)[:, :n_rois], index, total
+
+
 def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
     """Points of the current sweep inside the 1.2 x half-diagonal cylinder of every frame-0 hypothesis box.
 
@@ -144,40 +177,60 @@ def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
     points in cloud order, padded with its first point; an empty ROI gets its own centre with zero features; a ROI
     with more than `num_lidar_points` points is sub-sampled with the reference's fixed NumPy draw.
 
-    One pass per scene: distance matrix -> membership -> ranks by prefix sum -> one gather.
+    On the GPU the membership comes from `efg_cylinder_select_f32` (all scenes in two launches, no [boxes x points]
+    matrix, one read-back); host tensors take the PyTorch formulation below (`_crop_scene_torch`).
     """
     batch, _, n_track, n_hypo, _ = trajectory_rois.shape
     n_rois = n_track * n_hypo
     first = trajectory_rois[:, 0].reshape(batch, n_rois, 8)
     k = num_lidar_points
-    out = first.new_zeros(batch, n_rois, k, 6)
-    slot = torch.arange(k, device=first.device)
-    for b in range(batch):
-        cloud = points[b] if isinstance(points, (list, tuple)) else points[points[:, 0] == b][:, 1:]
-        boxes = first[b, :, :7]
-        radius = torch.sqrt((boxes[:, 3] / 2) ** 2 + (boxes[:, 4] / 2) ** 2) * 1.2
-        centre_fill = torch.cat([boxes[:, None, :3].expand(-1, k, -1), boxes.new_zeros(n_rois, k, 3)], -1)
-        if cloud.shape[0] == 0:
-            out[b] = centre_fill
-            continue
-        dist = torch.norm(cloud[None, :, :2] - boxes[:, None, :2], dim=2)
-        # (points of older sweeps, dt >= 1, are excluded by the membership test instead of a compaction of the cloud:
-        # same points in the same order, one host read-back less)
-        inside = (dist <= radius[:, None]) & (cloud[:, -1] < 1)[None]
-        count = inside.sum(1)
-        count_host = count.tolist()                   # the scene's one read-back: sizes everything below
-        total = sum(count_host)
-        if total == 0:
-            out[b] = centre_fill
-            continue
-        pairs = torch.nonzero_static(inside, size=total)   # (roi, point) in roi-major, cloud order
-        start = torch.cumsum(count, 0) - count
-        pick = torch.where(slot[None] < count[:, None], slot[None].expand(n_rois, -1), torch.zeros_like(slot)[None])
-        crowded = [i for i, c in enumerate(count_host) if c > k]
-        if crowded:
-            rows = torch.stack([_crowded_choice(count_host[i], k) for i in crowded]).to(first.device)
-            pick = pick.index_copy(0, torch.as_tensor(crowded, device=first.device), rows)
-        flat = (start[:, None] + pick).clamp(max=total - 1)
-        gathered = cloud[pairs[:, 1][flat]]
-        out[b] = torch.where((count == 0)[:, None, None], centre_fill, gathered)
-    return out
+    clouds = [points[b] if isinstance(points, (list, tuple)) else points[points[:, 0] == b][:, 1:] for b in range(batch)]
+    centre_fill = torch.cat([first[:, :, None, :3].expand(-1, -1, k, -1), first.new_zeros(batch, n_rois, k, 3)], -1)
+    if not first.is_cuda:
+        return torch.stack([_crop_scene_torch(k, first[b], clouds[b], centre_fill[b]) for b in range(batch)])
+    cloud, base, host, start, index, total = _crop_select_gpu(first, clouds, k)
+    if total == 0:
+        return centre_fill
+    dev = first.device
+    count = torch.as_tensor(host, device=dev)
+    slot = torch.arange(k, device=dev)
+    pick = torch.where(slot[None, None] < count[..., None], slot[None, None].expand(batch, n_rois, -1),
+                       torch.zeros_like(slot)[None, None])
+    crowded = [(b, r) for b in range(batch) for r, c in enumerate(host[b]) if c > k]
+    if crowded:     # in (scene, box) order: leaves NumPy's generator where the reference's loop leaves it
+        rows = torch.stack([_crowded_choice(host[b][r], k) for b, r in crowded]).to(dev)
+        flat = torch.as_tensor([b * n_rois + r for b, r in crowded], device=dev)
+        pick = pick.reshape(batch * n_rois, k).index_copy(0, flat, rows).reshape(batch, n_rois, k)
+    local = index[(start[..., None] + pick).clamp(max=total - 1)].long()
+    rows = local + torch.as_tensor(base[:-1], device=dev)[:, None, None]
+    gathered = cloud[rows.clamp(max=cloud.shape[0] - 1)]
+    return torch.where((count == 0)[..., None, None], centre_fill, gathered)
+
+
+def _crop_scene_torch(k, boxes8, cloud, centre_fill):
+    """One scene with PyTorch ops (host tensors: the CPU tests and the golden comparison)."""
+    n_rois = boxes8.shape[0]
+    boxes = boxes8[:, :7]
+    slot = torch.arange(k, device=boxes.device)
+    radius = torch.sqrt((boxes[:, 3] / 2) ** 2 + (boxes[:, 4] / 2) ** 2) * 1.2
+    if cloud.shape[0] == 0:
+        return centre_fill
+    dist = torch.norm(cloud[None, :, :2] - boxes[:, None, :2], dim=2)
+    # (points of older sweeps, dt >= 1, are excluded by the membership test instead of a compaction of the cloud:
+    # same points in the same order)
+    inside = (dist <= radius[:, None]) & (cloud[:, -1] < 1)[None]
+    count = inside.sum(1)
+    count_host = count.tolist()
+    total = sum(count_host)
+    if total == 0:
+        return centre_fill
+    pairs = torch.nonzero_static(inside, size=total)   # (roi, point) in roi-major, cloud order
+    start = torch.cumsum(count, 0) - count
+    pick = torch.where(slot[None] < count[:, None], slot[None].expand(n_rois, -1), torch.zeros_like(slot)[None])
+    crowded = [i for i, c in enumerate(count_host) if c > k]
+    if crowded:
+        rows = torch.stack([_crowded_choice(count_host[i], k) for i in crowded]).to(boxes.device)
+        pick = pick.index_copy(0, torch.as_tensor(crowded, device=boxes.device), rows)
+    flat = (start[:, None] + pick).clamp(max=total - 1)
+    gathered = cloud[pairs[:, 1][flat]]
+    return torch.where((count == 0)[:, None, None], centre_fill, gathered)

@@ -273,6 +273,20 @@ int efg_nms_segmented_f32(const float* boxes_sorted, const int32_t* segment, int
                           int64_t* keep, int* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Points inside vertical cylinders, per cylinder in cloud order (csrc/crop.hip).  Replaces the [boxes x points]
+ * distance matrix + per-box Python loop of TrajectoryFormer's crop_current_frame_points
+ * (playground/tracking.3d/waymo/trajectoryformer/trajectoryformer.centerpoint/modules/utils.py:361-431).
+ * points f32 [n_points][f] (several scenes concatenated); cylinder c tests the rows point_range[c] = {lo, hi} against
+ * centre_radius[c] = {x, y, r}: inside <=> sqrt(dx^2 + dy^2) <= r (and points[time_col] < max_time unless
+ * time_col < 0).  n_cyl must be a multiple of 16 and every aligned group of 16 must share one point range (pad a
+ * scene's list with r = -1).  Call 1: starts = index = NULL, counts i32 [n_cyl] <- number of points inside.
+ * Call 2: starts i64 [n_cyl] (exclusive prefix of the counts), index i32 [sum counts] <- the rows (relative to lo) of
+ * cylinder c's points, ascending, at index[starts[c] ...]. */
+int efg_cylinder_select_f32(const float* points, int64_t n_points, int f, int time_col, float max_time,
+                            const int64_t* point_range, const float* centre_radius, int64_t n_cyl, const int64_t* starts,
+                            int32_t* counts, int32_t* index, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the
  * device->host transfer + scipy.optimize.linear_sum_assignment(C[b]) of $CQ/modules/matcher.py:86-91.
  *   cost f32 [p, nq, g_stride]: p independent problems (layers x scenes), nq queries (rows) x GT

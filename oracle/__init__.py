@@ -297,3 +297,23 @@ def lsap(cost, ng=None):
     if rc != 0:
         raise ValueError("cost matrix is infeasible")
     return out[:ng]
+
+
+# ------------------------------------------------------------------------------------------------
+# TrajectoryFormer point crop: membership of points in vertical cylinders (checker for csrc/crop.hip)
+# ------------------------------------------------------------------------------------------------
+def cylinder_select(points, point_range, centre_radius, time_col=-1, max_time=1.0):
+    """numpy restatement of the membership test of $TF/modules/utils.py:361-402 (fp32: sqrt(dx*dx + dy*dy) <= r,
+    optional time gate).  Returns (counts [R], list of index arrays relative to each cylinder's range start)."""
+    pts = _f(points)
+    counts, lists = [], []
+    for (lo, hi), (x, y, r) in zip(np.asarray(point_range, np.int64), _f(centre_radius)):
+        seg = pts[lo:hi]
+        dx, dy = seg[:, 0] - np.float32(x), seg[:, 1] - np.float32(y)
+        inside = np.sqrt(dx * dx + dy * dy, dtype=np.float32) <= np.float32(r)
+        if time_col >= 0:
+            inside &= seg[:, time_col] < np.float32(max_time)
+        idx = np.nonzero(inside)[0].astype(np.int32)
+        counts.append(len(idx))
+        lists.append(idx)
+    return np.asarray(counts, np.int32), lists
