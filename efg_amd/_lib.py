@@ -91,6 +91,7 @@ _SIGS = {
     "efg_bn_backward_f32": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "efg_lsap_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_nms_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_tile_shape": (c_int, [c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "efg_cylinder_select_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
     "efg_nms_segmented_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

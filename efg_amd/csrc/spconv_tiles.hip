@@ -444,6 +444,27 @@ void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
   else launch_tiles_v<NT, R, 0>(a, ny, ks, stream);
 }
 
+// The launch shape of a (cin, cout, kvol, rows) convolution: NT n-tiles per wave, R sub-tiles per wave, KS split-K
+// waves, pipelined weight loads.  ONE definition for the launcher below and for efg_spconv_tile_shape (what the host
+// side labels its timings with).
+void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* nt_out, int* r_out, int* ks_out, int* pipe_out) {
+  static const int r_env = getenv("EFG_TILE_R") ? atoi(getenv("EFG_TILE_R")) : 0;
+  static const int ks_env = getenv("EFG_TILE_KS") ? atoi(getenv("EFG_TILE_KS")) : 0;
+  static const int nt_env = getenv("EFG_TILE_NT") ? atoi(getenv("EFG_TILE_NT")) : 0;
+  static const int pipe_env = getenv("EFG_TILE_PIPE") ? atoi(getenv("EFG_TILE_PIPE")) : -1;
+  const int ntiles = (cout + 15) / 16;
+  int nt = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
+  if (nt_env > 0) nt = nt_env <= 1 ? 1 : (nt_env <= 2 ? 2 : 4);
+  int r = (cin >= 128 && nt >= 4 && kvol >= 8 && m_in == m_out) ? 2 : 1;  // (submanifold: dense tables)
+  if (r_env > 0) r = r_env >= 2 ? 2 : 1;
+  int ks = (kvol >= 8) ? 4 : 1;
+  if (ks_env > 0) ks = ks_env >= 4 ? 4 : (ks_env >= 2 ? 2 : 1);
+  *nt_out = nt;
+  *r_out = r;
+  *ks_out = ks;
+  *pipe_out = pipe_env >= 0 ? pipe_env : (r == 2 ? 1 : 0);
+}
+
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
               const void* plan, int64_t m_out, float* out, int flip, int natural_order, hipStream_t stream) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
@@ -492,24 +513,14 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   //  * R = 2 sub-tiles per wave + software-pipelined weight loads once a step is long enough to amortise the extra
   //    registers (submanifold layers with cin >= 128; the strided layers' sparse tables lose with it), else R = 1;
   //  * NT = min(4, n-tiles): 64 output channels per wave, wider outputs tile over grid.y (each re-gathers A).
-  static const int r_env = getenv("EFG_TILE_R") ? atoi(getenv("EFG_TILE_R")) : 0;
-  static const int ks_env = getenv("EFG_TILE_KS") ? atoi(getenv("EFG_TILE_KS")) : 0;
-  static const int nt_env = getenv("EFG_TILE_NT") ? atoi(getenv("EFG_TILE_NT")) : 0;
-  static const int pipe_env = getenv("EFG_TILE_PIPE") ? atoi(getenv("EFG_TILE_PIPE")) : -1;
-  static const int deal_env = getenv("EFG_TILE_DEAL") ? atoi(getenv("EFG_TILE_DEAL")) : 1;
-  const long long tiles16 = ceil_div(m_out, 16);
-  int nt = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
-  if (nt_env > 0) nt = nt_env <= 1 ? 1 : (nt_env <= 2 ? 2 : 4);
+  int nt, r, ks, pipe;
+  tile_shape(cin, cout, kvol, m_in, m_out, &nt, &r, &ks, &pipe);
   const int ny = (ntiles + nt - 1) / nt;
-  int r = (cin >= 128 && nt >= 4 && kvol >= 8 && m_in == m_out) ? 2 : 1;  // (submanifold: dense tables)
-  if (r_env > 0) r = r_env >= 2 ? 2 : 1;
-  int ks = (kvol >= 8) ? 4 : 1;
-  if (ks_env > 0) ks = ks_env >= 4 ? 4 : (ks_env >= 2 ? 2 : 1);
-  a.pipe = pipe_env >= 0 ? pipe_env : (r == 2 ? 1 : 0);
+  static const int deal_env = getenv("EFG_TILE_DEAL") ? atoi(getenv("EFG_TILE_DEAL")) : 1;
+  a.pipe = pipe;
   a.deal = deal_env;
   static const int xcd_env = getenv("EFG_TILE_XCD") ? atoi(getenv("EFG_TILE_XCD")) : 1;
   a.xcd = xcd_env;
-  (void)tiles16;
   if (r == 2) {
     switch (nt) {
       case 4: launch_tiles<4, 2>(a, ny, ks, stream); break;
@@ -547,6 +558,13 @@ extern "C" int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, voi
   hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)ceil_div(m, kChunkRows)), dim3(256), 0, stream, nbr, (long long)m, kvol,
                      pv.rows, pv.nb, pv.vm);
   EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_spconv_tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* nt, int* r, int* ks) {
+  EFG_CHECK_ARG(cin >= 1 && cout >= 1 && kvol >= 1 && nt && r && ks, "tile_shape: bad arguments");
+  int pipe = 0;
+  tile_shape(cin, cout, kvol, m_in, m_out, nt, r, ks, &pipe);
   return EFG_OK;
 }
 

@@ -77,10 +77,21 @@ def _tiled():
     return os.environ.get("EFG_CONV_TILED", "1") != "0"
 
 
-def _tile_kernel_name(n_out_channels):
-    """Label of a tiled launch: the NT (16-column tiles per wave) instantiation, csrc/spconv_tiles.hip:run_tiles."""
-    ntiles = (n_out_channels + 15) // 16
-    return "conv_tile_kernel<%d>" % (4 if ntiles >= 4 else 2 if ntiles >= 2 else 1)
+_SHAPE_CACHE = {}
+
+
+def _tile_kernel_name(cin, cout, kvol, m_in, m_out):
+    """Label of a tiled launch = the NT (16-column tiles per wave) of the instantiation the library will run, asked
+    from the library itself (efg_spconv_tile_shape shares its rule with the launcher)."""
+    key = (cin, cout, kvol, m_in == m_out)
+    if key not in _SHAPE_CACHE:
+        import ctypes
+
+        nt, r, ks = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.check(L.lib().efg_spconv_tile_shape(cin, cout, kvol, m_in, m_out, ctypes.byref(nt), ctypes.byref(r),
+                                              ctypes.byref(ks)))
+        _SHAPE_CACHE[key] = "conv_tile_kernel<%d>" % nt.value
+    return _SHAPE_CACHE[key]
 
 
 def _build_plan(table, m, kvol):
@@ -152,7 +163,7 @@ def _conv_forward(features, w, bias, rb):
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
     if tiled:
         plan = rb.plan_fwd()
-        with _prof.timed(_tile_kernel_name(cout), _Cost(rb, cin, cout, "fwd")):
+        with _prof.timed(_tile_kernel_name(cin, cout, kvol, rb.m_in, rb.m_out), _Cost(rb, cin, cout, "fwd")):
             L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(features), rb.m_in, cin, L.ptr(packed), L.ptr(bias), cout,
                                                      kvol, L.ptr(plan), rb.m_out, 0 | nat, L.ptr(out), L.stream()))
         return out
@@ -179,7 +190,7 @@ def _conv_dgrad(grad_out, w, rb):
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     if tiled:
         plan, flip = rb.plan_dgrad()
-        with _prof.timed(_tile_kernel_name(cin), _Cost(rb, cin, cout, "dgrad")):
+        with _prof.timed(_tile_kernel_name(cout, cin, kvol, rb.m_out, rb.m_in), _Cost(rb, cin, cout, "dgrad")):
             L.check(lib.efg_spconv_forward_tiled_f32(L.ptr(grad_out), rb.m_out, cout, L.ptr(packed), None, cin, kvol,
                                                      L.ptr(plan), rb.m_in, flip | nat, L.ptr(grad_in), L.stream()))
         return grad_in

@@ -164,6 +164,10 @@ int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, si
  * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0.
  * flip_offsets | 2: `packed_weight` is in natural channel order (for_dgrad | 2) and cin % 4 == 0: the kernel gathers
  * 16 bytes per lane and reads its A fragments with one 16-byte LDS load per 16-channel step. */
+/* The launch shape efg_spconv_forward_tiled_f32 uses for these sizes: n-tiles (of 16 output channels) per wave, row
+ * sub-tiles per wave, split-K waves -- i.e. the conv_tile_kernel<NT, R, KS> instantiation; the host labels its timings
+ * with it (one definition shared with the launcher, so labels cannot drift from what ran). */
+int efg_spconv_tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* nt, int* r, int* ks);
 int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);
