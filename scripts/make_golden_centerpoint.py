@@ -99,6 +99,27 @@ def main():
         e64 = float((g.double() - p64[n].grad).abs().max() / p64[n].grad.abs().max())
         save["graderr64::" + n] = np.array(e64)
         print("   grad %-45s %-20s max %.3e  reference fp32-vs-fp64 err/max %.2e" % (n, tuple(g.shape), float(g.abs().max()), e64))
+    # inference branch of the SAME reference model (eval mode: decode, score / range masks, rotated NMS in pcdet
+    # convention, $CP1/center_head.py:173-376, box_torch_ops.py:237-263).  Its `efg._C.nms_gpu` (CUDA) -> the CPU oracle.
+    import oracle
+
+    def nms_stub(boxes, keep, thresh):
+        kept = oracle.nms(boxes.detach().numpy(), thresh, True)
+        keep[:len(kept)] = torch.from_numpy(kept)
+        return len(kept)
+
+    sys.modules["efg._C"].nms_gpu = nms_stub
+    import efg as _efg
+    _efg._C.nms_gpu = nms_stub
+    model.load_state_dict(state, strict=True)      # the training pass above moved the BatchNorm running statistics
+    model.eval()
+    with torch.no_grad():
+        results = model(G.reference_samples(cfg, points_list, copy.deepcopy(annos)))
+    for i, res in enumerate(results):
+        for k in ("scores", "labels", "boxes3d"):
+            save["infer::%s::%d" % (k, i)] = res[k]
+        print("   inference scene %d: %d boxes kept, scores %.3f..%.3f" % (i, len(res["scores"]), float(res["scores"].min()),
+                                                                   float(res["scores"].max())))
     out = os.path.join(ROOT, "tests", "golden", "centerpoint_full_small.npz")
     np.savez_compressed(out, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in save.items()})
     print("saved", out, os.path.getsize(out) // 1024, "KiB; losses", {k: round(float(v), 6) for k, v in losses.items()})

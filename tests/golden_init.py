@@ -94,6 +94,10 @@ CENTERPOINT_OVERRIDES = {
     "dataset.pc_range": [-6.4, -6.4, -2.0, 6.4, 6.4, 4.0],
     "model.loss.max_objs": 20,
     "model.post_process.post_center_limit_range": [-8.0, -8.0, -10.0, 8.0, 8.0, 10.0],
+    # random-weight boxes are ~1 m wide on a 0.8 m lattice (IoU ~0.1 between neighbours): a low threshold and a tight
+    # post-NMS cap make the inference fixture exercise suppression and truncation
+    "model.post_process.nms.nms_iou_threshold": 0.08,
+    "model.post_process.nms.nms_post_max_size": 60,
 }
 
 # TrajectoryFormer: the reference configuration as is (hidden 256, 3 + 3 encoder layers); small scenes

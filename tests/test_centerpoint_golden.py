@@ -131,3 +131,33 @@ def test_reference_centerpoint_gpu(dev):
     assert len(res) == 2 and set(res[0]) == {"scores", "labels", "boxes3d"}
     assert res[0]["boxes3d"].shape[1] == 7 and res[0]["scores"].shape[0] <= 300
     assert res[0]["scores"].numel() == 0 or (float(res[0]["scores"].min()) > 0.1 and int(res[0]["labels"].min()) >= 1)
+
+
+def _check_inference(model, g, cfg, device, install):
+    """Inference branch vs the reference's own eval-mode forward (decode, masks, rotated NMS in pcdet convention,
+    truncation): same kept boxes in the same order."""
+    model.eval()
+    with torch.no_grad(), install():
+        res = model(_batch(device, cfg))
+    assert len(res) == 2
+    for i, r in enumerate(res):
+        want_scores = g["infer::scores::%d" % i]
+        assert 10 < len(want_scores) <= 60                     # suppression happened, truncation bounds it
+        assert r["scores"].shape[0] == len(want_scores), (r["scores"].shape, len(want_scores))
+        np.testing.assert_array_equal(r["labels"].numpy(), g["infer::labels::%d" % i])
+        np.testing.assert_allclose(r["scores"].numpy(), want_scores, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(r["boxes3d"].numpy(), g["infer::boxes3d::%d" % i], rtol=0, atol=1e-4)
+
+
+def test_reference_centerpoint_inference_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    torch.set_num_threads(8)
+    model, cfg, g = _build(torch.device("cpu"))
+    _check_inference(model, g, cfg, torch.device("cpu"), cpu_backend.install)
+
+
+@pytest.mark.gpu
+def test_reference_centerpoint_inference_gpu(dev):
+    model, cfg, g = _build(dev)
+    _check_inference(model, g, cfg, dev, contextlib.nullcontext)
