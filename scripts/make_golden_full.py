@@ -222,7 +222,7 @@ def install_shims(model_dir=CQ):
     sys.path.insert(0, model_dir)
 
 
-def make_config(yaml_name):
+def make_config(yaml_name, extra=None):
     """Our YAML (same keys as $CQ / $VD config.yaml:67-144) at the reduced grid of Appendix A.5."""
     from golden_init import FULL_OVERRIDES
 
@@ -230,6 +230,7 @@ def make_config(yaml_name):
 
     ov = dict(FULL_OVERRIDES)
     ov["model.device"] = "cpu"
+    ov.update(extra or {})
     return load_config(os.path.join(ROOT, "configs", yaml_name), ov)
 
 
@@ -377,9 +378,43 @@ def run(tag, model_dir, yaml_name, out_name):
         print("   %-28s %.6f" % (k, float(v)))
 
 
+def run_infer(tag, model_dir, yaml_name, out_name):
+    """The reference model's INFERENCE branch (eval mode: no CDN, decode, score selection -- ConQueR: every (query,
+    class) with score >= 0.1, one scene per call; Voxel-DETR: the 300 best pairs) on the same weights and scenes."""
+    from golden_init import deterministic_state, full_inputs
+
+    install_shims(model_dir)
+    import voxel_detr  # the reference model, imported in place
+
+    from golden_init import INFER_OVERRIDES
+
+    cfg = make_config(yaml_name, INFER_OVERRIDES)
+    torch.manual_seed(0)
+    model = voxel_detr.VoxelDETR(cfg)
+    model.load_state_dict(deterministic_state(model.state_dict()), strict=True)
+    model.eval()
+    points_list, annos = full_inputs()
+    save = {}
+    with torch.no_grad():
+        for i in range(len(points_list)):
+            res = model(reference_samples(cfg, points_list[i:i + 1], annos[i:i + 1]))[0]
+            for k in ("scores", "labels", "boxes3d"):
+                save["%s::%d" % (k, i)] = res[k].numpy()
+            print("   %s scene %d: %d detections, scores %.3f..%.3f" % (tag, i, len(res["scores"]), float(res["scores"].min()),
+                                                                float(res["scores"].max())))
+    out = os.path.join(ROOT, "tests", "golden", out_name)
+    np.savez_compressed(out, **save)
+    print(tag, "saved", out, os.path.getsize(out) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "conquer"
-    if which == "conquer":
+    if "--infer" in sys.argv:
+        if which == "conquer":
+            run_infer("ConQueR", CQ, "conquer_waymo_res18.yaml", "conquer_infer_small.npz")
+        else:
+            run_infer("VoxelDETR", VD, "voxeldetr_waymo_res18.yaml", "voxeldetr_infer_small.npz")
+    elif which == "conquer":
         run("ConQueR", CQ, "conquer_waymo_res18.yaml", "conquer_full_small.npz")
     else:
         run("VoxelDETR", VD, "voxeldetr_waymo_res18.yaml", "voxeldetr_full_small.npz")

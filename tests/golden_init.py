@@ -16,6 +16,10 @@ FULL_OVERRIDES = {
 }
 
 
+# inference fixtures: 120 queries x 3 classes = 360 candidates, so that Voxel-DETR's fixed top-300 rule selects
+INFER_OVERRIDES = {"model.transformer.num_queries": 120}
+
+
 def deterministic_state(state):
     """name/shape -> value.  Scales are chosen so that activations stay O(1) through 21 sparse convs + the DETR."""
     out = {}
