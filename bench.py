@@ -100,6 +100,7 @@ def cpu_baseline(args):
         stages["hard_voxelize REFERENCE voxelization_cpu.cpp (1 thread) s/scene"] = round(time.perf_counter() - t0, 4)
     stages["voxels/scene"] = int(v.shape[0])
     tr = Trainer(device="cpu", overrides={"model.transformer.num_queries": args.queries}, seed=0, ddp=False)
+    tr.model.noise_generator = torch.Generator().manual_seed(4321)   # (the CDN noise of the parity check below)
     batch = synthetic_batch(1000, 1, n_points=args.points, n_sweeps=args.sweeps)
     with cpu_backend.install():
         t0 = time.perf_counter()
@@ -108,8 +109,9 @@ def cpu_baseline(args):
                                                   torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), 1, [1504, 1504, 40])
         stages["sparse backbone forward (oracle C, OpenMP) s/scene"] = round(time.perf_counter() - t0, 3)
         t0 = time.perf_counter()
-        tr.step(batch)
+        cpu_losses, _ = tr.step(batch)
         dt = time.perf_counter() - t0
+    cpu_losses = {k: float(v.detach()) for k, v in cpu_losses.items()}
     tr.close()
     cpu = "?"
     try:
@@ -117,11 +119,32 @@ def cpu_baseline(args):
             cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port", "cpu": cpu,
+    return {"parity_full_size": _parity_full_size(args, cpu_losses),
+            "value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port", "cpu": cpu,
             "sample": "1 train step (fwd+bwd+AdamW) on 1 synthetic scene of %d points (the GPU workload's scene size), "
                       "full ConQueR model (%d queries), oracle C ops (OpenMP) + PyTorch CPU dense layers, %.1f s"
                       % (args.points, args.queries, dt),
             "stages": stages}
+
+
+def _parity_full_size(args, cpu_losses):
+    """The SAME step (same seed-0 weights, same 180k-point scene, same CDN noise) on the HIP path: every loss term of
+    the GPU step against the oracle-backed CPU step that was just timed -- a parity check at the benchmark's full
+    scene size, which the oracle-sized tests cannot reach (the CPU side takes ~9 s)."""
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tr = Trainer(device=dev, overrides={"model.transformer.num_queries": args.queries}, seed=0, ddp=False)
+    tr.model.noise_generator = torch.Generator().manual_seed(4321)
+    gpu_losses, _ = tr.step(synthetic_batch(1000, 1, n_points=args.points, n_sweeps=args.sweeps, device=dev))
+    gpu_losses = {k: float(v.detach()) for k, v in gpu_losses.items()}
+    tr.close()
+    terms = sorted(k for k in cpu_losses if k.startswith("loss"))
+    rel = {k: abs(gpu_losses[k] - cpu_losses[k]) / max(abs(cpu_losses[k]), 1e-6) for k in terms}
+    worst = max(rel, key=rel.get)
+    return {"what": "every loss term of one full-size train step, HIP path vs the oracle-backed CPU step (same weights, "
+                    "scene, CDN noise)", "terms": len(terms), "total_cpu": sum(cpu_losses[k] for k in terms),
+            "total_gpu": sum(gpu_losses[k] for k in terms), "max_rel_diff": rel[worst], "worst_term": worst}
 
 
 def _geometry_report(trainer, batch):
@@ -273,7 +296,9 @@ def main():
                                       "same losses and gradients"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args)
+            base = cpu_baseline(args)
+            line["parity_full_size"] = base.pop("parity_full_size")
+            line["cpu_baseline"] = base
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
