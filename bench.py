@@ -112,6 +112,7 @@ def cpu_baseline(args):
         cpu_losses, _ = tr.step(batch)
         dt = time.perf_counter() - t0
     cpu_losses = {k: float(v.detach()) for k, v in cpu_losses.items()}
+    cpu_losses["__grad_norm__"] = _grad_norm(tr.model)
     tr.close()
     cpu = "?"
     try:
@@ -127,6 +128,11 @@ def cpu_baseline(args):
             "stages": stages}
 
 
+def _grad_norm(model):
+    """l2 norm of all gradients (fp64 accumulation) after a step."""
+    return float(torch.sqrt(sum((p.grad.double() ** 2).sum().cpu() for p in model.parameters() if p.grad is not None)))
+
+
 def _parity_full_size(args, cpu_losses):
     """The SAME step (same seed-0 weights, same 180k-point scene, same CDN noise) on the HIP path: every loss term of
     the GPU step against the oracle-backed CPU step that was just timed -- a parity check at the benchmark's full
@@ -138,13 +144,16 @@ def _parity_full_size(args, cpu_losses):
     tr.model.noise_generator = torch.Generator().manual_seed(4321)
     gpu_losses, _ = tr.step(synthetic_batch(1000, 1, n_points=args.points, n_sweeps=args.sweeps, device=dev))
     gpu_losses = {k: float(v.detach()) for k, v in gpu_losses.items()}
+    gpu_norm = _grad_norm(tr.model)
     tr.close()
     terms = sorted(k for k in cpu_losses if k.startswith("loss"))
     rel = {k: abs(gpu_losses[k] - cpu_losses[k]) / max(abs(cpu_losses[k]), 1e-6) for k in terms}
     worst = max(rel, key=rel.get)
     return {"what": "every loss term of one full-size train step, HIP path vs the oracle-backed CPU step (same weights, "
                     "scene, CDN noise)", "terms": len(terms), "total_cpu": sum(cpu_losses[k] for k in terms),
-            "total_gpu": sum(gpu_losses[k] for k in terms), "max_rel_diff": rel[worst], "worst_term": worst}
+            "total_gpu": sum(gpu_losses[k] for k in terms), "max_rel_diff": rel[worst], "worst_term": worst,
+            "grad_norm_cpu": cpu_losses["__grad_norm__"], "grad_norm_gpu": gpu_norm,
+            "grad_norm_rel_diff": abs(gpu_norm - cpu_losses["__grad_norm__"]) / max(cpu_losses["__grad_norm__"], 1e-12)}
 
 
 def _geometry_report(trainer, batch):
