@@ -5,10 +5,14 @@ over RCCL ("nccl" backend)."""
 import os
 import socket
 
+import sys
+
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # spawned workers import golden_init too
 
 
 def _free_port():
@@ -26,18 +30,27 @@ def _worker(rank, world, port, out, mode):
     import oracle  # noqa: F401
     from oracle import cpu_backend
 
-    from efg_amd.engine import Trainer, synthetic_batch
+    import copy
+
+    from golden_init import FULL_OVERRIDES, full_inputs
+
+    from efg_amd.engine import Trainer
 
     torch.set_num_threads(4)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
+    # the reduced grid of the full-model golden (128 x 128 x 40 voxels, 16 x 16 BEV tokens): the exchange logic does not
+    # depend on the scene size, and a CPU step at the full 188 x 188 token grid costs 10 s apiece
+    ov = dict(FULL_OVERRIDES)
+    ov.update({"model.transformer.num_queries": 40, "model.transformer.dec_layers": 2})
     tr = Trainer(device="cpu", overrides=ov, seed=0, ddp=True)
+    points_list, annos = full_inputs()
     tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
     # two steps: the flat / bucket buffers are laid out in step 1 and reused in step 2; DDP's static_graph steady
     # state starts at step 2
     with cpu_backend.install():
         for it in range(2):
-            batch = synthetic_batch(500 + 10 * it + rank, 1, n_points=4000, n_boxes=4)   # rank-sharded scenes
+            scene = (rank + it) % len(points_list)                                 # rank-sharded scenes
+            batch = [({"points": torch.from_numpy(points_list[scene])}, {"annotations": copy.deepcopy(annos[scene])})]
             loss_dict, total = tr.step(batch)
     w = tr.model.backbone.extractor.bottom_up.stem.conv1[0].weight
     g = w.grad.detach().clone()
