@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..operators.layernorm import add_layer_norm  # norm(x + r): one fused HIP pass each way on the GPU
 from ..operators.linear import linear  # F.linear; on long GPU matrices: split weight gradient + HIP bias gradient
 
 
@@ -66,9 +67,9 @@ class TransformerEncoderLayer(nn.Module):
         self.activation = F.relu
 
     def _mix(self, x, update):
-        x = self.norm1(x + self.dropout1(update))
+        x = add_layer_norm(x, self.dropout1(update), self.norm1)
         hidden = self.dropout(linear(x, self.linear1.weight, self.linear1.bias, relu=True))   # activation = ReLU
-        return self.norm2(x + self.dropout2(linear(hidden, self.linear2.weight, self.linear2.bias)))
+        return add_layer_norm(x, self.dropout2(linear(hidden, self.linear2.weight, self.linear2.bias)), self.norm2)
 
     def forward(self, token, src, pos=None):
         src = self._mix(src, attend(self.point_attn, src, src))
@@ -110,12 +111,13 @@ class FFN(nn.Module):
         self.activation = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
 
     def forward(self, tgt, tgt_input):
-        tgt = self.norm2(tgt + self.dropout2(tgt_input))
+        tgt = add_layer_norm(tgt, self.dropout2(tgt_input), self.norm2)
         if self.activation is F.relu:
             hidden = linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
         else:
             hidden = self.activation(linear(tgt, self.linear1.weight, self.linear1.bias))
-        return self.norm3(tgt + self.dropout3(linear(self.dropout(hidden), self.linear2.weight, self.linear2.bias)))
+        return add_layer_norm(tgt, self.dropout3(linear(self.dropout(hidden), self.linear2.weight, self.linear2.bias)),
+                              self.norm3)
 
 
 class TransformerEncoderLayerGlobalLocal(nn.Module):
