@@ -156,6 +156,30 @@ def _parity_full_size(args, cpu_losses):
             "grad_norm_rel_diff": abs(gpu_norm - cpu_losses["__grad_norm__"]) / max(cpu_losses["__grad_norm__"], 1e-12)}
 
 
+def _voxelize_alone(trainer, batch, iters=30):
+    """(microseconds per call, algorithmic bytes per call) of the rank's batched hard voxelization, timed by HIP events
+    on the current stream with nothing else running."""
+    from efg_amd.operators import voxelize_batch
+
+    cfg = trainer.cfg.dataset
+    vox = cfg.processors.train.Voxelization
+    pts = [b[0]["points"] for b in batch]
+    run = lambda: voxelize_batch(pts, list(cfg.voxel_size), list(cfg.pc_range), vox.max_points_in_voxel,  # noqa: E731
+                                 vox.max_voxel_num)
+    out = run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    n, f = sum(p.shape[0] for p in pts), pts[0].shape[1]
+    m = int(out["voxels"].shape[0])
+    nbytes = 4 * f * n + m * (4 * vox.max_points_in_voxel * f + 16 + 4 + 4 * f)      # DESIGN.md section 5
+    return e0.elapsed_time(e1) * 1e3 / iters, nbytes
+
+
 def _geometry_report(trainer, batch):
     """N, M per level and pairs per sparse-conv table of one batch (SURVEY.md §8d asks for them beside every GB/s
     figure).  One untimed forward of the backbone with a spy on the rulebook constructor."""
@@ -285,6 +309,15 @@ def main():
                 gbs = sum(v["bytes"] for v in grp.values()) / ms / 1e6
                 line[name + "_hbm"] = {"GBps_alg": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
                                        "ms_per_step": round(ms / max(args.profile_steps, 1), 3)}
+        if "voxelize_hbm" in line:
+            # the same call alone on an otherwise idle GPU (inside the step it runs on the geometry stream beside the
+            # previous step's backward, so its in-step duration mostly measures contention)
+            try:
+                us, nbytes = _voxelize_alone(trainer, pool[0])
+                line["voxelize_hbm"].update({"standalone_us": round(us, 1), "standalone_GBps_alg": round(nbytes / us / 1e3, 1),
+                                             "standalone_frac_of_8TBps": round(nbytes / us / 1e3 / 8000.0, 4)})
+            except Exception as exc:  # accounting only
+                line["voxelize_hbm"]["standalone_error"] = str(exc)
         try:
             line["geometry"] = _geometry_report(trainer, pool[0])
         except Exception as exc:  # accounting only
