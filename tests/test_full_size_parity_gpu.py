@@ -1,0 +1,71 @@
+"""Parity at BASELINE's full scene size for the widened configurations: one training step of CenterPoint (1 x 180k
+points) and of TrajectoryFormer (1 x 180k points, 60 objects, 11 frames of detector boxes) on the HIP path against
+the SAME step with the oracle standing in for every HIP op on the host (same seed-0 weights, inputs and NumPy
+generator).  The ConQueR twin of this check runs inside `bench.py` (`parity_full_size`).  ~40 s of host work."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _losses(make_trainer, make_batch, device, install, seed):
+    np.random.seed(seed)
+    tr = make_trainer(device)
+    with install():
+        loss_dict, total = tr.step(make_batch(device))
+    out = {k: float(v.detach()) for k, v in loss_dict.items()}
+    norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum().cpu() for p in tr.model.parameters() if p.grad is not None)))
+    tr.close()
+    return out, norm
+
+
+def _compare(make_trainer, make_batch, dev, oracle_mod, rel):
+    import contextlib
+
+    from oracle import cpu_backend
+
+    torch.set_num_threads(16)
+    cpu, cpu_norm = _losses(make_trainer, make_batch, torch.device("cpu"), cpu_backend.install, 3)
+    gpu, gpu_norm = _losses(make_trainer, make_batch, dev, contextlib.nullcontext, 3)
+    assert set(cpu) == set(gpu)
+    for k in cpu:
+        assert gpu[k] == pytest.approx(cpu[k], rel=rel, abs=1e-6), k
+    assert gpu_norm == pytest.approx(cpu_norm, rel=5e-4)
+
+
+def test_centerpoint_full_size_step(dev, oracle_mod):
+    from efg_amd.centerpoint import VoxelNet
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    cfg = os.path.join(ROOT, "configs", "centerpoint_waymo_voxelnet.yaml")
+    _compare(lambda d: Trainer(config=cfg, device=d, seed=0, model_cls=VoxelNet, ddp=False, max_iters=100),
+             lambda d: synthetic_batch(3000, 1, n_points=180000, device=d if d.type == "cuda" else None), dev, oracle_mod,
+             rel=2e-4)
+
+
+def test_trajectoryformer_full_size_step(dev, oracle_mod):
+    from efg_amd.engine import Trainer
+    from efg_amd.tracking import TrajectoryFormer
+    from efg_amd.tracking.synthetic import synthetic_tracking_batch
+
+    cfg = os.path.join(ROOT, "configs", "trajectoryformer_waymo_centerpoint.yaml")
+    _compare(lambda d: Trainer(config=cfg, device=d, seed=0, model_cls=TrajectoryFormer, ddp=False, max_iters=100),
+             lambda d: synthetic_tracking_batch(7000, 1, device=d if d.type == "cuda" else None, n_points=180000,
+                                                n_objects=60, n_false=20), dev, oracle_mod, rel=2e-4)
+
+
+def test_conquer_full_size_step(dev, oracle_mod):
+    """The headline configuration itself: one 180k-point scene, 1000 queries, 31 loss terms + the gradient norm."""
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    def trainer(d):
+        tr = Trainer(device=d, seed=0, ddp=False, overrides={"model.transformer.num_queries": 1000})
+        tr.model.noise_generator = torch.Generator().manual_seed(4321)      # the CDN noise, drawn on the host
+        return tr
+
+    _compare(trainer, lambda d: synthetic_batch(1000, 1, n_points=180000, device=d if d.type == "cuda" else None), dev,
+             oracle_mod, rel=1e-4)
