@@ -16,6 +16,7 @@ from ..modeling.backbones.configurable_rpn import RPN
 from ..modeling.backbones.sparse_net import SpMiddleResNetFHD
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import voxelize_batch
+from ..operators.voxelize import wait_for_points
 from ..spconv import core as spconv_core
 from .center_head import CenterHead
 from .targets import assign_scene
@@ -76,7 +77,7 @@ class VoxelNet(nn.Module):
             mean = out["voxel_mean"][:, :nf].contiguous()
         else:
             main = torch.cuda.current_stream()
-            geo.wait_stream(main)
+            wait_for_points(geo, main, samples, pts)
             with torch.cuda.stream(geo):
                 out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
                 mean = out["voxel_mean"][:, :nf].contiguous()

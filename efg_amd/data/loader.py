@@ -1,0 +1,106 @@
+"""One-batch-ahead sample preparation on the training GPU itself.
+
+The reference prepares samples on DataLoader worker PROCESSES (efg/data/build.py `build_dataloader`: num_workers
+x NumPy augmentation + CPU voxelization, then collate + upload).  With the loader-side chain running as HIP kernels
+on the training GPU (gpu_pipeline.py, gt_database.py) worker processes are the wrong shape: the clouds and the object
+database live in this process's HBM.  What the chain still needs is to stay OFF the training stream: its range filter
+sizes the cloud with one count read-back, and on the main stream that read-back waits for every kernel of the
+previous step still queued there (measured: 37.8 -> 46.2 ms/step inline, 38.9 through this loader;
+scripts/ubench/pipeline_step.py, profiles/r02k_pipeline_step.txt).
+
+`DeviceLoader` runs `produce(index) -> (sample, info)` on ONE background thread under its own HIP stream, `depth`
+batches ahead; each sample leaves with a `ready_event` recorded on that stream, which is what VoxelDETR / CenterPoint /
+TrajectoryFormer wait on before their first kernel (voxel_detr.py `_inputs`), so no stream ever waits for the host.
+One producer thread (not a pool) keeps the reference's NumPy random stream in order: sample i draws before sample
+i+1, as with num_workers=0.  The model's own NumPy draws, if any, must use their own generator.
+"""
+import queue
+import threading
+
+import torch
+
+
+class _Failure:
+    def __init__(self, exc):
+        self.exc = exc
+
+
+class DeviceLoader:
+    def __init__(self, produce, batch_size, length, device=None, depth=2):
+        """produce(i) for i in range(length * batch_size), batched in order; device: the GPU the chain runs on
+        (None: plain host producer, no streams -- used by the CPU tests)."""
+        self.produce, self.batch_size, self.length, self.depth = produce, batch_size, length, depth
+        self.device = torch.device(device) if device is not None else None
+        self._queue = queue.Queue(maxsize=depth)
+        self._stop = threading.Event()
+        self._stream = None
+        if self.device is not None:
+            self._stream = torch.cuda.Stream(device=self.device)
+            # whatever the producer reads (raw clouds, the object database) was uploaded on the caller's stream
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._thread = threading.Thread(target=self._work, name="efg-device-loader", daemon=True)
+        self._served = 0
+        self._thread.start()
+
+    def _put(self, item):
+        while not self._stop.is_set():
+            try:
+                self._queue.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _work(self):
+        try:
+            if self.device is not None:
+                torch.cuda.set_device(self.device)   # the current device is per thread
+            for b in range(self.length):
+                batch = []
+                for i in range(b * self.batch_size, (b + 1) * self.batch_size):
+                    if self._stop.is_set():
+                        return
+                    if self._stream is None:
+                        batch.append(self.produce(i))
+                        continue
+                    with torch.cuda.stream(self._stream):
+                        sample, info = self.produce(i)
+                        event = torch.cuda.Event()
+                        event.record(self._stream)
+                    sample["ready_event"] = event
+                    batch.append((sample, info))
+                if not self._put(batch):
+                    return
+        except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
+            self._put(_Failure(exc))
+
+    def __len__(self):
+        return self.length
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._served == self.length:
+            raise StopIteration
+        item = self._queue.get()
+        if isinstance(item, _Failure):
+            self._served = self.length
+            raise item.exc
+        self._served += 1
+        return item
+
+    def close(self):
+        self._stop.set()
+        while True:   # unblock a producer waiting on a full queue
+            try:
+                self._queue.get_nowait()
+            except queue.Empty:
+                break
+        self._thread.join(timeout=10)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

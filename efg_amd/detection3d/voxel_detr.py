@@ -29,6 +29,7 @@ from ..modeling.backbones.fpn import build_resnet_fpn_backbone
 from ..modeling.common import Conv2d
 from ..modeling.readers import VoxelMeanFeatureExtractor
 from ..operators import groupnorm, voxelize_batch
+from ..operators.voxelize import wait_for_points
 from ..operators.linear import Linear, linear
 from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
@@ -151,14 +152,7 @@ class VoxelDETR(nn.Module):
             # voxelization sizes every downstream tensor (one count readback): run it on the geometry stream so
             # the readback does not wait for the previous step's backward still queued on the main stream
             main = torch.cuda.current_stream()
-            events = [s.get("ready_event") for s in samples]
-            converted = any(torch.is_tensor(s["points"]) and (not s["points"].is_cuda or s["points"].dtype !=
-                                                               torch.float32) for s in samples)
-            if all(e is not None for e in events) and not converted:
-                for e in events:
-                    geo.wait_event(e)  # the caller's promise: the points are complete once this event fires
-            else:  # (also when `pts` were uploaded / converted on the main stream just above)
-                geo.wait_stream(main)  # unknown provenance: order after everything queued so far
+            wait_for_points(geo, main, samples, pts)
             with torch.cuda.stream(geo):
                 out = voxelize_batch(pts, vc.voxel_size, vc.pc_range, vc.max_points_in_voxel, vc.max_voxel_num)
                 mean = out["voxel_mean"][:, : self.input_dim].contiguous()

@@ -157,3 +157,20 @@ def voxelize_concat(points, offsets, voxel_size, coors_range, max_points, max_vo
     if with_mean:
         out["voxel_mean"] = mean[:m]
     return out
+
+
+def wait_for_points(stream, main, samples, pts):
+    """Order `stream` (a model's geometry stream) after the producers of `pts`.  Samples that carry a `ready_event`
+    (engine.synthetic_batch, data/loader.py DeviceLoader) promise "the points are complete once this event fires":
+    the stream waits for those events only, NOT for the previous step's backward still queued on `main`, so the
+    voxel-count read-back that follows returns early and the host prepares step n+1 under step n.  Anything else
+    (host arrays uploaded just now, converted dtypes) has unknown provenance: wait for everything queued on `main`."""
+    events = [s.get("ready_event") for s in samples]
+    converted = any(torch.is_tensor(s["points"]) and (not s["points"].is_cuda or s["points"].dtype != torch.float32)
+                    for s in samples)
+    if all(e is not None for e in events) and not converted:
+        for e, p in zip(events, pts):
+            stream.wait_event(e)
+            p.record_stream(stream)   # possibly allocated on a loader's stream: keep alive until `stream` has read it
+    else:
+        stream.wait_stream(main)

@@ -76,3 +76,21 @@ for e in ev:
         g[key][1] += sum(k.duration for k in e.kernels)
 for (th, name, shp), (n, us) in sorted(g.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%s %-12s %3d x %8.1f us total  %s" % (th, name, n, us, shp))
+print("\n-- forward launches by efg:: scope (innermost record_function containing the op)")
+scopes = [e for e in ev if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("efg::") and e.thread == main_thread]
+per = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
+for e in ev:
+    if e.device_type != torch.autograd.DeviceType.CPU or e.thread != main_thread or not e.kernels or e.name.startswith("efg::"):
+        continue
+    t0, t1 = e.time_range.start, e.time_range.end
+    inner = None
+    for sc in scopes:
+        if sc.time_range.start <= t0 and t1 <= sc.time_range.end:
+            if inner is None or sc.time_range.elapsed_us() < inner.time_range.elapsed_us():
+                inner = sc
+    key = inner.name if inner is not None else "(none)"
+    per[key][0] += len(e.kernels)
+    per[key][1] += sum(k.duration for k in e.kernels)
+    per[key][2][e.name] += len(e.kernels)
+for key, (n, us, ops_) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+    print("%-28s %5d launches %8.3f ms   top: %s" % (key, n, us / 1e3, ", ".join("%s x%d" % kv for kv in ops_.most_common(6))))
