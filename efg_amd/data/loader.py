@@ -9,8 +9,9 @@ previous step still queued there (measured: 37.8 -> 46.2 ms/step inline, 38.9 th
 scripts/ubench/pipeline_step.py, profiles/r02k_pipeline_step.txt).
 
 `DeviceLoader` runs `produce(index) -> (sample, info)` on ONE background thread under its own HIP stream, `depth`
-batches ahead; each sample leaves with a `ready_event` recorded on that stream, which is what VoxelDETR / CenterPoint /
-TrajectoryFormer wait on before their first kernel (voxel_detr.py `_inputs`), so no stream ever waits for the host.
+batches ahead; each sample leaves with its batch's `ready_event` recorded on that stream, which is what VoxelDETR /
+CenterPoint / TrajectoryFormer wait on before their first kernel (operators/voxelize.py `wait_for_points`), so no stream
+ever waits for the host.
 One producer thread (not a pool) keeps the reference's NumPy random stream in order: sample i draws before sample
 i+1, as with num_workers=0.  The model's own NumPy draws, if any, must use their own generator.
 """
@@ -26,10 +27,12 @@ class _Failure:
 
 
 class DeviceLoader:
-    def __init__(self, produce, batch_size, length, device=None, depth=2):
+    def __init__(self, produce, batch_size, length, device=None, depth=2, collate=None):
         """produce(i) for i in range(length * batch_size), batched in order; device: the GPU the chain runs on
-        (None: plain host producer, no streams -- used by the CPU tests)."""
+        (None: plain host producer, no streams -- used by the CPU tests); collate(batch) -> batch: per-batch work on
+        the loader's thread and stream (TrajectoryFormer.prepare: NMS, linking, hypotheses, point crop, targets)."""
         self.produce, self.batch_size, self.length, self.depth = produce, batch_size, length, depth
+        self.collate = collate
         self.device = torch.device(device) if device is not None else None
         self._queue = queue.Queue(maxsize=depth)
         self._stop = threading.Event()
@@ -51,25 +54,30 @@ class DeviceLoader:
                 continue
         return False
 
+    def _make(self, b):
+        batch = []
+        for i in range(b * self.batch_size, (b + 1) * self.batch_size):
+            if self._stop.is_set():
+                return None
+            batch.append(self.produce(i))
+        return self.collate(batch) if self.collate is not None else batch
+
     def _work(self):
         try:
             if self.device is not None:
                 torch.cuda.set_device(self.device)   # the current device is per thread
             for b in range(self.length):
-                batch = []
-                for i in range(b * self.batch_size, (b + 1) * self.batch_size):
-                    if self._stop.is_set():
-                        return
-                    if self._stream is None:
-                        batch.append(self.produce(i))
-                        continue
+                if self._stream is None:
+                    batch = self._make(b)
+                else:
                     with torch.cuda.stream(self._stream):
-                        sample, info = self.produce(i)
-                        event = torch.cuda.Event()
-                        event.record(self._stream)
-                    sample["ready_event"] = event
-                    batch.append((sample, info))
-                if not self._put(batch):
+                        batch = self._make(b)
+                        if batch is not None:
+                            event = torch.cuda.Event()
+                            event.record(self._stream)   # ONE event per batch: everything above is complete when it fires
+                            for sample, _ in batch:
+                                (sample[0] if isinstance(sample, (list, tuple)) else sample)["ready_event"] = event
+                if batch is None or not self._put(batch):
                     return
         except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
             self._put(_Failure(exc))

@@ -30,12 +30,30 @@ def run(args, rank, local_rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(max(args.warmup, 1)):
-        trainer.step(pool[w % len(pool)])
+    # The parameter-free half of the step (NMS, linking, forecast, hypotheses, point crop, targets) runs as the
+    # DeviceLoader's collate, two batches ahead on the loader's thread and stream; the loader is long enough to keep
+    # preparing through the whole timed region (it still prepares batches K+1, K+2 while step K trains), so the K timed
+    # steps contain K preparations.  EFG_TF_LOADER=0: preparation inside the step, on the model's side stream.
+    warmup = max(args.warmup, 1)
+    loader = None
+    if os.environ.get("EFG_TF_LOADER", "1") != "0":
+        from ..data.loader import DeviceLoader
+
+        def produce(i):
+            sample, info = pool[(i // args.scenes) % len(pool)][i % args.scenes]
+            return [dict(sample[0])], info    # a fresh sample dict: the loader attaches per-batch state to it
+
+        loader = DeviceLoader(produce, batch_size=args.scenes, length=warmup + args.steps + 2, device=dev, depth=2,
+                              collate=trainer.model.prepare)
+        batches = iter(loader)
+    else:
+        batches = (pool[i % len(pool)] for i in range(warmup + args.steps))
+    for w in range(warmup):
+        trainer.step(next(batches))
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        trainer.step(pool[s % len(pool)])
+        trainer.step(next(batches))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -53,7 +71,10 @@ def run(args, rank, local_rank, world, dev):
                                    "%d tracks x %d hypotheses x %d points in the last step, hidden 256, 3+3 encoder layers, "
                                    "fwd+bwd+AdamW+OneCycle+clip" % (args.scenes, args.points, args.objects, m.num_track,
                                                                     m.num_hypo_train, m.num_lidar_points),
+                       "preparation": "DeviceLoader, 2 batches ahead" if loader is not None else "in step, side stream",
                        "global_batch": args.scenes * world, "parallelism": "dp%d" % world}}))
+    if loader is not None:
+        loader.close()
     trainer.close()
     if world > 1:
         dist.destroy_process_group()

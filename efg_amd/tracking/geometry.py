@@ -7,6 +7,8 @@ selections and for the occupancy counts of crowded ROIs (the reference sub-sampl
 
 Boxes are (x, y, z, dx, dy, dz, heading[, t]); trajectories are [batch, frame, track, hypothesis, 8].
 """
+import functools
+
 import numpy as np
 import torch
 
@@ -128,12 +130,32 @@ def reorder_rois(pred_bboxes):
     return out, valid
 
 
+@functools.lru_cache(maxsize=8192)
+def _crowded_draw(count, k):
+    """(indices, generator state after the draw) of `np.random.seed(0); np.random.choice(count, k, replace=False)`."""
+    keep = np.random.get_state()
+    np.random.seed(0)
+    picked = np.random.choice(count, k, replace=False).astype(np.int64)
+    after = np.random.get_state()
+    np.random.set_state(keep)
+    return picked, after
+
+
 def _crowded_choice(count, k):
     """The reference re-seeds NumPy with 0 before every sub-sampling draw (utils.py:409-413), so the selection is a
-    pure function of the ROI's point count.  Drawn through the global generator exactly as there, so that the
-    generator is left in the same state for whatever draws from it next (the hypothesis augmentation)."""
-    np.random.seed(0)
-    return torch.from_numpy(np.random.choice(count, k, replace=False).astype(np.int64))
+    pure function of the ROI's point count: memoised (a training step draws for ~250 crowded boxes; seeding the
+    Mersenne twister and permuting `count` indices costs 30 us each).  The global generator is left exactly where the
+    reference's draw leaves it, for whatever draws from it next (the hypothesis augmentation)."""
+    picked, after = _crowded_draw(int(count), int(k))
+    np.random.set_state(after)
+    return torch.from_numpy(picked)
+
+
+def _crowded_choices(counts, k):
+    """`_crowded_choice` for a sequence of ROIs, in order -> int64 [len, k]; one generator update, for the last."""
+    draws = [_crowded_draw(int(c), int(k)) for c in counts]
+    np.random.set_state(draws[-1][1])
+    return torch.from_numpy(np.stack([d[0] for d in draws]))
 
 
 def _crop_select_gpu(first, clouds, k):
@@ -166,7 +188,7 @@ def _crop_select_gpu(first, clouds, k):
         L.check(lib.efg_cylinder_select_f32(L.ptr(cloud), cloud.shape[0], cloud.shape[1], cloud.shape[1] - 1, 1.0,
                                             L.ptr(rng), L.ptr(xyr), batch * padded, L.ptr(starts), None, L.ptr(index),
                                             L.stream()))
-    return cloud, base, host, starts.view(batch, padded)[:, :n_rois], index, total
+    return cloud, base, host, flat_counts[:, :n_rois], starts.view(batch, padded)[:, :n_rois], index, total
 
 
 def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
@@ -188,17 +210,16 @@ def crop_current_frame_points(num_lidar_points, trajectory_rois, points):
     centre_fill = torch.cat([first[:, :, None, :3].expand(-1, -1, k, -1), first.new_zeros(batch, n_rois, k, 3)], -1)
     if not first.is_cuda:
         return torch.stack([_crop_scene_torch(k, first[b], clouds[b], centre_fill[b]) for b in range(batch)])
-    cloud, base, host, start, index, total = _crop_select_gpu(first, clouds, k)
+    cloud, base, host, count, start, index, total = _crop_select_gpu(first, clouds, k)
     if total == 0:
         return centre_fill
     dev = first.device
-    count = torch.as_tensor(host, device=dev)
     slot = torch.arange(k, device=dev)
     pick = torch.where(slot[None, None] < count[..., None], slot[None, None].expand(batch, n_rois, -1),
                        torch.zeros_like(slot)[None, None])
     crowded = [(b, r) for b in range(batch) for r, c in enumerate(host[b]) if c > k]
     if crowded:     # in (scene, box) order: leaves NumPy's generator where the reference's loop leaves it
-        rows = torch.stack([_crowded_choice(host[b][r], k) for b, r in crowded]).to(dev)
+        rows = _crowded_choices([host[b][r] for b, r in crowded], k).to(dev)
         flat = torch.as_tensor([b * n_rois + r for b, r in crowded], device=dev)
         pick = pick.reshape(batch * n_rois, k).index_copy(0, flat, rows).reshape(batch, n_rois, k)
     local = index[(start[..., None] + pick).clamp(max=total - 1)].long()

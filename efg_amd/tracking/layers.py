@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..operators import attention
 from ..operators.layernorm import add_layer_norm  # norm(x + r): one fused HIP pass each way on the GPU
 from ..operators.linear import linear  # F.linear; on long GPU matrices: split weight gradient + HIP bias gradient
 
@@ -37,7 +38,10 @@ def attend(mha, query, memory):
     c, h = mha.embed_dim, mha.num_heads
     b, lq, _ = query.shape
     if query is memory:
-        q, k, v = linear(query, mha.in_proj_weight, mha.in_proj_bias).chunk(3, dim=-1)
+        qkv = linear(query, mha.in_proj_weight, mha.in_proj_bias)
+        if attention.fused(qkv, h):      # csrc/attention.hip: the point encoder's 128-token, 64-wide-head self-attention
+            return linear(attention.self_attention_qkv(qkv, h), mha.out_proj.weight, mha.out_proj.bias)
+        q, k, v = qkv.chunk(3, dim=-1)
     else:
         q = linear(query, mha.in_proj_weight[:c], mha.in_proj_bias[:c])
         k, v = linear(memory, mha.in_proj_weight[c:], mha.in_proj_bias[c:]).chunk(2, dim=-1)

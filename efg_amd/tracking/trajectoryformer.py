@@ -15,6 +15,7 @@ numbers are kept and marked "(reference behaviour)".
 
 The online tracker (`forward_inference` and its track bank, :244-438, :974-1407) lives in `online.py` and is mixed in.
 """
+import copy
 import os
 
 import numpy as np
@@ -128,9 +129,51 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         labels = [on_device(a["pred_labels"], torch.float32) for a in annos]
         return clouds, targets, boxes, scores, labels
 
+    @staticmethod
+    def _first_sample(batched_inputs):
+        sample = batched_inputs[0][0]
+        return sample[0] if isinstance(sample, (list, tuple)) else sample
+
+    def prepare(self, batched_inputs):
+        """The parameter-free half of the step (`_prepare`) for a batch, ahead of time: meant as the `collate` of a
+        `data.loader.DeviceLoader`, i.e. on the loader's thread and HIP stream while the previous batches train.  The
+        result rides on the first sample (`"prepared"`) and `forward_train` adopts it once the batch's `ready_event`
+        has fired.  Runs on a shallow twin of the module (same parameters and buffers) so that the per-batch
+        attributes (`batch_size`, `num_track`) of the step in flight on the main thread are not touched."""
+        if not self.load_motion_module:
+            self.load_pretrain_motionencoder()    # as `forward` does before its first batch
+        twin = copy.copy(self)
+        twin.batch_size = len(batched_inputs)
+        with torch.no_grad():
+            prep = twin._prepare(batched_inputs)
+        self._first_sample(batched_inputs)["prepared"] = {
+            "prep": prep, "batch_size": twin.batch_size, "num_track": getattr(twin, "num_track", 0)}
+        return batched_inputs
+
+    def _adopt(self, batched_inputs, prepared):
+        first = self._first_sample(batched_inputs)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if main is not None:
+            if first.get("ready_event") is not None:
+                main.wait_event(first["ready_event"])
+            else:
+                torch.cuda.synchronize(self.device)   # unknown producer stream
+        self.batch_size, self.num_track = prepared["batch_size"], prepared["num_track"]
+        prep = prepared["prep"]
+        if main is not None:
+            for v in (prep or {}).values():
+                for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+        return prep
+
     def forward_train(self, batched_inputs):
-        self.batch_size = len(batched_inputs)
-        prep = self._on_prep_stream(self._prepare, batched_inputs)
+        prepared = self._first_sample(batched_inputs).get("prepared")
+        if prepared is not None:
+            prep = self._adopt(batched_inputs, prepared)
+        else:
+            self.batch_size = len(batched_inputs)
+            prep = self._on_prep_stream(self._prepare, batched_inputs)
         zero = torch.zeros(1, 1, device=self.device)
         if prep is None:
             return {"loss_cls": zero, "loss_reg": zero.clone()}

@@ -291,6 +291,20 @@ int efg_cylinder_select_f32(const float* points, int64_t n_points, int f, int ti
                             int32_t* counts, int32_t* index, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Self-attention over short sequences in exact fp32 (csrc/attention.hip): softmax(scale * Q K^T) V for 1 <= seq <= 128
+ * tokens and 64-wide heads, one workgroup per (sequence, head), probabilities kept in MFMA accumulators.  Replaces the
+ * nn.MultiheadAttention core of TrajectoryFormer's point encoder (.../trajectoryformer.centerpoint/modules/
+ * transformer.py:44-92: self_attn over the 128 points of every trajectory hypothesis; 1232 x 4 sequences per layer).
+ *   qkv f32 [batch, seq, 3, heads, 64]: the fused in-projection output (q | k | v along the channel axis)
+ *   out f32 [batch, seq, heads, 64]; lse f32 [batch, heads, seq] = log sum_k exp(scale * <q, k>) (kept for the backward)
+ * Backward: dout f32 [batch, seq, heads, 64] -> dqkv f32 [batch, seq, 3, heads, 64], the gradient of the in-projection
+ * output (every element written); the probabilities are recomputed from lse. */
+int efg_attention_fwd_f32(const float* qkv, int64_t batch, int seq, int heads, float scale, float* out, float* lse,
+                          void* stream);
+int efg_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, int64_t batch, int seq,
+                          int heads, float scale, float* dqkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the
  * device->host transfer + scipy.optimize.linear_sum_assignment(C[b]) of $CQ/modules/matcher.py:86-91.
  *   cost f32 [p, nq, g_stride]: p independent problems (layers x scenes), nq queries (rows) x GT

@@ -67,15 +67,17 @@ for (th, name), v in sorted(ops.items(), key=lambda kv: -kv[1][2])[:35]:
 print("\n-- by kernel time")
 for (th, name), v in sorted(ops.items(), key=lambda kv: -kv[1][3])[:40]:
     print("%s %-55s %5d ops %5d launches  kernels %7.3f ms" % (th, name[:55], v[0], v[1], v[3] / 1e3))
-print("\n-- GEMM shapes by kernel time")
+print("\n-- GEMM / attention shapes by kernel time")
 g = collections.defaultdict(lambda: [0, 0.0])
 for e in ev:
-    if e.device_type == torch.autograd.DeviceType.CPU and e.name in ("aten::mm", "aten::addmm", "aten::bmm", "aten::baddbmm") and e.kernels:
+    if e.device_type == torch.autograd.DeviceType.CPU and e.name in (
+            "aten::mm", "aten::addmm", "aten::bmm", "aten::baddbmm", "aten::_efficient_attention_forward",
+            "aten::_efficient_attention_backward", "aten::_flash_attention_forward", "aten::_flash_attention_backward") and e.kernels:
         key = (("fwd" if e.thread == main_thread else "bwd"), e.name, str(e.input_shapes)[:90])
         g[key][0] += 1
         g[key][1] += sum(k.duration for k in e.kernels)
 for (th, name, shp), (n, us) in sorted(g.items(), key=lambda kv: -kv[1][1])[:40]:
-    print("%s %-12s %3d x %8.1f us total  %s" % (th, name, n, us, shp))
+    print("%s %-12s %3d x %8.1f us total  %s" % (th, name.replace("_efficient_attention", "attn")[:18], n, us, shp))
 print("\n-- forward launches by efg:: scope (innermost record_function containing the op)")
 scopes = [e for e in ev if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("efg::") and e.thread == main_thread]
 per = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])

@@ -1,0 +1,89 @@
+"""csrc/attention.hip against fp64 attention (and PyTorch's fp32 SDPA as the yardstick): forward, log-sum-exp and the
+gradient of the fused in-projection output, for full and ragged sequence lengths."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(qkv, heads, dtype):
+    x = qkv.detach().to(dtype).requires_grad_(True)
+    b, s, c3 = x.shape
+    q, k, v = (t.reshape(b, s, heads, 64).transpose(1, 2) for t in x.chunk(3, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(64), -1)
+    lse = torch.logsumexp(q @ k.transpose(-1, -2) / math.sqrt(64), -1)
+    out = (att @ v).transpose(1, 2).reshape(b, s, c3 // 3)
+    return x, out, lse
+
+
+@pytest.mark.parametrize("batch,seq,heads", [(37, 128, 4), (5, 100, 4), (3, 72, 2), (4, 16, 1), (2, 1, 4), (3, 33, 8)])
+def test_forward_backward_match_fp64(batch, seq, heads):
+    from efg_amd import _lib as L
+    from efg_amd.operators.attention import _SelfAttention, fused
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(batch * 1000 + seq)
+    qkv = (torch.randn(batch, seq, 3 * heads * 64, generator=g) * 1.5).to(dev).requires_grad_(True)
+    w = torch.randn(batch, seq, heads * 64, generator=g).to(dev)
+    assert fused(qkv, heads)
+    out = _SelfAttention.apply(qkv, heads)
+    (out * w).sum().backward()
+    x64, out64, lse64 = _reference(qkv, heads, torch.float64)
+    (out64 * w.double()).sum().backward()
+    x32, out32, _ = _reference(qkv, heads, torch.float32)
+    (out32 * w).sum().backward()
+
+    def err(a, ref):
+        return float((a.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+    # as accurate as PyTorch's own fp32 evaluation of the same formula (within 4x), and tight in absolute terms
+    assert err(out, out64) <= max(4 * err(out32, out64), 2e-6), (err(out, out64), err(out32, out64))
+    assert err(qkv.grad, x64.grad) <= max(4 * err(x32.grad, x64.grad), 5e-6), (err(qkv.grad, x64.grad), err(x32.grad, x64.grad))
+    # the saved log-sum-exp
+    lse = torch.empty(batch, heads, seq, device=dev)
+    o2 = torch.empty(batch, seq, heads * 64, device=dev)
+    L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv.detach()), batch, seq, heads, 1 / math.sqrt(64), L.ptr(o2), L.ptr(lse),
+                                          L.stream()))
+    assert torch.equal(o2, out.detach())
+    assert err(lse, lse64) <= 1e-6
+
+
+def test_matches_sdpa_in_the_point_encoder_layer():
+    """`attend` with the kernel against `attend` through SDPA, gradients to the parameters included."""
+    import os
+
+    from torch import nn
+
+    from efg_amd.tracking.layers import attend
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mha = nn.MultiheadAttention(256, 4).to(dev)
+    x = torch.randn(61, 128, 256, device=dev)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["EFG_ATTENTION"] = mode
+        try:
+            mha.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = attend(mha, xi, xi)
+            y.square().sum().backward()
+            res[mode] = (y.detach(), xi.grad, mha.in_proj_weight.grad.clone(), mha.out_proj.weight.grad.clone())
+        finally:
+            os.environ.pop("EFG_ATTENTION", None)
+    for a, b in zip(res["1"], res["0"]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+def test_bad_arguments_are_reported():
+    from efg_amd import _lib as L
+
+    dev = torch.device("cuda:0")
+    qkv = torch.zeros(1, 129, 192, device=dev)
+    out = torch.zeros(1, 129, 64, device=dev)
+    lse = torch.zeros(1, 1, 129, device=dev)
+    with pytest.raises(RuntimeError, match="seq"):
+        L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv), 1, 129, 1, 0.125, L.ptr(out), L.ptr(lse), L.stream()))

@@ -110,3 +110,49 @@ def test_loader_samples_equal_the_inline_chain_and_train_identically():
         tol = 1e-4 if step == 0 else 5e-2
         for k in l_in:
             assert abs(l_in[k] - l_ah[k]) <= tol * max(1.0, abs(l_in[k])), (step, k, l_in[k], l_ah[k])
+
+
+@pytest.mark.gpu
+def test_trajectoryformer_prepared_ahead_trains_like_prepared_in_step():
+    """`TrajectoryFormer.prepare` as the loader's collate (its own thread and stream, two batches ahead) against the
+    preparation inside the step: same NumPy stream => same hypotheses, crops and targets => same losses."""
+    import os
+
+    from efg_amd.engine import Trainer
+    from efg_amd.tracking.synthetic import synthetic_tracking_batch
+    from efg_amd.tracking.trajectoryformer import TrajectoryFormer
+
+    dev = torch.device("cuda:0")
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
+                       "trajectoryformer_waymo_centerpoint.yaml")
+    pool = [synthetic_tracking_batch(8100 + 10 * p, 2, device=dev, n_points=20000, n_objects=14, n_false=4)
+            for p in range(3)]
+    torch.cuda.synchronize()
+
+    def run(ahead):
+        tr = Trainer(config=cfg, device=dev, seed=0, model_cls=TrajectoryFormer, max_iters=100)
+        np.random.seed(77)
+        out = []
+        if ahead:
+            def produce(i):
+                sample, info = pool[i // 2][i % 2]
+                return [dict(sample[0])], info
+
+            with DeviceLoader(produce, batch_size=2, length=3, device=dev, collate=tr.model.prepare) as loader:
+                for batch in loader:
+                    assert "prepared" in batch[0][0][0]
+                    torch.manual_seed(3)
+                    out.append({k: float(v) for k, v in tr.step(batch)[0].items()})
+        else:
+            for batch in pool:
+                torch.manual_seed(3)
+                out.append({k: float(v) for k, v in tr.step(batch)[0].items()})
+        tr.close()
+        return out
+
+    inline, ahead = run(False), run(True)
+    for step, (a, b) in enumerate(zip(inline, ahead)):
+        assert a.keys() == b.keys()
+        tol = 1e-4 if step == 0 else 2e-2    # later steps start from weights that carry the atomics' rounding noise
+        for k in a:
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (step, k, a[k], b[k])
