@@ -176,9 +176,13 @@ def _crop_select_gpu(first, clouds, k):
     xyr[:, :n_rois, 2] = radius
     rng = torch.as_tensor(np.repeat(np.stack([base[:-1], base[1:]], 1)[:, None, :], padded, 1), device=dev).contiguous()
     counts = torch.zeros(batch * padded, dtype=torch.int32, device=dev)
+    groups = batch * padded // 16
+    chunks = int(min(64, max(1, 2048 // max(groups, 1), 1)))     # ~2000 workgroups: 8 per CU
+    per_chunk = torch.empty(batch * padded, chunks, dtype=torch.int32, device=dev)
     lib = L.lib()
     L.check(lib.efg_cylinder_select_f32(L.ptr(cloud), cloud.shape[0], cloud.shape[1], cloud.shape[1] - 1, 1.0, L.ptr(rng),
-                                        L.ptr(xyr), batch * padded, None, L.ptr(counts), None, L.stream()))
+                                        L.ptr(xyr), batch * padded, None, L.ptr(counts), None, chunks, L.ptr(per_chunk),
+                                        L.stream()))
     host = counts.view(batch, padded)[:, :n_rois].tolist()          # the step's one read-back for the crop
     flat_counts = counts.view(batch, padded).long()
     starts = (torch.cumsum(flat_counts.reshape(-1), 0) - flat_counts.reshape(-1)).contiguous()
@@ -187,7 +191,7 @@ def _crop_select_gpu(first, clouds, k):
     if total:
         L.check(lib.efg_cylinder_select_f32(L.ptr(cloud), cloud.shape[0], cloud.shape[1], cloud.shape[1] - 1, 1.0,
                                             L.ptr(rng), L.ptr(xyr), batch * padded, L.ptr(starts), None, L.ptr(index),
-                                            L.stream()))
+                                            chunks, L.ptr(per_chunk), L.stream()))
     return cloud, base, host, flat_counts[:, :n_rois], starts.view(batch, padded)[:, :n_rois], index, total
 
 

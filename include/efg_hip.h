@@ -285,10 +285,13 @@ int efg_nms_segmented_f32(const float* boxes_sorted, const int32_t* segment, int
  * time_col < 0).  n_cyl must be a multiple of 16 and every aligned group of 16 must share one point range (pad a
  * scene's list with r = -1).  Call 1: starts = index = NULL, counts i32 [n_cyl] <- number of points inside.
  * Call 2: starts i64 [n_cyl] (exclusive prefix of the counts), index i32 [sum counts] <- the rows (relative to lo) of
- * cylinder c's points, ascending, at index[starts[c] ...]. */
+ * cylinder c's points, ascending, at index[starts[c] ...].
+ * n_chunks (1..64): every scene's point range is cut into that many slices, one workgroup per (16 cylinders, slice), so
+ * that a few hundred cylinders fill the chip.  With n_chunks > 1: chunk_counts i32 [n_cyl][n_chunks] is written by call
+ * 1 and read by call 2 (same n_chunks), and call 1 ACCUMULATES into counts, which must be zero on entry. */
 int efg_cylinder_select_f32(const float* points, int64_t n_points, int f, int time_col, float max_time,
                             const int64_t* point_range, const float* centre_radius, int64_t n_cyl, const int64_t* starts,
-                            int32_t* counts, int32_t* index, void* stream);
+                            int32_t* counts, int32_t* index, int n_chunks, int32_t* chunk_counts, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Self-attention over short sequences in exact fp32 (csrc/attention.hip): softmax(scale * Q K^T) V for 1 <= seq <= 128

@@ -10,7 +10,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _select(points, rng, xyr, time_col):
+def _select(points, rng, xyr, time_col, chunks=1):
     from efg_amd import _lib as L
 
     dev = points.device
@@ -18,20 +18,24 @@ def _select(points, rng, xyr, time_col):
     rng_t = torch.as_tensor(rng, device=dev).contiguous()
     xyr_t = torch.as_tensor(xyr, device=dev).contiguous()
     lib = L.lib()
+    per_chunk = torch.full((len(xyr), chunks), -3, dtype=torch.int32, device=dev)
     L.check(lib.efg_cylinder_select_f32(L.ptr(points), points.shape[0], points.shape[1], time_col, 1.0, L.ptr(rng_t),
-                                        L.ptr(xyr_t), len(xyr), None, L.ptr(counts), None, L.stream()))
+                                        L.ptr(xyr_t), len(xyr), None, L.ptr(counts), None, chunks, L.ptr(per_chunk),
+                                        L.stream()))
     c = counts.long()
     starts = (torch.cumsum(c, 0) - c).contiguous()
     total = int(c.sum())
     index = torch.full((max(total, 1),), -7, dtype=torch.int32, device=dev)
     L.check(lib.efg_cylinder_select_f32(L.ptr(points), points.shape[0], points.shape[1], time_col, 1.0, L.ptr(rng_t),
-                                        L.ptr(xyr_t), len(xyr), L.ptr(starts), None, L.ptr(index), L.stream()))
+                                        L.ptr(xyr_t), len(xyr), L.ptr(starts), None, L.ptr(index), chunks, L.ptr(per_chunk),
+                                        L.stream()))
     return counts.cpu().numpy(), starts.cpu().numpy(), index.cpu().numpy()[:total]
 
 
+@pytest.mark.parametrize("chunks", [1, 7, 64])
 @pytest.mark.parametrize("sizes,cyl,time_col", [((5000,), 16, -1), ((30000, 0, 12345), 48, 5), ((180000, 170000), 320, 5),
                                                  ((257,), 16, 5)])
-def test_counts_and_ordered_indices_match_oracle(dev, sizes, cyl, time_col):
+def test_counts_and_ordered_indices_match_oracle(dev, sizes, cyl, time_col, chunks):
     rng = np.random.default_rng(sum(sizes) + cyl)
     clouds = [np.concatenate([rng.uniform(-40, 40, (n, 3)), rng.uniform(0, 1, (n, 2)),
                               rng.choice([0.0, 0.1, 1.0, 1.2], (n, 1), p=[0.6, 0.2, 0.1, 0.1])], 1).astype(np.float32)
@@ -47,7 +51,7 @@ def test_counts_and_ordered_indices_match_oracle(dev, sizes, cyl, time_col):
         xyr.append(c)
         ranges.append(np.repeat([[base[s], base[s + 1]]], cyl, 0))
     xyr, ranges = np.concatenate(xyr), np.concatenate(ranges).astype(np.int64)
-    counts, starts, index = _select(torch.from_numpy(pts).to(dev), ranges, xyr, time_col)
+    counts, starts, index = _select(torch.from_numpy(pts).to(dev), ranges, xyr, time_col, chunks)
     want_counts, want_lists = oracle.cylinder_select(pts, ranges, xyr, time_col, 1.0)
     np.testing.assert_array_equal(counts, want_counts)
     for c in range(len(xyr)):
