@@ -10,8 +10,10 @@
 // the row reductions of the softmax are 32 in-lane values + two cross-lane steps.  The backward recomputes the
 // probabilities from the saved log-sum-exp in two kernels: dQ with waves owning queries (S^T orientation), dK / dV
 // with waves owning keys (S orientation, where the tile is the A operand of P^T dO and dS^T Q).  Q, K, V are read
-// straight from the fused in-projection output [B, S, 3, H, 64]; dQ, dK, dV are written into ONE tensor of the same
-// layout, the gradient of that projection.
+// through (batch, row) strides, i.e. straight from the fused in-projection output [B, S, 3, H, 64], and dQ, dK, dV are
+// written with the same strides into ONE tensor of that layout, the gradient of the projection.  The same kernels serve
+// the encoder's cross-attention (its summary token, 1 query, against the 128 points: Q [B, 1, H, 64], K | V
+// [B, 128, 2, H, 64]); there only the first wave has queries and the kernels are bound by reading K and V.
 //
 // k-index permutation: the dot products over d use lane group j for d = 16 t + 4 j + s (s = MFMA step), so that one
 // 16-byte LDS / global read feeds four MFMAs; A and B use the same permutation, the sum is order-independent.
@@ -71,21 +73,31 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const float* __restrict__ qkv, int seq, int heads, float scale,
-                                                          float* __restrict__ out, float* __restrict__ lse) {
+// Operand addressing shared by the three kernels: element (b, row, h, d) of Q at q + b * q_bs + row * q_rs + h * 64 + d,
+// of K / V at k|v + b * kv_bs + row * kv_rs + h * 64 + d; gradients use the strides of the operand they belong to.
+struct Operands {
+  const float* q;
+  const float* k;
+  const float* v;
+  long long q_bs, q_rs, kv_bs, kv_rs;
+  int sq, sk, heads;
+  float scale;
+};
+
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const Operands a, float* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) float Ks[kS][kLd];
   __shared__ __attribute__((aligned(16))) float Vs[kS][kLd];
+  const int heads = a.heads, seq = a.sk, sq = a.sq;
+  const float scale = a.scale;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const long long rs = 3LL * heads * kD;
-  const float* base = qkv + (long long)b * seq * rs + h * kD;
-  load_rows(Ks, base + heads * kD, seq, rs);
-  load_rows(Vs, base + 2 * heads * kD, seq, rs);
+  load_rows(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs);
+  load_rows(Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
   const int q0 = 32 * wv;
   f32x4 bq[2][4];
-  load_frags(bq, base, q0, seq, rs, scale * kLog2e);
+  load_frags(bq, a.q + b * a.q_bs + h * kD, q0, sq, a.q_rs, scale * kLog2e);
   __syncthreads();
-  if (q0 >= seq) return;
+  if (q0 >= sq) return;
 
   // S^T tiles: acc[kt][qt][i] = log2e * scale * <K[16 kt + 4 j + i], Q[q0 + 16 qt + c]>
   f32x4 acc[8][2];
@@ -95,9 +107,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const float* __restric
     if (16 * kt < seq) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]);
-        acc[kt][0] = mfma_k4(a, bq[0][t], acc[kt][0]);
-        acc[kt][1] = mfma_k4(a, bq[1][t], acc[kt][1]);
+        const f32x4 ak = *reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]);
+        acc[kt][0] = mfma_k4(ak, bq[0][t], acc[kt][0]);
+        acc[kt][1] = mfma_k4(ak, bq[1][t], acc[kt][1]);
       }
     }
   }
@@ -128,7 +140,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const float* __restric
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) acc[kt][qt] *= inv;
     const int q = q0 + 16 * qt + c;
-    if (j == 0 && q < seq) lse[((long long)b * heads + h) * seq + q] = (m + log2f(sum)) * kLn2;
+    if (j == 0 && q < sq) lse[((long long)b * heads + h) * sq + q] = (m + log2f(sum)) * kLn2;
   }
   // O = P V: the S^T tile is the A operand (row = query c, k = key 4 j + s)
   f32x4 o[2][4];
@@ -156,8 +168,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = q0 + 16 * qt + 4 * j + i;
-      if (q < seq) {
-        float* dst = out + (((long long)b * seq + q) * heads + h) * kD + c;
+      if (q < sq) {
+        float* dst = out + (((long long)b * sq + q) * heads + h) * kD + c;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dst[16 * dt] = o[qt][dt][i];
       }
@@ -165,25 +177,26 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const float* __restric
 }
 
 // ---- backward: dQ (waves own queries) ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const Operands a, const float* __restrict__ out,
                                                              const float* __restrict__ lse, const float* __restrict__ dout,
-                                                             int seq, int heads, float scale, float* __restrict__ dqkv) {
+                                                             float* __restrict__ dq_out) {
   __shared__ __attribute__((aligned(16))) float Ks[kS][kLd];
   __shared__ __attribute__((aligned(16))) float Vs[kS][kLd];
+  const int heads = a.heads, seq = a.sk, sq = a.sq;
+  const float scale = a.scale;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const long long rs = 3LL * heads * kD, os = (long long)heads * kD;
-  const float* base = qkv + (long long)b * seq * rs + h * kD;
-  load_rows(Ks, base + heads * kD, seq, rs);
-  load_rows(Vs, base + 2 * heads * kD, seq, rs);
+  const long long os = (long long)heads * kD;
+  load_rows(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs);
+  load_rows(Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
   const int q0 = 32 * wv;
   f32x4 bq[2][4], bdo[2][4];
-  load_frags(bq, base, q0, seq, rs, scale * kLog2e);
-  load_frags(bdo, dout + (long long)b * seq * os + h * kD, q0, seq, os, 1.f);
+  load_frags(bq, a.q + b * a.q_bs + h * kD, q0, sq, a.q_rs, scale * kLog2e);
+  load_frags(bdo, dout + (long long)b * sq * os + h * kD, q0, sq, os, 1.f);
   float delta[2], l2[2];
   {
     f32x4 bo[2][4];
-    load_frags(bo, out + (long long)b * seq * os + h * kD, q0, seq, os, 1.f);
+    load_frags(bo, out + (long long)b * sq * os + h * kD, q0, sq, os, 1.f);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float part = 0.f;
@@ -194,11 +207,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const float* __rest
       }
       delta[qt] = group_sum(part);
       const int q = q0 + 16 * qt + c;
-      l2[qt] = q < seq ? lse[((long long)b * heads + h) * seq + q] * kLog2e : 0.f;
+      l2[qt] = q < sq ? lse[((long long)b * heads + h) * sq + q] * kLog2e : 0.f;
     }
   }
   __syncthreads();
-  if (q0 >= seq) return;
+  if (q0 >= sq) return;
 
   f32x4 dq[2][4];
 #pragma unroll
@@ -243,8 +256,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = q0 + 16 * qt + 4 * j + i;
-      if (q < seq) {
-        float* dst = dqkv + ((long long)b * seq + q) * rs + h * kD + c;
+      if (q < sq) {
+        float* dst = dq_out + b * a.q_bs + q * a.q_rs + h * kD + c;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dst[16 * dt] = dq[qt][dt][i] * scale;
       }
@@ -252,23 +265,24 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const float* __rest
 }
 
 // ---- backward: dK, dV (waves own keys) --------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const Operands a, const float* __restrict__ out,
                                                               const float* __restrict__ lse, const float* __restrict__ dout,
-                                                              int seq, int heads, float scale, float* __restrict__ dqkv) {
+                                                              float* __restrict__ dk_out, float* __restrict__ dv_out) {
   __shared__ __attribute__((aligned(16))) float Qs[kS][kLd];
   __shared__ __attribute__((aligned(16))) float dOs[kS][kLd];
   __shared__ float l2s[kS], dls[kS];
+  const int heads = a.heads, seq = a.sk, sq = a.sq;
+  const float scale = a.scale;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const long long rs = 3LL * heads * kD, os = (long long)heads * kD;
-  const float* base = qkv + (long long)b * seq * rs + h * kD;
-  const float* dob = dout + (long long)b * seq * os + h * kD;
-  const float* ob = out + (long long)b * seq * os + h * kD;
-  load_rows(Qs, base, seq, rs);
-  load_rows(dOs, dob, seq, os);
+  const long long os = (long long)heads * kD;
+  const float* dob = dout + (long long)b * sq * os + h * kD;
+  const float* ob = out + (long long)b * sq * os + h * kD;
+  load_rows(Qs, a.q + b * a.q_bs + h * kD, sq, a.q_rs);
+  load_rows(dOs, dob, sq, os);
   {   // delta[q] = <dO[q], O[q]>, two threads per query
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
     float part = 0.f;
-    if (q < seq) {
+    if (q < sq) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(dob + q * os + 32 * half + 4 * u);
@@ -280,14 +294,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const float* __res
     part += __shfl_xor(part, 1);
     if (half == 0) {
       dls[q] = part;
-      l2s[q] = q < seq ? lse[((long long)b * heads + h) * seq + q] * kLog2e : 1e30f;   // beyond the sequence: p = 0
+      l2s[q] = q < sq ? lse[((long long)b * heads + h) * sq + q] * kLog2e : 1e30f;   // beyond the sequence: p = 0
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
   const int k0 = 32 * wv;
   f32x4 bk[2][4], bv[2][4];
-  load_frags(bk, base + heads * kD, k0, seq, rs, scale * kLog2e);
-  load_frags(bv, base + 2 * heads * kD, k0, seq, rs, 1.f);
+  load_frags(bk, a.k + b * a.kv_bs + h * kD, k0, seq, a.kv_rs, scale * kLog2e);
+  load_frags(bv, a.v + b * a.kv_bs + h * kD, k0, seq, a.kv_rs, 1.f);
   __syncthreads();
   if (k0 >= seq) return;
 
@@ -298,7 +312,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const float* __res
     for (int dt = 0; dt < 4; ++dt) dk[kt][dt] = dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
   for (int qt = 0; qt < 8; ++qt) {
-    if (16 * qt >= seq) break;
+    if (16 * qt >= sq) break;
     f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -344,11 +358,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const float* __res
     for (int i = 0; i < 4; ++i) {
       const int key = k0 + 16 * kt + 4 * j + i;
       if (key < seq) {
-        float* dst = dqkv + ((long long)b * seq + key) * rs + h * kD + c;
+        const long long at = b * a.kv_bs + key * a.kv_rs + h * kD + c;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dst[heads * kD + 16 * dt] = dk[kt][dt][i] * scale;
-          dst[2 * heads * kD + 16 * dt] = dv[kt][dt][i];
+          dk_out[at + 16 * dt] = dk[kt][dt][i] * scale;
+          dv_out[at + 16 * dt] = dv[kt][dt][i];
         }
       }
     }
@@ -361,34 +375,51 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 using namespace efg;
 
-// qkv [batch, seq, 3, heads, 64] (the fused in-projection output) -> out [batch, seq, heads, 64], lse [batch, heads, seq]
-// (natural-log sum of exp(scale * <q, k>)).  1 <= seq <= 128.
-extern "C" int efg_attention_fwd_f32(const float* qkv, int64_t batch, int seq, int heads, float scale, float* out, float* lse,
-                                     void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  EFG_CHECK_ARG(batch >= 0 && heads >= 1 && seq >= 1 && seq <= kS, "attention_fwd: 1 <= seq <= %d, head width %d", kS, kD);
+static int check_operands(const char* who, const float* q, int64_t q_bs, int64_t q_rs, const float* k, const float* v, int64_t kv_bs,
+                          int64_t kv_rs, int64_t batch, int seq_q, int seq_k, int heads) {
+  EFG_CHECK_ARG(batch >= 0 && heads >= 1 && seq_q >= 1 && seq_q <= kS && seq_k >= 1 && seq_k <= kS,
+                "%s: 1 <= seq_q, seq_k <= %d, head width %d", who, kS, kD);
+  EFG_CHECK_ARG(batch * heads < (1LL << 31), "%s: too many sequences", who);
   if (batch == 0) return EFG_OK;
-  EFG_CHECK_ARG(qkv && out && lse && aligned16(qkv), "attention_fwd: null or unaligned pointer");
-  EFG_CHECK_ARG(batch * heads < (1LL << 31), "attention_fwd: too many sequences");
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, qkv, seq, heads, scale, out, lse);
+  EFG_CHECK_ARG(q && k && v && aligned16(q) && aligned16(k) && aligned16(v), "%s: null or unaligned operand", who);
+  EFG_CHECK_ARG(q_bs % 4 == 0 && q_rs % 4 == 0 && kv_bs % 4 == 0 && kv_rs % 4 == 0 && q_rs >= (int64_t)heads * kD &&
+                    kv_rs >= (int64_t)heads * kD,
+                "%s: strides must be multiples of 4 floats and rows at least heads x %d wide", who, kD);
+  return EFG_OK;
+}
+
+// softmax(scale * Q K^T) V per (sequence, head).  Element (b, row, h, d) of Q at q + b * q_batch_stride + row * q_row_stride
+// + h * 64 + d, of K / V at k|v + b * kv_batch_stride + row * kv_row_stride + h * 64 + d (strides in floats), which
+// covers the fused in-projection layouts [B, S, 3, H, 64] (self-attention) and [B, Sk, 2, H, 64] + [B, Sq, H, 64] (cross).
+// out [batch, seq_q, heads, 64], lse [batch, heads, seq_q].
+extern "C" int efg_attention_fwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k, const float* v,
+                                     int64_t kv_batch_stride, int64_t kv_row_stride, int64_t batch, int seq_q, int seq_k, int heads,
+                                     float scale, float* out, float* lse, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = check_operands("attention_fwd", q, q_batch_stride, q_row_stride, k, v, kv_batch_stride, kv_row_stride, batch, seq_q,
+                                seq_k, heads);
+  if (rc != EFG_OK || batch == 0) return rc;
+  EFG_CHECK_ARG(out && lse, "attention_fwd: null output");
+  const Operands a{q, k, v, q_batch_stride, q_row_stride, kv_batch_stride, kv_row_stride, seq_q, seq_k, heads, scale};
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, a, out, lse);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
 
-// dqkv [batch, seq, 3, heads, 64] = gradient of the in-projection output, every element written.
-extern "C" int efg_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, int64_t batch, int seq,
-                                     int heads, float scale, float* dqkv, void* stream_) {
+// dq / dk / dv are addressed like q / k / v (same strides); every element of the (b, row < seq, h, d) sub-arrays is written.
+extern "C" int efg_attention_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k, const float* v,
+                                     int64_t kv_batch_stride, int64_t kv_row_stride, const float* out, const float* lse,
+                                     const float* dout, int64_t batch, int seq_q, int seq_k, int heads, float scale, float* dq,
+                                     float* dk, float* dv, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EFG_CHECK_ARG(batch >= 0 && heads >= 1 && seq >= 1 && seq <= kS, "attention_bwd: 1 <= seq <= %d, head width %d", kS, kD);
-  if (batch == 0) return EFG_OK;
-  EFG_CHECK_ARG(qkv && out && lse && dout && dqkv && aligned16(qkv) && aligned16(out) && aligned16(dout),
-                "attention_bwd: null or unaligned pointer");
-  EFG_CHECK_ARG(batch * heads < (1LL << 31), "attention_bwd: too many sequences");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, qkv, out, lse, dout, seq, heads,
-                     scale, dqkv);
+  const int rc = check_operands("attention_bwd", q, q_batch_stride, q_row_stride, k, v, kv_batch_stride, kv_row_stride, batch, seq_q,
+                                seq_k, heads);
+  if (rc != EFG_OK || batch == 0) return rc;
+  EFG_CHECK_ARG(out && lse && dout && dq && dk && dv && aligned16(out) && aligned16(dout), "attention_bwd: null or unaligned pointer");
+  const Operands a{q, k, v, q_batch_stride, q_row_stride, kv_batch_stride, kv_row_stride, seq_q, seq_k, heads, scale};
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, a, out, lse, dout, dq);
   EFG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, qkv, out, lse, dout, seq, heads,
-                     scale, dqkv);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, a, out, lse, dout, dk, dv);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

@@ -34,23 +34,15 @@ class MLP(nn.Module):
 
 def attend(mha, query, memory):
     """softmax(Q K^T / sqrt(d)) V with the parameters of an nn.MultiheadAttention, batch-first:
-    query [B, Lq, C], memory [B, Lk, C] (keys = values) -> [B, Lq, C]."""
+    query [B, Lq, C], memory [B, Lk, C] (keys = values) -> [B, Lq, C].  The core runs csrc/attention.hip on the GPU for
+    up to 128 tokens and 64-wide heads (operators/attention.py), SDPA otherwise."""
     c, h = mha.embed_dim, mha.num_heads
-    b, lq, _ = query.shape
     if query is memory:
-        qkv = linear(query, mha.in_proj_weight, mha.in_proj_bias)
-        if attention.fused(qkv, h):      # csrc/attention.hip: the point encoder's 128-token, 64-wide-head self-attention
-            return linear(attention.self_attention_qkv(qkv, h), mha.out_proj.weight, mha.out_proj.bias)
-        q, k, v = qkv.chunk(3, dim=-1)
+        out = attention.self_attention_qkv(linear(query, mha.in_proj_weight, mha.in_proj_bias), h)
     else:
-        q = linear(query, mha.in_proj_weight[:c], mha.in_proj_bias[:c])
-        k, v = linear(memory, mha.in_proj_weight[c:], mha.in_proj_bias[c:]).chunk(2, dim=-1)
-
-    def heads(t):
-        return t.reshape(b, t.shape[1], h, c // h).transpose(1, 2)
-
-    out = F.scaled_dot_product_attention(heads(q), heads(k), heads(v))
-    return linear(out.transpose(1, 2).reshape(b, lq, c), mha.out_proj.weight, mha.out_proj.bias)
+        out = attention.cross_attention_kv(linear(query, mha.in_proj_weight[:c], mha.in_proj_bias[:c]),
+                                           linear(memory, mha.in_proj_weight[c:], mha.in_proj_bias[c:]), h)
+    return linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
 class TransformerEncoderLayer(nn.Module):

@@ -294,18 +294,25 @@ int efg_cylinder_select_f32(const float* points, int64_t n_points, int f, int ti
                             int32_t* counts, int32_t* index, int n_chunks, int32_t* chunk_counts, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Self-attention over short sequences in exact fp32 (csrc/attention.hip): softmax(scale * Q K^T) V for 1 <= seq <= 128
- * tokens and 64-wide heads, one workgroup per (sequence, head), probabilities kept in MFMA accumulators.  Replaces the
- * nn.MultiheadAttention core of TrajectoryFormer's point encoder (.../trajectoryformer.centerpoint/modules/
- * transformer.py:44-92: self_attn over the 128 points of every trajectory hypothesis; 1232 x 4 sequences per layer).
- *   qkv f32 [batch, seq, 3, heads, 64]: the fused in-projection output (q | k | v along the channel axis)
- *   out f32 [batch, seq, heads, 64]; lse f32 [batch, heads, seq] = log sum_k exp(scale * <q, k>) (kept for the backward)
- * Backward: dout f32 [batch, seq, heads, 64] -> dqkv f32 [batch, seq, 3, heads, 64], the gradient of the in-projection
- * output (every element written); the probabilities are recomputed from lse. */
-int efg_attention_fwd_f32(const float* qkv, int64_t batch, int seq, int heads, float scale, float* out, float* lse,
-                          void* stream);
-int efg_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, int64_t batch, int seq,
-                          int heads, float scale, float* dqkv, void* stream);
+ * Attention over short sequences in exact fp32 (csrc/attention.hip): softmax(scale * Q K^T) V for 1 <= seq_q, seq_k <=
+ * 128 tokens and 64-wide heads, one workgroup per (sequence, head), probabilities kept in MFMA accumulators.  Replaces
+ * the nn.MultiheadAttention cores of TrajectoryFormer's point encoder (.../trajectoryformer.centerpoint/modules/
+ * transformer.py:44-92: self_attn over the 128 points of every trajectory hypothesis, 1232 x 4 sequences per layer, and
+ * point_attn of the summary token against them).
+ *   element (b, row, h, d) of Q at q + b * q_batch_stride + row * q_row_stride + h * 64 + d, of K / V at
+ *   k|v + b * kv_batch_stride + row * kv_row_stride + h * 64 + d (strides in floats, multiples of 4; 16-byte aligned
+ *   bases): the fused in-projection outputs [B, S, 3, H, 64] (q | k | v along the channel axis) or [B, Sq, H, 64] +
+ *   [B, Sk, 2, H, 64] are read in place.
+ *   out f32 [batch, seq_q, heads, 64]; lse f32 [batch, heads, seq_q] = log sum_k exp(scale * <q, k>) (for the backward)
+ * Backward: dout f32 [batch, seq_q, heads, 64] -> dq / dk / dv addressed with the strides of q / k / v (so one tensor of
+ * the in-projection's layout receives all three); the probabilities are recomputed from lse. */
+int efg_attention_fwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k, const float* v,
+                          int64_t kv_batch_stride, int64_t kv_row_stride, int64_t batch, int seq_q, int seq_k, int heads,
+                          float scale, float* out, float* lse, void* stream);
+int efg_attention_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k, const float* v,
+                          int64_t kv_batch_stride, int64_t kv_row_stride, const float* out, const float* lse,
+                          const float* dout, int64_t batch, int seq_q, int seq_k, int heads, float scale, float* dq, float* dk,
+                          float* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the

@@ -42,13 +42,53 @@ def test_forward_backward_match_fp64(batch, seq, heads):
     # as accurate as PyTorch's own fp32 evaluation of the same formula (within 4x), and tight in absolute terms
     assert err(out, out64) <= max(4 * err(out32, out64), 2e-6), (err(out, out64), err(out32, out64))
     assert err(qkv.grad, x64.grad) <= max(4 * err(x32.grad, x64.grad), 5e-6), (err(qkv.grad, x64.grad), err(x32.grad, x64.grad))
-    # the saved log-sum-exp
+    # the saved log-sum-exp, through the C ABI
+    c = heads * 64
+    x = qkv.detach()
     lse = torch.empty(batch, heads, seq, device=dev)
-    o2 = torch.empty(batch, seq, heads * 64, device=dev)
-    L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv.detach()), batch, seq, heads, 1 / math.sqrt(64), L.ptr(o2), L.ptr(lse),
+    o2 = torch.empty(batch, seq, c, device=dev)
+    L.check(L.lib().efg_attention_fwd_f32(x.data_ptr(), seq * 3 * c, 3 * c, x.data_ptr() + 4 * c, x.data_ptr() + 8 * c,
+                                          seq * 3 * c, 3 * c, batch, seq, seq, heads, 1 / math.sqrt(64), L.ptr(o2), L.ptr(lse),
                                           L.stream()))
     assert torch.equal(o2, out.detach())
     assert err(lse, lse64) <= 1e-6
+
+
+@pytest.mark.parametrize("batch,sq,sk,heads", [(41, 1, 128, 4), (7, 5, 77, 2), (3, 128, 16, 4), (2, 40, 128, 1)])
+def test_cross_attention_matches_fp64(batch, sq, sk, heads):
+    from efg_amd.operators.attention import cross_attention_kv, fused_cross
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(batch * 100 + sq + sk)
+    c = heads * 64
+    q = torch.randn(batch, sq, c, generator=g).to(dev).requires_grad_(True)
+    kv = (torch.randn(batch, sk, 2 * c, generator=g) * 1.3).to(dev).requires_grad_(True)
+    w = torch.randn(batch, sq, c, generator=g).to(dev)
+    assert fused_cross(q, kv, heads)
+    out = cross_attention_kv(q, kv, heads)
+    (out * w).sum().backward()
+
+    def ref(dtype):
+        q_, kv_ = q.detach().to(dtype).requires_grad_(True), kv.detach().to(dtype).requires_grad_(True)
+        k_, v_ = kv_.chunk(2, -1)
+
+        def split(t):
+            return t.reshape(batch, t.shape[1], heads, 64).transpose(1, 2)
+
+        att = torch.softmax(split(q_) @ split(k_).transpose(-1, -2) / 8.0, -1)
+        o = (att @ split(v_)).transpose(1, 2).reshape(batch, sq, c)
+        (o * w.to(dtype)).sum().backward()
+        return o.detach(), q_.grad, kv_.grad
+
+    o64, dq64, dkv64 = ref(torch.float64)
+    o32, dq32, dkv32 = ref(torch.float32)
+
+    def err(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+
+    assert err(out, o64) <= max(4 * err(o32, o64), 2e-6)
+    assert err(q.grad, dq64) <= max(4 * err(dq32, dq64), 5e-6)
+    assert err(kv.grad, dkv64) <= max(4 * err(dkv32, dkv64), 5e-6)
 
 
 def test_matches_sdpa_in_the_point_encoder_layer():
@@ -63,19 +103,23 @@ def test_matches_sdpa_in_the_point_encoder_layer():
     torch.manual_seed(0)
     mha = nn.MultiheadAttention(256, 4).to(dev)
     x = torch.randn(61, 128, 256, device=dev)
-    res = {}
-    for mode in ("1", "0"):
-        os.environ["EFG_ATTENTION"] = mode
-        try:
-            mha.zero_grad()
-            xi = x.clone().requires_grad_(True)
-            y = attend(mha, xi, xi)
-            y.square().sum().backward()
-            res[mode] = (y.detach(), xi.grad, mha.in_proj_weight.grad.clone(), mha.out_proj.weight.grad.clone())
-        finally:
-            os.environ.pop("EFG_ATTENTION", None)
-    for a, b in zip(res["1"], res["0"]):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    token = torch.randn(61, 1, 256, device=dev)
+    for cross in (False, True):
+        res = {}
+        for mode in ("1", "0"):
+            os.environ["EFG_ATTENTION"] = mode
+            try:
+                mha.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                ti = token.clone().requires_grad_(True)
+                y = attend(mha, ti, xi) if cross else attend(mha, xi, xi)
+                y.square().sum().backward()
+                res[mode] = (y.detach(), xi.grad, mha.in_proj_weight.grad.clone(), mha.out_proj.weight.grad.clone()) + \
+                    ((ti.grad,) if cross else ())
+            finally:
+                os.environ.pop("EFG_ATTENTION", None)
+        for a, b in zip(res["1"], res["0"]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
 def test_bad_arguments_are_reported():
@@ -86,4 +130,8 @@ def test_bad_arguments_are_reported():
     out = torch.zeros(1, 129, 64, device=dev)
     lse = torch.zeros(1, 1, 129, device=dev)
     with pytest.raises(RuntimeError, match="seq"):
-        L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv), 1, 129, 1, 0.125, L.ptr(out), L.ptr(lse), L.stream()))
+        L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv), 129 * 192, 192, qkv.data_ptr() + 256, qkv.data_ptr() + 512, 129 * 192,
+                                              192, 1, 129, 129, 1, 0.125, L.ptr(out), L.ptr(lse), L.stream()))
+    with pytest.raises(RuntimeError, match="strides"):
+        L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv), 64 * 190, 190, qkv.data_ptr() + 256, qkv.data_ptr() + 512, 64 * 190,
+                                              190, 1, 64, 64, 1, 0.125, L.ptr(out), L.ptr(lse), L.stream()))
