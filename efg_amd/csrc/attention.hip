@@ -37,13 +37,24 @@ __device__ __forceinline__ f32x4 mfma_k4(const f32x4 a, const f32x4 b, f32x4 c) 
   return c;
 }
 
-// rows [0, seq) of a [seq, 64] strided matrix into LDS, rows beyond zero-filled
-__device__ __forceinline__ void load_rows(float (*dst)[kLd], const float* __restrict__ src, int seq, long long stride) {
-  for (int idx = threadIdx.x; idx < kS * 16; idx += 256) {
-    const int row = idx >> 4, c4 = idx & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < seq) v = *reinterpret_cast<const f32x4*>(src + row * stride + 4 * c4);
-    *reinterpret_cast<f32x4*>(&dst[row][4 * c4]) = v;
+// rows [0, seq) of two [seq, 64] strided matrices into LDS, rows beyond zero-filled.  All 16 global loads of a thread are
+// issued before the first LDS write (unconditional loads from a clamped row, zeroed afterwards): written as a loop of
+// load-then-store the compiler waits for every pair of loads, and with two waves per SIMD nothing hides that latency.
+__device__ __forceinline__ void load_rows2(float (*dst_a)[kLd], const float* __restrict__ src_a, int seq_a, long long stride_a,
+                                           float (*dst_b)[kLd], const float* __restrict__ src_b, int seq_b, long long stride_b) {
+  f32x4 va[8], vb[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = threadIdx.x + 256 * it, row = idx >> 4, c4 = idx & 15;
+    va[it] = *reinterpret_cast<const f32x4*>(src_a + min(row, seq_a - 1) * stride_a + 4 * c4);
+    vb[it] = *reinterpret_cast<const f32x4*>(src_b + min(row, seq_b - 1) * stride_b + 4 * c4);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = threadIdx.x + 256 * it, row = idx >> 4, c4 = idx & 15;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(&dst_a[row][4 * c4]) = row < seq_a ? va[it] : zero;
+    *reinterpret_cast<f32x4*>(&dst_b[row][4 * c4]) = row < seq_b ? vb[it] : zero;
   }
 }
 
@@ -54,12 +65,10 @@ __device__ __forceinline__ void load_frags(f32x4 (&frag)[2][4], const float* __r
 #pragma unroll
   for (int tile = 0; tile < 2; ++tile) {
     const int row = row0 + 16 * tile + c;
+    const float m = row < seq ? mul : 0.f;   // rows beyond the sequence: a clamped (valid) load, zeroed
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < seq) v = *reinterpret_cast<const f32x4*>(src + row * stride + 16 * t + 4 * j);
-      frag[tile][t] = v * mul;
-    }
+    for (int t = 0; t < 4; ++t)
+      frag[tile][t] = *reinterpret_cast<const f32x4*>(src + min(row, seq - 1) * stride + 16 * t + 4 * j) * m;
   }
 }
 
@@ -90,26 +99,33 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const Operands a, floa
   const int heads = a.heads, seq = a.sk, sq = a.sq;
   const float scale = a.scale;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  load_rows(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs);
-  load_rows(Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
   const int q0 = 32 * wv;
   f32x4 bq[2][4];
   load_frags(bq, a.q + b * a.q_bs + h * kD, q0, sq, a.q_rs, scale * kLog2e);
+  load_rows2(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs, Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
   __syncthreads();
   if (q0 >= sq) return;
 
-  // S^T tiles: acc[kt][qt][i] = log2e * scale * <K[16 kt + 4 j + i], Q[q0 + 16 qt + c]>
+  // S^T tiles: acc[kt][qt][i] = log2e * scale * <K[16 kt + 4 j + i], Q[q0 + 16 qt + c]>.  The A fragments of key tile
+  // kt + 1 are read while tile kt multiplies (the compiler otherwise waits on every pair of reads right before its MFMAs).
   f32x4 acc[8][2];
+  f32x4 ak[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ak[0][t] = *reinterpret_cast<const f32x4*>(&Ks[c][16 * t + 4 * j]);
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     acc[kt][0] = acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (16 * kt < seq) {
+      if (kt + 1 < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          ak[(kt + 1) & 1][t] = *reinterpret_cast<const f32x4*>(&Ks[16 * (kt + 1) + c][16 * t + 4 * j]);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f32x4 ak = *reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]);
-        acc[kt][0] = mfma_k4(ak, bq[0][t], acc[kt][0]);
-        acc[kt][1] = mfma_k4(ak, bq[1][t], acc[kt][1]);
+        acc[kt][0] = mfma_k4(ak[kt & 1][t], bq[0][t], acc[kt][0]);
+        acc[kt][1] = mfma_k4(ak[kt & 1][t], bq[1][t], acc[kt][1]);
       }
     }
   }
@@ -148,19 +164,19 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const Operands a, floa
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto v_frag = [&](int u) {   // B operand of step u = 4 kt + dt: V[16 kt + 4 j + s][16 dt + c], s = 0..3
+    const float* p = &Vs[16 * (u >> 2) + 4 * j][16 * (u & 3) + c];
+    return f32x4{p[0], p[kLd], p[2 * kLd], p[3 * kLd]};
+  };
+  const int steps = 4 * min(8, (seq + 15) >> 4);
+  f32x4 vf[2];
+  vf[0] = v_frag(0);
 #pragma unroll
-  for (int kt = 0; kt < 8; ++kt) {
-    if (16 * kt < seq) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        f32x4 v;
-        v.x = Vs[16 * kt + 4 * j + 0][16 * dt + c];
-        v.y = Vs[16 * kt + 4 * j + 1][16 * dt + c];
-        v.z = Vs[16 * kt + 4 * j + 2][16 * dt + c];
-        v.w = Vs[16 * kt + 4 * j + 3][16 * dt + c];
-        o[0][dt] = mfma_k4(acc[kt][0], v, o[0][dt]);
-        o[1][dt] = mfma_k4(acc[kt][1], v, o[1][dt]);
-      }
+  for (int u = 0; u < 32; ++u) {
+    if (u < steps) {
+      if (u + 1 < 32) vf[(u + 1) & 1] = v_frag(u + 1);   // (a tile past `seq` is read but not used: rows exist, zero-filled)
+      o[0][u & 3] = mfma_k4(acc[u >> 2][0], vf[u & 1], o[0][u & 3]);
+      o[1][u & 3] = mfma_k4(acc[u >> 2][1], vf[u & 1], o[1][u & 3]);
     }
   }
 #pragma unroll
@@ -186,8 +202,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const Operands a, c
   const float scale = a.scale;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const long long os = (long long)heads * kD;
-  load_rows(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs);
-  load_rows(Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
+  load_rows2(Ks, a.k + b * a.kv_bs + h * kD, seq, a.kv_rs, Vs, a.v + b * a.kv_bs + h * kD, seq, a.kv_rs);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
   const int q0 = 32 * wv;
   f32x4 bq[2][4], bdo[2][4];
@@ -218,37 +233,52 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const Operands a, c
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+  // per key tile: the A fragments of tile kt + 1 and the K^T fragments of this tile's dQ product are read before the
+  // S / dP products start, so the LDS latency sits under 32 MFMAs
+  f32x4 ak[2][4], av[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ak[0][t] = *reinterpret_cast<const f32x4*>(&Ks[c][16 * t + 4 * j]);
+    av[0][t] = *reinterpret_cast<const f32x4*>(&Vs[c][16 * t + 4 * j]);
+  }
+#pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
-    if (16 * kt >= seq) break;
-    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (16 * kt < seq) {
+      if (kt + 1 < 8) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 ak = *reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]);
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&Vs[16 * kt + c][16 * t + 4 * j]);
-      s[0] = mfma_k4(ak, bq[0][t], s[0]);
-      s[1] = mfma_k4(ak, bq[1][t], s[1]);
-      dp[0] = mfma_k4(av, bdo[0][t], dp[0]);
-      dp[1] = mfma_k4(av, bdo[1][t], dp[1]);
-    }
-    f32x4 ds[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float p = (16 * kt + 4 * j + i < seq) ? exp2f(s[qt][i] - l2[qt]) : 0.f;
-        ds[qt][i] = p * (dp[qt][i] - delta[qt]);
+        for (int t = 0; t < 4; ++t) {
+          ak[(kt + 1) & 1][t] = *reinterpret_cast<const f32x4*>(&Ks[16 * (kt + 1) + c][16 * t + 4 * j]);
+          av[(kt + 1) & 1][t] = *reinterpret_cast<const f32x4*>(&Vs[16 * (kt + 1) + c][16 * t + 4 * j]);
+        }
       }
+      f32x4 kv[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 kv;
-      kv.x = Ks[16 * kt + 4 * j + 0][16 * dt + c];
-      kv.y = Ks[16 * kt + 4 * j + 1][16 * dt + c];
-      kv.z = Ks[16 * kt + 4 * j + 2][16 * dt + c];
-      kv.w = Ks[16 * kt + 4 * j + 3][16 * dt + c];
-      dq[0][dt] = mfma_k4(ds[0], kv, dq[0][dt]);
-      dq[1][dt] = mfma_k4(ds[1], kv, dq[1][dt]);
+      for (int dt = 0; dt < 4; ++dt) {
+        const float* p = &Ks[16 * kt + 4 * j][16 * dt + c];
+        kv[dt] = f32x4{p[0], p[kLd], p[2 * kLd], p[3 * kLd]};
+      }
+      f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[0] = mfma_k4(ak[kt & 1][t], bq[0][t], s[0]);
+        s[1] = mfma_k4(ak[kt & 1][t], bq[1][t], s[1]);
+        dp[0] = mfma_k4(av[kt & 1][t], bdo[0][t], dp[0]);
+        dp[1] = mfma_k4(av[kt & 1][t], bdo[1][t], dp[1]);
+      }
+      f32x4 ds[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = (16 * kt + 4 * j + i < seq) ? exp2f(s[qt][i] - l2[qt]) : 0.f;
+          ds[qt][i] = p * (dp[qt][i] - delta[qt]);
+        }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dq[0][dt] = mfma_k4(ds[0], kv[dt], dq[0][dt]);
+        dq[1][dt] = mfma_k4(ds[1], kv[dt], dq[1][dt]);
+      }
     }
   }
 #pragma unroll
@@ -277,8 +307,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const Operands a, 
   const long long os = (long long)heads * kD;
   const float* dob = dout + (long long)b * sq * os + h * kD;
   const float* ob = out + (long long)b * sq * os + h * kD;
-  load_rows(Qs, a.q + b * a.q_bs + h * kD, sq, a.q_rs);
-  load_rows(dOs, dob, sq, os);
+  load_rows2(Qs, a.q + b * a.q_bs + h * kD, sq, a.q_rs, dOs, dob, sq, os);
   {   // delta[q] = <dO[q], O[q]>, two threads per query
     const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
     float part = 0.f;
@@ -310,46 +339,57 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const Operands a, 
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dk[kt][dt] = dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+  f32x4 aq[2][4], ad[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    aq[0][t] = *reinterpret_cast<const f32x4*>(&Qs[c][16 * t + 4 * j]);
+    ad[0][t] = *reinterpret_cast<const f32x4*>(&dOs[c][16 * t + 4 * j]);
+  }
+#pragma unroll
   for (int qt = 0; qt < 8; ++qt) {
-    if (16 * qt >= sq) break;
-    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (16 * qt < sq) {
+      if (qt + 1 < 8) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 aq = *reinterpret_cast<const f32x4*>(&Qs[16 * qt + c][16 * t + 4 * j]);
-      const f32x4 ad = *reinterpret_cast<const f32x4*>(&dOs[16 * qt + c][16 * t + 4 * j]);
-      s[0] = mfma_k4(aq, bk[0][t], s[0]);
-      s[1] = mfma_k4(aq, bk[1][t], s[1]);
-      dp[0] = mfma_k4(ad, bv[0][t], dp[0]);
-      dp[1] = mfma_k4(ad, bv[1][t], dp[1]);
-    }
-    // s[kt][i] = S[query 16 qt + 4 j + i][key k0 + 16 kt + c]: the A operand (row = key c, k = query 4 j + s) below
-    f32x4 p[2], ds[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float l = l2s[16 * qt + 4 * j + i], d = dls[16 * qt + 4 * j + i];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        p[kt][i] = exp2f(s[kt][i] - l);
-        ds[kt][i] = p[kt][i] * (dp[kt][i] - d);
+        for (int t = 0; t < 4; ++t) {
+          aq[(qt + 1) & 1][t] = *reinterpret_cast<const f32x4*>(&Qs[16 * (qt + 1) + c][16 * t + 4 * j]);
+          ad[(qt + 1) & 1][t] = *reinterpret_cast<const f32x4*>(&dOs[16 * (qt + 1) + c][16 * t + 4 * j]);
+        }
       }
-    }
+      f32x4 bd[4], bqv[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 bd, bqv;
-      bd.x = dOs[16 * qt + 4 * j + 0][16 * dt + c];
-      bd.y = dOs[16 * qt + 4 * j + 1][16 * dt + c];
-      bd.z = dOs[16 * qt + 4 * j + 2][16 * dt + c];
-      bd.w = dOs[16 * qt + 4 * j + 3][16 * dt + c];
-      bqv.x = Qs[16 * qt + 4 * j + 0][16 * dt + c];
-      bqv.y = Qs[16 * qt + 4 * j + 1][16 * dt + c];
-      bqv.z = Qs[16 * qt + 4 * j + 2][16 * dt + c];
-      bqv.w = Qs[16 * qt + 4 * j + 3][16 * dt + c];
-      dv[0][dt] = mfma_k4(p[0], bd, dv[0][dt]);
-      dv[1][dt] = mfma_k4(p[1], bd, dv[1][dt]);
-      dk[0][dt] = mfma_k4(ds[0], bqv, dk[0][dt]);
-      dk[1][dt] = mfma_k4(ds[1], bqv, dk[1][dt]);
+      for (int dt = 0; dt < 4; ++dt) {
+        const float* pd = &dOs[16 * qt + 4 * j][16 * dt + c];
+        const float* pq = &Qs[16 * qt + 4 * j][16 * dt + c];
+        bd[dt] = f32x4{pd[0], pd[kLd], pd[2 * kLd], pd[3 * kLd]};
+        bqv[dt] = f32x4{pq[0], pq[kLd], pq[2 * kLd], pq[3 * kLd]};
+      }
+      f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[0] = mfma_k4(aq[qt & 1][t], bk[0][t], s[0]);
+        s[1] = mfma_k4(aq[qt & 1][t], bk[1][t], s[1]);
+        dp[0] = mfma_k4(ad[qt & 1][t], bv[0][t], dp[0]);
+        dp[1] = mfma_k4(ad[qt & 1][t], bv[1][t], dp[1]);
+      }
+      // s[kt][i] = S[query 16 qt + 4 j + i][key k0 + 16 kt + c]: the A operand (row = key c, k = query 4 j + s) below
+      f32x4 p[2], ds[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float l = l2s[16 * qt + 4 * j + i], d = dls[16 * qt + 4 * j + i];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          p[kt][i] = exp2f(s[kt][i] - l);
+          ds[kt][i] = p[kt][i] * (dp[kt][i] - d);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[0][dt] = mfma_k4(p[0], bd[dt], dv[0][dt]);
+        dv[1][dt] = mfma_k4(p[1], bd[dt], dv[1][dt]);
+        dk[0][dt] = mfma_k4(ds[0], bqv[dt], dk[0][dt]);
+        dk[1][dt] = mfma_k4(ds[1], bqv[dt], dk[1][dt]);
+      }
     }
   }
 #pragma unroll
