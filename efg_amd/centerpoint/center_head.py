@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from ..modeling.common import get_norm
+from ..operators.batchnorm import run_sequential
 from ..operators.iou3d_nms import nms_gpu
 
 
@@ -72,7 +73,7 @@ class SepHead(nn.Module):
             setattr(self, name, stack)
 
     def forward(self, x):
-        return {name: getattr(self, name)(x) for name in self.heads}
+        return {name: run_sequential(getattr(self, name), x) for name in self.heads}
 
 
 class CenterHead(nn.Module):
@@ -98,7 +99,7 @@ class CenterHead(nn.Module):
             self.tasks.append(SepHead(share_conv_channel, heads, bn=norm, init_bias=init_bias, final_kernel=3))
 
     def forward(self, x):
-        x = self.shared_conv(x)
+        x = run_sequential(self.shared_conv, x)
         return [task(x) for task in self.tasks]
 
     @staticmethod

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ...operators.batchnorm import run_sequential
 from ..common import get_norm
 
 
@@ -64,7 +65,7 @@ class RPN(nn.Module):
     def forward(self, x):
         outs = []
         for i, block in enumerate(self.blocks):
-            x = block(x)
+            x = run_sequential(block, x)     # norm + ReLU fused on the GPU (operators/batchnorm.py), same modules
             if i >= self._first_up:
-                outs.append(self.deblocks[i - self._first_up](x))
+                outs.append(run_sequential(self.deblocks[i - self._first_up], x))
         return torch.cat(outs, dim=1) if outs else x

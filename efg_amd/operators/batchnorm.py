@@ -66,3 +66,39 @@ def bn_act(x, bn, relu=False, residual=None):
         return torch.relu(y) if relu else y
     return BatchNormActFunction.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                       bn.num_batches_tracked, bn.momentum, bn.eps, relu)
+
+
+def fusable_nhwc(bn, x):
+    """A training-mode BatchNorm2d over a channels-last map: per-channel statistics over N*H*W rows, i.e. the [M, C] row
+    problem the kernels above solve (the dense BEV stacks of CenterPoint: RPN, shared conv, task heads)."""
+    return (os.environ.get("EFG_FUSED_BN", "1") != "0" and type(bn) is torch.nn.BatchNorm2d and bn.training and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 1024
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 2 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def bn_act_nhwc(x, bn, relu=False):
+    """relu?(bn(x)) for a channels-last [B, C, H, W] map, result channels-last: one fused pass each way instead of
+    MIOpen's batch norm + a separate ReLU (and its threshold_backward)."""
+    b, c, h, w = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)   # a view: channels-last memory is [B*H*W, C] row-major
+    y = BatchNormActFunction.apply(rows, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, bn.momentum, bn.eps, relu)
+    return y.view(b, h, w, c).permute(0, 3, 1, 2)
+
+
+def run_sequential(seq, x):
+    """`seq(x)` for an nn.Sequential, with every (BatchNorm2d[, ReLU]) pair that qualifies evaluated by `bn_act_nhwc`.
+    The modules (and so the parameter names and the eval-mode path) are the reference's."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if fusable_nhwc(m, x):
+            relu = i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.ReLU
+            x = bn_act_nhwc(x, m, relu)
+            i += 2 if relu else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

@@ -62,3 +62,44 @@ def test_eval_mode_uses_the_module():
     bn = torch.nn.BatchNorm1d(32).cuda().eval()
     x = torch.randn(100, 32, device="cuda")
     torch.testing.assert_close(bn_act(x, bn, relu=True), torch.relu(bn(x)))
+
+
+def test_channels_last_conv_stack_matches_the_modules():
+    """operators/batchnorm.py `run_sequential`: BatchNorm2d + ReLU over a channels-last map through the row kernels vs the
+    nn.Sequential it stands in for, evaluated in fp64 -- outputs, input / parameter gradients, running statistics.
+    (The fp32 modules themselves are the weaker yardstick here: MIOpen's channels-last batch-norm backward is 3-4e-3
+    off the fp64 gradients on this stack, the row kernels 5e-7.)"""
+    from torch import nn
+
+    from efg_amd.operators.batchnorm import fusable_nhwc, run_sequential
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    seq = nn.Sequential(nn.ZeroPad2d(1), nn.Conv2d(32, 64, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(),
+                        nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                        nn.Conv2d(64, 8, 3, padding=1)).to(dev).to(memory_format=torch.channels_last)
+    ref = copy.deepcopy(seq).double()
+    x = torch.randn(2, 32, 47, 53, device=dev).contiguous(memory_format=torch.channels_last)
+    assert fusable_nhwc(seq[2], seq[1](seq[0](x)))
+    xa, xb = x.clone().requires_grad_(True), x.double().requires_grad_(True)
+    ya, yb = run_sequential(seq, xa), ref(xb)
+    assert ya.is_contiguous(memory_format=torch.channels_last)
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * w.double()).sum().backward()
+
+    def close(a, b, tol):
+        err = float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+        assert err <= tol, err
+
+    close(ya, yb, 2e-6)
+    close(xa.grad, xb.grad, 5e-6)
+    for pa, pb in zip(seq.parameters(), ref.parameters()):
+        close(pa.grad, pb.grad, 5e-6)
+    for (name, ba), bb in zip(seq.named_buffers(), ref.buffers()):
+        if "num_batches" in name:
+            assert int(ba) == int(bb) == 1
+        else:
+            close(ba, bb, 2e-6)
+    seq.eval(), ref.eval()
+    close(run_sequential(seq, x), ref(x.double()), 2e-6)    # eval mode: the modules themselves
