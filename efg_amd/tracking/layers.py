@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..operators import attention
+from ..operators.batchnorm import bn_act
 from ..operators.layernorm import add_layer_norm  # norm(x + r): one fused HIP pass each way on the GPU
 from ..operators.linear import linear  # F.linear; on long GPU matrices: split weight gradient + HIP bias gradient
 
@@ -169,15 +170,15 @@ class PointNetfeat(nn.Module):
         for i in range(4):
             setattr(self, "bn%d" % (i + 1), nn.BatchNorm1d(widths[i + 1]))
 
-    def _stage(self, rows, i):
-        conv = getattr(self, "conv%d" % i)
-        return getattr(self, "bn%d" % i)(F.linear(rows, conv.weight.squeeze(-1), conv.bias))
+    def _stage(self, rows, i, relu):
+        conv = getattr(self, "conv%d" % i)   # norm (+ ReLU) in one fused pass each way on the GPU (operators/batchnorm.py)
+        return bn_act(F.linear(rows, conv.weight.squeeze(-1), conv.bias), getattr(self, "bn%d" % i), relu=relu)
 
     def forward_rows(self, rows, steps):
         """rows [S * steps, C] (sequence-major) -> (pooled [S, out], per-step [S, steps, out])."""
         for i in (1, 2, 3):
-            rows = F.relu(self._stage(rows, i))
-        per_step = self._stage(rows, 4).view(-1, steps, self.output_channel)
+            rows = self._stage(rows, i, True)
+        per_step = self._stage(rows, 4, False).view(-1, steps, self.output_channel)
         return per_step.max(dim=1)[0], per_step
 
     def forward(self, x):
@@ -215,8 +216,8 @@ class PointNet(nn.Module):
         """x [S, C, T] -> (embedding [S, channels], per-step features [S, 512, T])."""
         s, c, t = x.shape
         pooled, per_step = self.feat.forward_rows(self.pre_bn(x.transpose(1, 2).reshape(s * t, c)), t)
-        hidden = F.relu(self.bn1(self.fc1(pooled)))
-        return F.relu(self.bn2(self.fc2(hidden))), per_step.transpose(1, 2)
+        hidden = bn_act(self.fc1(pooled), self.bn1, relu=True)
+        return bn_act(self.fc2(hidden), self.bn2, relu=True), per_step.transpose(1, 2)
 
     def init_weights(self):
         for m in self.modules():
