@@ -408,6 +408,294 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const Operands a, 
     }
 }
 
+// ==== long sequences, 32-wide heads (ConQueR's decoder self-attention: 2 x 8 heads x 1240 queries, bool mask) ============
+// Same S^T trick, blocked over 128 keys with the online softmax: a workgroup owns 64 queries (a wave 16 = one tile) of one
+// (sequence, head) and walks the key blocks; the running max / sum of query c live in the lanes of column c, the O tile has
+// queries on its rows, so the per-block rescale factors move with one __shfl per row.  The boolean attention mask comes
+// bit-packed ([S, ceil(S / 32)] words, bit = 1: not allowed): a lane reads 4 words per 128-key block.
+constexpr int kDL = 32;    // head width
+constexpr int kLdL = 36;   // LDS row stride (floats)
+constexpr int kBlk = 128;  // keys (or queries, in the dK / dV kernel) per LDS block
+
+struct LongOperands {
+  const float* q;
+  const float* k;
+  const float* v;
+  long long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;
+  const unsigned* mask;   // [s, mask_words] or null
+  int mask_words;
+  int s, heads;
+  float scale;
+};
+
+// rows [row0, row0 + 128) of two [s, 32] strided matrices into LDS (zero beyond s); all loads before the first LDS write
+__device__ __forceinline__ void load_block2(float (*dst_a)[kLdL], const float* __restrict__ src_a, long long stride_a,
+                                            float (*dst_b)[kLdL], const float* __restrict__ src_b, long long stride_b, int row0,
+                                            int s) {
+  f32x4 va[4], vb[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = threadIdx.x + 256 * it, row = row0 + (idx >> 3), c4 = idx & 7;
+    va[it] = *reinterpret_cast<const f32x4*>(src_a + min(row, s - 1) * stride_a + 4 * c4);
+    vb[it] = *reinterpret_cast<const f32x4*>(src_b + min(row, s - 1) * stride_b + 4 * c4);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = threadIdx.x + 256 * it, r = idx >> 3, c4 = idx & 7;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(&dst_a[r][4 * c4]) = row0 + r < s ? va[it] : zero;
+    *reinterpret_cast<f32x4*>(&dst_b[r][4 * c4]) = row0 + r < s ? vb[it] : zero;
+  }
+}
+
+// B-operand fragments of 16 rows: frag[t] = src[row0 + (lane & 15)][16 t + 4 j ..] * mul, rows beyond s zero
+__device__ __forceinline__ void load_frag16(f32x4 (&frag)[2], const float* __restrict__ src, int row0, int s, long long stride,
+                                            float mul) {
+  const int lane = threadIdx.x & 63, j = lane >> 4, c = lane & 15;
+  const int row = row0 + c;
+  const float m = row < s ? mul : 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    frag[t] = *reinterpret_cast<const f32x4*>(src + min(row, s - 1) * stride + 16 * t + 4 * j) * m;
+}
+
+__device__ __forceinline__ f32x4 col_frag(const float (*m)[kLdL], int row, int col) {   // rows row .. row + 3 of one column
+  return f32x4{m[row][col], m[row + 1][col], m[row + 2][col], m[row + 3][col]};
+}
+
+__global__ void __launch_bounds__(256) attn_long_fwd_kernel(const LongOperands a, float* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) float Ks[kBlk][kLdL];
+  __shared__ __attribute__((aligned(16))) float Vs[kBlk][kLdL];
+  const int s = a.s, heads = a.heads;
+  const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
+  const int q0 = 64 * blockIdx.x + 16 * wv;
+  const float* kp = a.k + b * a.k_bs + h * kDL;
+  const float* vp = a.v + b * a.v_bs + h * kDL;
+  f32x4 bq[2];
+  load_frag16(bq, a.q + b * a.q_bs + h * kDL, q0, s, a.q_rs, a.scale * kLog2e);
+  const unsigned* mrow = a.mask ? a.mask + (long long)min(q0 + c, s - 1) * a.mask_words : nullptr;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < s; k0 += kBlk) {
+    __syncthreads();
+    load_block2(Ks, kp, a.k_rs, Vs, vp, a.v_rs, k0, s);
+    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    if (mrow) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mw[w] = (k0 >> 5) + w < a.mask_words ? mrow[(k0 >> 5) + w] : 0u;
+    }
+    __syncthreads();
+    f32x4 acc[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        acc[kt] = mfma_k4(*reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]), bq[t], acc[kt]);
+    }
+    float bm = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = 16 * kt + 4 * j + i;
+        const bool dead = k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u);
+        acc[kt][i] = dead ? -INFINITY : acc[kt][i];
+        bm = fmaxf(bm, acc[kt][i]);
+      }
+    const float m_new = fmaxf(m_run, group_max(bm));
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;   // nothing allowed so far: every p below is exp2(-inf) = 0
+    float bs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[kt][i] = exp2f(acc[kt][i] - m_use);
+        bs += acc[kt][i];
+      }
+    const float alpha = exp2f(m_run - m_use);   // m_run = -inf -> 0
+    l_run = l_run * alpha + group_sum(bs);
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ai = __shfl(alpha, 4 * j + i);   // lane 4 j + i holds the factor of query 4 j + i
+      o[0][i] *= ai;
+      o[1][i] *= ai;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      o[0] = mfma_k4(acc[kt], col_frag(Vs, 16 * kt + 4 * j, c), o[0]);
+      o[1] = mfma_k4(acc[kt], col_frag(Vs, 16 * kt + 4 * j, 16 + c), o[1]);
+    }
+  }
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;   // a query with no allowed key: zeros (PyTorch: NaN)
+  if (j == 0 && q0 + c < s) lse[((long long)b * heads + h) * s + q0 + c] = (m_run + log2f(l_run)) * kLn2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float ii = __shfl(inv, 4 * j + i);
+    const int q = q0 + 4 * j + i;
+    if (q < s) {
+      float* dst = out + (((long long)b * s + q) * heads + h) * kDL + c;
+      dst[0] = o[0][i] * ii;
+      dst[16] = o[1][i] * ii;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperands a, const float* __restrict__ out,
+                                                               const float* __restrict__ lse, const float* __restrict__ dout,
+                                                               float* __restrict__ dq_out) {
+  __shared__ __attribute__((aligned(16))) float Ks[kBlk][kLdL];
+  __shared__ __attribute__((aligned(16))) float Vs[kBlk][kLdL];
+  const int s = a.s, heads = a.heads;
+  const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
+  const int q0 = 64 * blockIdx.x + 16 * wv;
+  const long long os = (long long)heads * kDL;
+  const float* kp = a.k + b * a.k_bs + h * kDL;
+  const float* vp = a.v + b * a.v_bs + h * kDL;
+  f32x4 bq[2], bdo[2], bo[2];
+  load_frag16(bq, a.q + b * a.q_bs + h * kDL, q0, s, a.q_rs, a.scale * kLog2e);
+  load_frag16(bdo, dout + (long long)b * s * os + h * kDL, q0, s, os, 1.f);
+  load_frag16(bo, out + (long long)b * s * os + h * kDL, q0, s, os, 1.f);
+  float part = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x4 pr = bo[t] * bdo[t];
+    part += pr.x + pr.y + pr.z + pr.w;
+  }
+  const float delta = group_sum(part);
+  const float l2 = q0 + c < s ? lse[((long long)b * heads + h) * s + q0 + c] * kLog2e : 0.f;
+  const unsigned* mrow = a.mask ? a.mask + (long long)min(q0 + c, s - 1) * a.mask_words : nullptr;
+  f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < s; k0 += kBlk) {
+    __syncthreads();
+    load_block2(Ks, kp, a.k_rs, Vs, vp, a.v_rs, k0, s);
+    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    if (mrow) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mw[w] = (k0 >> 5) + w < a.mask_words ? mrow[(k0 >> 5) + w] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sv = mfma_k4(*reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]), bq[t], sv);
+        dp = mfma_k4(*reinterpret_cast<const f32x4*>(&Vs[16 * kt + c][16 * t + 4 * j]), bdo[t], dp);
+      }
+      f32x4 ds;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = 16 * kt + 4 * j + i;
+        const bool dead = k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u);
+        const float p = dead ? 0.f : exp2f(sv[i] - l2);
+        ds[i] = p * (dp[i] - delta);
+      }
+      dq[0] = mfma_k4(ds, col_frag(Ks, 16 * kt + 4 * j, c), dq[0]);
+      dq[1] = mfma_k4(ds, col_frag(Ks, 16 * kt + 4 * j, 16 + c), dq[1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + 4 * j + i;
+    if (q < s) {
+      float* dst = dq_out + b * a.q_bs + q * a.q_rs + h * kDL + c;
+      dst[0] = dq[0][i] * a.scale;
+      dst[16] = dq[1][i] * a.scale;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_long_bwd_dkv_kernel(const LongOperands a, const float* __restrict__ out,
+                                                                const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                float* __restrict__ dk_out, float* __restrict__ dv_out) {
+  __shared__ __attribute__((aligned(16))) float Qs[kBlk][kLdL];
+  __shared__ __attribute__((aligned(16))) float dOs[kBlk][kLdL];
+  __shared__ float l2s[kBlk], dls[kBlk];
+  __shared__ unsigned msk[4][kBlk];
+  const int s = a.s, heads = a.heads;
+  const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane >> 4, c = lane & 15;
+  const int k0 = 64 * blockIdx.x + 16 * wv;       // this wave's 16 keys: inside one mask word
+  const long long os = (long long)heads * kDL;
+  const float* qp = a.q + b * a.q_bs + h * kDL;
+  const float* dob = dout + (long long)b * s * os + h * kDL;
+  const float* ob = out + (long long)b * s * os + h * kDL;
+  f32x4 bk[2], bv[2];
+  load_frag16(bk, a.k + b * a.k_bs + h * kDL, k0, s, a.k_rs, a.scale * kLog2e);
+  load_frag16(bv, a.v + b * a.v_bs + h * kDL, k0, s, a.v_rs, 1.f);
+  const int kbit = (k0 & 31) + c;                 // bit of key k0 + c in its word
+  f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  for (int r0 = 0; r0 < s; r0 += kBlk) {
+    __syncthreads();
+    load_block2(Qs, qp, a.q_rs, dOs, dob, os, r0, s);
+    {   // per query of the block: delta = <dO, O>, log-sum-exp, and each wave's mask word
+      const int r = threadIdx.x >> 1, half = threadIdx.x & 1, q = r0 + r;
+      float part = 0.f;
+      if (q < s) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(dob + q * os + 16 * half + 4 * u);
+          const f32x4 y = *reinterpret_cast<const f32x4*>(ob + q * os + 16 * half + 4 * u);
+          const f32x4 pr = x * y;
+          part += pr.x + pr.y + pr.z + pr.w;
+        }
+      }
+      part += __shfl_xor(part, 1);
+      if (half == 0) {
+        dls[r] = part;
+        l2s[r] = q < s ? lse[((long long)b * heads + h) * s + q] * kLog2e : 1e30f;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rr = lane + 64 * u, qq = r0 + rr;
+        msk[wv][rr] = (a.mask && qq < s && k0 < s) ? a.mask[(long long)qq * a.mask_words + (k0 >> 5)] : 0u;
+      }
+    }
+    __syncthreads();
+    if (k0 < s) {
+#pragma unroll 2
+      for (int qt = 0; qt < 8; ++qt) {
+        if (r0 + 16 * qt >= s) break;
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          sv = mfma_k4(*reinterpret_cast<const f32x4*>(&Qs[16 * qt + c][16 * t + 4 * j]), bk[t], sv);
+          dp = mfma_k4(*reinterpret_cast<const f32x4*>(&dOs[16 * qt + c][16 * t + 4 * j]), bv[t], dp);
+        }
+        f32x4 p, ds;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 16 * qt + 4 * j + i;
+          const bool dead = (msk[wv][r] >> kbit) & 1u;
+          p[i] = dead ? 0.f : exp2f(sv[i] - l2s[r]);
+          ds[i] = p[i] * (dp[i] - dls[r]);
+        }
+        dv[0] = mfma_k4(p, col_frag(dOs, 16 * qt + 4 * j, c), dv[0]);
+        dv[1] = mfma_k4(p, col_frag(dOs, 16 * qt + 4 * j, 16 + c), dv[1]);
+        dk[0] = mfma_k4(ds, col_frag(Qs, 16 * qt + 4 * j, c), dk[0]);
+        dk[1] = mfma_k4(ds, col_frag(Qs, 16 * qt + 4 * j, 16 + c), dk[1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int key = k0 + 4 * j + i;
+    if (key < s) {
+      float* kd = dk_out + b * a.k_bs + key * a.k_rs + h * kDL + c;
+      float* vd = dv_out + b * a.v_bs + key * a.v_rs + h * kDL + c;
+      kd[0] = dk[0][i] * a.scale;
+      kd[16] = dk[1][i] * a.scale;
+      vd[0] = dv[0][i];
+      vd[16] = dv[1][i];
+    }
+  }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -460,6 +748,56 @@ extern "C" int efg_attention_bwd_f32(const float* q, int64_t q_batch_stride, int
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, a, out, lse, dout, dq);
   EFG_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(batch * heads)), dim3(256), 0, stream, a, out, lse, dout, dk, dv);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+// ---- long sequences (any s >= 1), 32-wide heads, optional boolean mask ---------------------------------------------------------
+// q / k / v element (b, row, h, d) at ptr + b * batch_stride + row * row_stride + h * 32 + d (strides in floats, multiples of 4).
+// mask_bits: u32 [s, mask_words], bit (key & 31) of word key >> 5 of row `query` set = that key is NOT attended (torch's boolean
+// attn_mask), null = no mask; the same mask for every sequence and head.  out [batch, s, heads, 32], lse [batch, heads, s].
+static int check_long(const char* who, const float* q, const float* k, const float* v, const int64_t* st, int64_t batch, int s,
+                      int heads, const uint32_t* mask_bits, int mask_words) {
+  EFG_CHECK_ARG(batch >= 0 && heads >= 1 && s >= 1, "%s: bad sizes", who);
+  EFG_CHECK_ARG(batch * heads < 65536, "%s: batch x heads must be < 65536", who);
+  if (batch == 0) return EFG_OK;
+  EFG_CHECK_ARG(q && k && v && aligned16(q) && aligned16(k) && aligned16(v), "%s: null or unaligned operand", who);
+  for (int i = 0; i < 6; ++i) EFG_CHECK_ARG(st[i] % 4 == 0, "%s: strides must be multiples of 4 floats", who);
+  EFG_CHECK_ARG(!mask_bits || mask_words >= (s + 31) / 32, "%s: mask rows need ceil(s / 32) words", who);
+  return EFG_OK;
+}
+
+extern "C" int efg_attention_long_fwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k,
+                                          int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
+                                          int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, int64_t batch, int s,
+                                          int heads, float scale, float* out, float* lse, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t st[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
+  const int rc = check_long("attention_long_fwd", q, k, v, st, batch, s, heads, mask_bits, mask_words);
+  if (rc != EFG_OK || batch == 0) return rc;
+  EFG_CHECK_ARG(out && lse, "attention_long_fwd: null output");
+  const LongOperands a{q, k, v, st[0], st[1], st[2], st[3], st[4], st[5], mask_bits, mask_words, s, heads, scale};
+  hipLaunchKernelGGL(attn_long_fwd_kernel, dim3((unsigned)((s + 63) / 64), (unsigned)(batch * heads)), dim3(256), 0, stream, a, out,
+                     lse);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_attention_long_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k,
+                                          int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
+                                          int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, const float* out,
+                                          const float* lse, const float* dout, int64_t batch, int s, int heads, float scale,
+                                          float* dq, float* dk, float* dv, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t st[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
+  const int rc = check_long("attention_long_bwd", q, k, v, st, batch, s, heads, mask_bits, mask_words);
+  if (rc != EFG_OK || batch == 0) return rc;
+  EFG_CHECK_ARG(out && lse && dout && dq && dk && dv && aligned16(out) && aligned16(dout), "attention_long_bwd: null or unaligned pointer");
+  const LongOperands a{q, k, v, st[0], st[1], st[2], st[3], st[4], st[5], mask_bits, mask_words, s, heads, scale};
+  const dim3 grid((unsigned)((s + 63) / 64), (unsigned)(batch * heads));
+  hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, dim3(256), 0, stream, a, out, lse, dout, dq);
+  EFG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, dim3(256), 0, stream, a, out, lse, dout, dk, dv);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

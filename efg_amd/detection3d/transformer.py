@@ -10,6 +10,7 @@ from torch import nn
 from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
+from ..operators import attention
 from ..operators.layernorm import add_layer_norm
 from ..operators.linear import Linear, linear
 from .box_attention import Box3dAttention
@@ -79,17 +80,31 @@ class TransformerDecoderLayer(nn.Module):
         assert activation == "relu"
         self.activation = F.relu
 
-    def forward(self, idx, query, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask=None):
-        if idx == 0:
-            query = self.pos_embed_layer(ref_windows)
-            q = k = query
-        elif query_pos is None:
-            query_pos = self.pos_embed_layer(ref_windows)
-            q = k = _with_pos(query, query_pos)
-        q, k, v = q.transpose(0, 1), k.transpose(0, 1), query.transpose(0, 1)
+    def _self_attention(self, qk_in, v_in, attn_mask, attn_bits):
+        """self_attn(q = k = qk_in, v = v_in) of the nn.MultiheadAttention module, batch first."""
+        mha = self.self_attn
+        c, h = mha.embed_dim, mha.num_heads
+        if (attention.fused_long(v_in, h) and (attn_mask is None or attn_bits is not None) and mha.dropout == 0.0
+                and mha.in_proj_weight is not None):
+            # csrc/attention.hip (long / 32-wide-head kernels): q | k from ONE projection of the shared input, the boolean
+            # mask as bit rows, one gradient tensor for that projection
+            qk = F.linear(qk_in, mha.in_proj_weight[:2 * c], mha.in_proj_bias[:2 * c])
+            v = F.linear(v_in, mha.in_proj_weight[2 * c:], mha.in_proj_bias[2 * c:])
+            return F.linear(attention.long_self_attention(qk, v, attn_bits, h), mha.out_proj.weight, mha.out_proj.bias)
+        q, v = qk_in.transpose(0, 1), v_in.transpose(0, 1)
         # need_weights=False: same output, skips materialising the head-averaged attention map the reference
         # computes and discards ($CQ/transformer.py:295)
-        query2 = self.self_attn(q, k, v, attn_mask=attn_mask, need_weights=False)[0].transpose(0, 1)
+        return mha(q, q, v, attn_mask=attn_mask, need_weights=False)[0].transpose(0, 1)
+
+    def forward(self, idx, query, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask=None,
+                attn_bits=None):
+        if idx == 0:
+            query = self.pos_embed_layer(ref_windows)
+            qk_in = query
+        elif query_pos is None:
+            query_pos = self.pos_embed_layer(ref_windows)
+            qk_in = _with_pos(query, query_pos)
+        query2 = self._self_attention(qk_in, query, attn_mask, attn_bits)
         query = add_layer_norm(query, self.dropout1(query2), self.norm1)
         query2 = self.multihead_attn(_with_pos(query, query_pos), memory, memory_shape, None, memory_start_idx, None,
                                      ref_windows[..., :7])[0]
@@ -108,8 +123,13 @@ class TransformerDecoder(nn.Module):
     def forward(self, query, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask=None):
         output = query
         intermediate, intermediate_ref_windows = [], []
+        attn_bits = None   # the boolean mask as bit rows, packed once for all layers (operators/attention.py)
+        if (attn_mask is not None and attn_mask.is_cuda and attn_mask.dtype == torch.bool and attn_mask.dim() == 2
+                and attn_mask.shape[0] == attn_mask.shape[1] and os.environ.get("EFG_ATTENTION", "1") != "0"):
+            attn_bits = attention.pack_mask(attn_mask)
         for idx, layer in enumerate(self.layers):
-            output = layer(idx, output, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask)
+            output = layer(idx, output, query_pos, memory, memory_shape, memory_start_idx, ref_windows, attn_mask,
+                           attn_bits)
             new_ref_logits, new_ref_windows = self.detection_head(output, ref_windows[..., :7], idx)
             ref_windows = torch.cat((new_ref_windows.detach(), new_ref_logits.sigmoid().detach()), dim=-1)
             intermediate.append(output)

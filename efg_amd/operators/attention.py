@@ -109,3 +109,67 @@ def cross_attention_kv(q, kv, heads):
     if fused_cross(q, kv, heads):
         return _CrossAttention.apply(q, kv, heads)
     return _sdpa(q, *kv.chunk(2, dim=-1), heads)
+
+
+# ---- long sequences, 32-wide heads, boolean mask (the decoder's self-attention in ConQueR / Voxel-DETR) ------------------------
+LONG_HEAD_DIM = 32
+
+
+def pack_mask(attn_mask):
+    """bool [S, S] (True = not attended) -> int32 [S, ceil(S / 32)] bit rows for the kernels; None -> None."""
+    if attn_mask is None:
+        return None
+    s = attn_mask.shape[-1]
+    words = (s + 31) // 32
+    m = torch.zeros(attn_mask.shape[0], words * 32, dtype=torch.int64, device=attn_mask.device)
+    m[:, :s] = attn_mask.to(torch.int64)
+    shifts = torch.arange(32, device=attn_mask.device, dtype=torch.int64)
+    packed = (m.view(-1, words, 32) << shifts).sum(-1)          # < 2^32
+    return torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+
+
+class _LongSelfAttention(Function):
+    """qk [B, S, 2C] (q | k of one fused projection), v [B, S, C], mask bits -> [B, S, C]."""
+
+    @staticmethod
+    def _strides(qk, v):
+        b, s, c2 = qk.shape
+        c = c2 // 2
+        return (qk.data_ptr(), s * c2, c2, qk.data_ptr() + 4 * c, s * c2, c2, v.data_ptr(), s * c, c)
+
+    @staticmethod
+    def forward(ctx, qk, v, mask_bits, heads):
+        qk, v = qk.contiguous(), v.contiguous()
+        b, s, c = v.shape
+        out = torch.empty(b, s, c, dtype=torch.float32, device=v.device)
+        lse = torch.empty(b, heads, s, dtype=torch.float32, device=v.device)
+        scale = 1.0 / math.sqrt(LONG_HEAD_DIM)
+        L.check(L.lib().efg_attention_long_fwd_f32(*_LongSelfAttention._strides(qk, v), L.ptr(mask_bits),
+                                                   0 if mask_bits is None else mask_bits.shape[1], b, s, heads, scale,
+                                                   L.ptr(out), L.ptr(lse), L.stream()))
+        ctx.save_for_backward(qk, v, out, lse, mask_bits)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        qk, v, out, lse, mask_bits = ctx.saved_tensors
+        b, s, c = v.shape
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        scale = 1.0 / math.sqrt(LONG_HEAD_DIM)
+        L.check(L.lib().efg_attention_long_bwd_f32(*_LongSelfAttention._strides(qk, v), L.ptr(mask_bits),
+                                                   0 if mask_bits is None else mask_bits.shape[1], L.ptr(out), L.ptr(lse),
+                                                   L.ptr(grad.contiguous()), b, s, ctx.heads, scale, dqk.data_ptr(),
+                                                   dqk.data_ptr() + 4 * c, dv.data_ptr(), L.stream()))
+        return dqk, dv, None, None
+
+
+def fused_long(x, heads):
+    """x: the [B, S, C] input of the attention (batch first)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == heads * LONG_HEAD_DIM
+            and x.shape[0] * heads < 65536 and x.shape[0] > 0 and x.shape[1] > 0
+            and os.environ.get("EFG_ATTENTION", "1") != "0")
+
+
+def long_self_attention(qk, v, mask_bits, heads):
+    return _LongSelfAttention.apply(qk, v, mask_bits, heads)

@@ -314,6 +314,23 @@ int efg_attention_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_
                           const float* dout, int64_t batch, int seq_q, int seq_k, int heads, float scale, float* dq, float* dk,
                           float* dv, void* stream);
 
+/* The same for sequences of any length with 32-wide heads and an optional boolean mask, blocked over 128 keys with the
+ * online softmax (csrc/attention.hip, second half).  Replaces the core of the decoder's nn.MultiheadAttention self-attention
+ * in ConQueR / Voxel-DETR (projects/ConQueR/.../transformer.py:258-317: 1000 queries + denoising groups, 8 heads of 32, bool
+ * attn_mask).  q / k / v each with their own (batch, row) strides in floats; mask_bits u32 [s, mask_words]: bit (key & 31) of
+ * word (key >> 5) in row `query` set = that key is NOT attended (torch's boolean attn_mask, shared by all sequences and
+ * heads), NULL = no mask.  A query whose keys are all masked yields zeros (PyTorch: NaN).
+ * out f32 [batch, s, heads, 32], lse f32 [batch, heads, s]; backward: dq / dk / dv addressed like q / k / v. */
+int efg_attention_long_fwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k,
+                               int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
+                               int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, int64_t batch, int s, int heads,
+                               float scale, float* out, float* lse, void* stream);
+int efg_attention_long_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q_row_stride, const float* k,
+                               int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
+                               int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, const float* out,
+                               const float* lse, const float* dout, int64_t batch, int s, int heads, float scale, float* dq,
+                               float* dk, float* dv, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the
  * device->host transfer + scipy.optimize.linear_sum_assignment(C[b]) of $CQ/modules/matcher.py:86-91.

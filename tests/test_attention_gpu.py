@@ -135,3 +135,92 @@ def test_bad_arguments_are_reported():
     with pytest.raises(RuntimeError, match="strides"):
         L.check(L.lib().efg_attention_fwd_f32(L.ptr(qkv), 64 * 190, 190, qkv.data_ptr() + 256, qkv.data_ptr() + 512, 64 * 190,
                                               190, 1, 64, 64, 1, 0.125, L.ptr(out), L.ptr(lse), L.stream()))
+
+
+def _long_reference(qk, v, mask, heads, dtype):
+    qk_, v_ = qk.detach().to(dtype).requires_grad_(True), v.detach().to(dtype).requires_grad_(True)
+    b, s, c = v_.shape
+    q, k = qk_.chunk(2, -1)
+
+    def split(t):
+        return t.reshape(b, s, heads, 32).transpose(1, 2)
+
+    logits = split(q) @ split(k).transpose(-1, -2) / math.sqrt(32)
+    if mask is not None:
+        logits = logits.masked_fill(mask, float("-inf"))
+    out = (torch.softmax(logits, -1) @ split(v_)).transpose(1, 2).reshape(b, s, c)
+    return qk_, v_, out, torch.logsumexp(logits, -1)
+
+
+@pytest.mark.parametrize("batch,seq,heads,masked", [(2, 1240, 8, True), (2, 1000, 8, False), (3, 129, 2, True), (1, 64, 1, True),
+                                                    (2, 5, 4, False), (1, 333, 3, True)])
+def test_long_attention_matches_fp64(batch, seq, heads, masked):
+    from efg_amd.operators.attention import long_self_attention, pack_mask
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(seq * 10 + heads)
+    c = heads * 32
+    qk = (torch.randn(batch, seq, 2 * c, generator=g) * 1.4).to(dev).requires_grad_(True)
+    v = torch.randn(batch, seq, c, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(batch, seq, c, generator=g).to(dev)
+    mask = None
+    if masked:   # denoising-style: blocks that only see themselves + random holes, every query keeps itself
+        grp = torch.randint(0, 4, (seq,), generator=g)
+        mask = (grp[:, None] != grp[None, :]) | (torch.rand(seq, seq, generator=g) < 0.1)
+        mask[torch.arange(seq), torch.arange(seq)] = False
+        mask = mask.to(dev)
+    bits = pack_mask(mask)
+    out = long_self_attention(qk, v, bits, heads)
+    (out * w).sum().backward()
+    qk64, v64, out64, lse64 = _long_reference(qk, v, mask, heads, torch.float64)
+    (out64 * w.double()).sum().backward()
+    qk32, v32, out32, _ = _long_reference(qk, v, mask, heads, torch.float32)
+    (out32 * w).sum().backward()
+
+    def err(a, ref):
+        return float((a.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+    assert err(out, out64) <= max(4 * err(out32, out64), 2e-6), (err(out, out64), err(out32, out64))
+    assert err(qk.grad, qk64.grad) <= max(4 * err(qk32.grad, qk64.grad), 5e-6), (err(qk.grad, qk64.grad), err(qk32.grad, qk64.grad))
+    assert err(v.grad, v64.grad) <= max(4 * err(v32.grad, v64.grad), 5e-6)
+
+
+def test_pack_mask_bits():
+    from efg_amd.operators.attention import pack_mask
+
+    g = torch.Generator().manual_seed(3)
+    m = torch.rand(70, 70, generator=g) < 0.5
+    bits = pack_mask(m.cuda()).cpu()
+    assert bits.shape == (70, 3) and bits.dtype == torch.int32
+    for q in (0, 13, 69):
+        for k in (0, 31, 32, 63, 64, 69):
+            assert bool((int(bits[q, k // 32]) >> (k % 32)) & 1) == bool(m[q, k])
+
+
+def test_decoder_layer_self_attention_matches_the_module():
+    """TransformerDecoderLayer._self_attention: kernel path vs the nn.MultiheadAttention call it replaces."""
+    import os
+
+    from efg_amd.detection3d.transformer import TransformerDecoderLayer
+    from efg_amd.operators.attention import pack_mask
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layer = TransformerDecoderLayer(256, 8, 1, 1024, 0.0).to(dev)
+    x, pos = torch.randn(2, 1100, 256, device=dev), torch.randn(2, 1100, 256, device=dev)
+    grp = torch.randint(0, 3, (1100,), device=dev)
+    mask = grp[:, None] != grp[None, :]
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["EFG_ATTENTION"] = mode
+        try:
+            layer.zero_grad()
+            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+            y = layer._self_attention(xi + pi, xi, mask, pack_mask(mask) if mode == "1" else None)
+            y.square().sum().backward()
+            res[mode] = (y.detach(), xi.grad, pi.grad, layer.self_attn.in_proj_weight.grad.clone(),
+                         layer.self_attn.in_proj_bias.grad.clone(), layer.self_attn.out_proj.weight.grad.clone())
+        finally:
+            os.environ.pop("EFG_ATTENTION", None)
+    for a, b in zip(res["1"], res["0"]):
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max())
