@@ -428,23 +428,28 @@ struct LongOperands {
   float scale;
 };
 
-// rows [row0, row0 + 128) of two [s, 32] strided matrices into LDS (zero beyond s); all loads before the first LDS write
-__device__ __forceinline__ void load_block2(float (*dst_a)[kLdL], const float* __restrict__ src_a, long long stride_a,
-                                            float (*dst_b)[kLdL], const float* __restrict__ src_b, long long stride_b, int row0,
-                                            int s) {
-  f32x4 va[4], vb[4];
+// rows [row0, row0 + 128) of two [s, 32] strided matrices: global -> registers (`fetch`, clamped rows) and registers -> LDS
+// (`store`, zero beyond s).  The kernels fetch block n + 1 right after storing block n, so the global latency runs under
+// block n's MFMAs: at ConQueR's shape there are only ~1.25 workgroups per CU and nothing else would hide it.
+struct BlockRegs {
+  f32x4 a[4], b[4];
+};
+__device__ __forceinline__ void fetch_block2(BlockRegs& r, const float* __restrict__ src_a, long long stride_a,
+                                             const float* __restrict__ src_b, long long stride_b, int row0, int s) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int idx = threadIdx.x + 256 * it, row = row0 + (idx >> 3), c4 = idx & 7;
-    va[it] = *reinterpret_cast<const f32x4*>(src_a + min(row, s - 1) * stride_a + 4 * c4);
-    vb[it] = *reinterpret_cast<const f32x4*>(src_b + min(row, s - 1) * stride_b + 4 * c4);
+    const int idx = threadIdx.x + 256 * it, row = min(row0 + (idx >> 3), s - 1), c4 = idx & 7;
+    r.a[it] = *reinterpret_cast<const f32x4*>(src_a + row * stride_a + 4 * c4);
+    r.b[it] = *reinterpret_cast<const f32x4*>(src_b + row * stride_b + 4 * c4);
   }
+}
+__device__ __forceinline__ void store_block2(float (*dst_a)[kLdL], float (*dst_b)[kLdL], const BlockRegs& r, int row0, int s) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int idx = threadIdx.x + 256 * it, r = idx >> 3, c4 = idx & 7;
+    const int idx = threadIdx.x + 256 * it, rr = idx >> 3, c4 = idx & 7;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(&dst_a[r][4 * c4]) = row0 + r < s ? va[it] : zero;
-    *reinterpret_cast<f32x4*>(&dst_b[r][4 * c4]) = row0 + r < s ? vb[it] : zero;
+    *reinterpret_cast<f32x4*>(&dst_a[rr][4 * c4]) = row0 + rr < s ? r.a[it] : zero;
+    *reinterpret_cast<f32x4*>(&dst_b[rr][4 * c4]) = row0 + rr < s ? r.b[it] : zero;
   }
 }
 
@@ -477,14 +482,23 @@ __global__ void __launch_bounds__(256) attn_long_fwd_kernel(const LongOperands a
   const unsigned* mrow = a.mask ? a.mask + (long long)min(q0 + c, s - 1) * a.mask_words : nullptr;
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 0; k0 < s; k0 += kBlk) {
-    __syncthreads();
-    load_block2(Ks, kp, a.k_rs, Vs, vp, a.v_rs, k0, s);
-    unsigned mw[4] = {0u, 0u, 0u, 0u};
+  BlockRegs nxt;
+  unsigned mw_nxt[4] = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int k0) {
+    fetch_block2(nxt, kp, a.k_rs, vp, a.v_rs, k0, s);
     if (mrow) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) mw[w] = (k0 >> 5) + w < a.mask_words ? mrow[(k0 >> 5) + w] : 0u;
+      for (int w = 0; w < 4; ++w) mw_nxt[w] = mrow[min((k0 >> 5) + w, a.mask_words - 1)];   // (words past the row: keys >= s)
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < s; k0 += kBlk) {
+    __syncthreads();
+    store_block2(Ks, Vs, nxt, k0, s);
+    unsigned mw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mw[w] = mw_nxt[w];
+    if (k0 + kBlk < s) fetch(k0 + kBlk);
     __syncthreads();
     f32x4 acc[8];
 #pragma unroll
@@ -545,7 +559,7 @@ __global__ void __launch_bounds__(256) attn_long_fwd_kernel(const LongOperands a
 
 __global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperands a, const float* __restrict__ out,
                                                                const float* __restrict__ lse, const float* __restrict__ dout,
-                                                               float* __restrict__ dq_out) {
+                                                               float* __restrict__ dq_out, float* __restrict__ delta_ws) {
   __shared__ __attribute__((aligned(16))) float Ks[kBlk][kLdL];
   __shared__ __attribute__((aligned(16))) float Vs[kBlk][kLdL];
   const int s = a.s, heads = a.heads;
@@ -569,14 +583,24 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperand
   const float l2 = q0 + c < s ? lse[((long long)b * heads + h) * s + q0 + c] * kLog2e : 0.f;
   const unsigned* mrow = a.mask ? a.mask + (long long)min(q0 + c, s - 1) * a.mask_words : nullptr;
   f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 0; k0 < s; k0 += kBlk) {
-    __syncthreads();
-    load_block2(Ks, kp, a.k_rs, Vs, vp, a.v_rs, k0, s);
-    unsigned mw[4] = {0u, 0u, 0u, 0u};
+  if (j == 0 && q0 + c < s) delta_ws[((long long)b * heads + h) * s + q0 + c] = delta;   // for the dK / dV kernel
+  BlockRegs nxt;
+  unsigned mw_nxt[4] = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int k0) {
+    fetch_block2(nxt, kp, a.k_rs, vp, a.v_rs, k0, s);
     if (mrow) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) mw[w] = (k0 >> 5) + w < a.mask_words ? mrow[(k0 >> 5) + w] : 0u;
+      for (int w = 0; w < 4; ++w) mw_nxt[w] = mrow[min((k0 >> 5) + w, a.mask_words - 1)];
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < s; k0 += kBlk) {
+    __syncthreads();
+    store_block2(Ks, Vs, nxt, k0, s);
+    unsigned mw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mw[w] = mw_nxt[w];
+    if (k0 + kBlk < s) fetch(k0 + kBlk);
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -609,7 +633,7 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperand
   }
 }
 
-__global__ void __launch_bounds__(256) attn_long_bwd_dkv_kernel(const LongOperands a, const float* __restrict__ out,
+__global__ void __launch_bounds__(256) attn_long_bwd_dkv_kernel(const LongOperands a, const float* __restrict__ delta_ws,
                                                                 const float* __restrict__ lse, const float* __restrict__ dout,
                                                                 float* __restrict__ dk_out, float* __restrict__ dv_out) {
   __shared__ __attribute__((aligned(16))) float Qs[kBlk][kLdL];
@@ -623,39 +647,41 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dkv_kernel(const LongOperan
   const long long os = (long long)heads * kDL;
   const float* qp = a.q + b * a.q_bs + h * kDL;
   const float* dob = dout + (long long)b * s * os + h * kDL;
-  const float* ob = out + (long long)b * s * os + h * kDL;
   f32x4 bk[2], bv[2];
   load_frag16(bk, a.k + b * a.k_bs + h * kDL, k0, s, a.k_rs, a.scale * kLog2e);
   load_frag16(bv, a.v + b * a.v_bs + h * kDL, k0, s, a.v_rs, 1.f);
   const int kbit = (k0 & 31) + c;                 // bit of key k0 + c in its word
   f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  BlockRegs nxt;
+  float nl = 0.f, nd = 0.f;      // threads 0..127: log-sum-exp and delta of query r0 + threadIdx.x
+  unsigned nm[2] = {0u, 0u};     // this wave's mask word of queries r0 + lane, r0 + lane + 64
+  const long long stat0 = ((long long)b * heads + h) * s;
+  auto fetch = [&](int r0) {
+    fetch_block2(nxt, qp, a.q_rs, dob, os, r0, s);
+    if (threadIdx.x < kBlk) {
+      const int q = min(r0 + (int)threadIdx.x, s - 1);
+      nl = lse[stat0 + q];
+      nd = delta_ws[stat0 + q];
+    }
+    if (a.mask) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        nm[u] = a.mask[(long long)min(r0 + lane + 64 * u, s - 1) * a.mask_words + (min(k0, s - 1) >> 5)];
+    }
+  };
+  fetch(0);
   for (int r0 = 0; r0 < s; r0 += kBlk) {
     __syncthreads();
-    load_block2(Qs, qp, a.q_rs, dOs, dob, os, r0, s);
-    {   // per query of the block: delta = <dO, O>, log-sum-exp, and each wave's mask word
-      const int r = threadIdx.x >> 1, half = threadIdx.x & 1, q = r0 + r;
-      float part = 0.f;
-      if (q < s) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(dob + q * os + 16 * half + 4 * u);
-          const f32x4 y = *reinterpret_cast<const f32x4*>(ob + q * os + 16 * half + 4 * u);
-          const f32x4 pr = x * y;
-          part += pr.x + pr.y + pr.z + pr.w;
-        }
-      }
-      part += __shfl_xor(part, 1);
-      if (half == 0) {
-        dls[r] = part;
-        l2s[r] = q < s ? lse[((long long)b * heads + h) * s + q] * kLog2e : 1e30f;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rr = lane + 64 * u, qq = r0 + rr;
-        msk[wv][rr] = (a.mask && qq < s && k0 < s) ? a.mask[(long long)qq * a.mask_words + (k0 >> 5)] : 0u;
-      }
+    store_block2(Qs, dOs, nxt, r0, s);
+    if (threadIdx.x < kBlk) {
+      const bool live = r0 + (int)threadIdx.x < s;
+      l2s[threadIdx.x] = live ? nl * kLog2e : 1e30f;   // beyond the sequence: p = 0
+      dls[threadIdx.x] = live ? nd : 0.f;
     }
+    msk[wv][lane] = nm[0];
+    msk[wv][lane + 64] = nm[1];
+    if (r0 + kBlk < s) fetch(r0 + kBlk);
     __syncthreads();
     if (k0 < s) {
 #pragma unroll 2
@@ -787,17 +813,18 @@ extern "C" int efg_attention_long_bwd_f32(const float* q, int64_t q_batch_stride
                                           int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
                                           int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, const float* out,
                                           const float* lse, const float* dout, int64_t batch, int s, int heads, float scale,
-                                          float* dq, float* dk, float* dv, void* stream_) {
+                                          float* dq, float* dk, float* dv, float* delta_ws, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t st[6] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride, v_batch_stride, v_row_stride};
   const int rc = check_long("attention_long_bwd", q, k, v, st, batch, s, heads, mask_bits, mask_words);
   if (rc != EFG_OK || batch == 0) return rc;
-  EFG_CHECK_ARG(out && lse && dout && dq && dk && dv && aligned16(out) && aligned16(dout), "attention_long_bwd: null or unaligned pointer");
+  EFG_CHECK_ARG(out && lse && dout && dq && dk && dv && delta_ws && aligned16(out) && aligned16(dout),
+                "attention_long_bwd: null or unaligned pointer");
   const LongOperands a{q, k, v, st[0], st[1], st[2], st[3], st[4], st[5], mask_bits, mask_words, s, heads, scale};
   const dim3 grid((unsigned)((s + 63) / 64), (unsigned)(batch * heads));
-  hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, dim3(256), 0, stream, a, out, lse, dout, dq);
+  hipLaunchKernelGGL(attn_long_bwd_dq_kernel, grid, dim3(256), 0, stream, a, out, lse, dout, dq, delta_ws);
   EFG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, dim3(256), 0, stream, a, out, lse, dout, dk, dv);
+  hipLaunchKernelGGL(attn_long_bwd_dkv_kernel, grid, dim3(256), 0, stream, a, (const float*)delta_ws, lse, dout, dk, dv);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

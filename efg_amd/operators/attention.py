@@ -160,7 +160,8 @@ class _LongSelfAttention(Function):
         L.check(L.lib().efg_attention_long_bwd_f32(*_LongSelfAttention._strides(qk, v), L.ptr(mask_bits),
                                                    0 if mask_bits is None else mask_bits.shape[1], L.ptr(out), L.ptr(lse),
                                                    L.ptr(grad.contiguous()), b, s, ctx.heads, scale, dqk.data_ptr(),
-                                                   dqk.data_ptr() + 4 * c, dv.data_ptr(), L.stream()))
+                                                   dqk.data_ptr() + 4 * c, dv.data_ptr(), L.ptr(torch.empty_like(lse)),
+                                                   L.stream()))
         return dqk, dv, None, None
 
 

@@ -329,7 +329,7 @@ int efg_attention_long_bwd_f32(const float* q, int64_t q_batch_stride, int64_t q
                                int64_t k_batch_stride, int64_t k_row_stride, const float* v, int64_t v_batch_stride,
                                int64_t v_row_stride, const uint32_t* mask_bits, int mask_words, const float* out,
                                const float* lse, const float* dout, int64_t batch, int s, int heads, float scale, float* dq,
-                               float* dk, float* dv, void* stream);
+                               float* dk, float* dv, float* delta_ws /* scratch f32 [batch, heads, s] */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Linear sum assignment on the device (SURVEY.md section 8(f) "GPU matcher").  Replaces the
