@@ -227,7 +227,8 @@ class Transformer(nn.Module):
                         self.decoder_gt(None, None, static[0], static[1], static[2], static[3], static[4])
                 cur.wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: a DeviceLoader thread (data/loader.py) may allocate / launch on its own stream meanwhile
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = self.decoder_gt(None, None, static[0], static[1], static[2], static[3], static[4])
             except Exception as exc:  # noqa: BLE001 -- any capture problem: run eagerly from now on, say so once
                 if os.environ.get("EFG_GT_GRAPH_STRICT", "0") == "1":  # tests: a failed capture is a failure

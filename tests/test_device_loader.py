@@ -156,3 +156,37 @@ def test_trajectoryformer_prepared_ahead_trains_like_prepared_in_step():
         tol = 1e-4 if step == 0 else 2e-2    # later steps start from weights that carry the atomics' rounding noise
         for k in a:
             assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (step, k, a[k], b[k])
+
+
+@pytest.mark.gpu
+def test_graph_capture_succeeds_while_the_loader_is_producing(monkeypatch):
+    """The momentum decoder is captured into a HIP graph at the first steps; a loader thread launching and allocating on
+    its own stream at the same time must not break the capture (EFG_GT_GRAPH_STRICT: a failed capture raises)."""
+    from efg_amd.data.gpu_pipeline import DevicePoints, build_train_pipeline, run
+    from efg_amd.data.synthetic import PC_RANGE, make_scene
+    from efg_amd.engine import Trainer
+
+    monkeypatch.setenv("EFG_GT_GRAPH_STRICT", "1")
+    dev = torch.device("cuda:0")
+    np.random.seed(5)
+    chain = build_train_pipeline(PC_RANGE)
+    scenes = []
+    for s in range(2):
+        pts, boxes, labels = make_scene(900 + s, n_points=30000, n_boxes=8)
+        scenes.append((torch.from_numpy(pts).to(dev), {"gt_boxes": boxes[:, [0, 1, 2, 3, 4, 5, 8]].copy(), "labels": labels,
+                                                       "difficulty": np.zeros(len(labels), np.int64),
+                                                       "num_points_in_gt": np.full(len(labels), 50, np.int64)}))
+    torch.cuda.synchronize()
+
+    def produce(i):
+        pts, ann = scenes[i % 2]
+        cloud, info = run(chain, DevicePoints(pts.clone()), {"annotations": copy.deepcopy(ann)})
+        info["annotations"]["gt_boxes"] = info["annotations"]["gt_boxes"].astype(np.float32)
+        return {"points": cloud}, info
+
+    tr = Trainer(device=dev, seed=0)
+    with DeviceLoader(produce, batch_size=2, length=8, device=dev, depth=2) as loader:
+        for batch in loader:
+            losses, total = tr.step(batch)
+            assert torch.isfinite(total)
+    tr.close()
