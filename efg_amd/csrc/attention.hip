@@ -29,6 +29,10 @@ constexpr int kLd = 68;   // LDS row stride (floats): 16-byte aligned rows, 4-ba
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
+// 2^x for x <= ~0: the bare v_exp_f32 (1 ulp; below -126 it flushes to 0, which is what a vanishing probability should be);
+// exp2f() wraps it in a range test + ldexp for denormal results, 5 instructions per value in the softmax loops
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ f32x4 mfma_k4(const f32x4 a, const f32x4 b, f32x4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const Operands a, floa
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float p = exp2f(acc[kt][qt][i] - m);
+        const float p = fast_exp2(acc[kt][qt][i] - m);
         acc[kt][qt][i] = p;
         sum += p;
       }
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const Operands a, c
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = (16 * kt + 4 * j + i < seq) ? exp2f(s[qt][i] - l2[qt]) : 0.f;
+          const float p = (16 * kt + 4 * j + i < seq) ? fast_exp2(s[qt][i] - l2[qt]) : 0.f;
           ds[qt][i] = p * (dp[qt][i] - delta[qt]);
         }
 #pragma unroll
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const Operands a, 
         const float l = l2s[16 * qt + 4 * j + i], d = dls[16 * qt + 4 * j + i];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          p[kt][i] = exp2f(s[kt][i] - l);
+          p[kt][i] = fast_exp2(s[kt][i] - l);
           ds[kt][i] = p[kt][i] * (dp[kt][i] - d);
         }
       }
@@ -508,16 +512,23 @@ __global__ void __launch_bounds__(256) attn_long_fwd_kernel(const LongOperands a
       for (int t = 0; t < 2; ++t)
         acc[kt] = mfma_k4(*reinterpret_cast<const f32x4*>(&Ks[16 * kt + c][16 * t + 4 * j]), bq[t], acc[kt]);
     }
+    // a block inside the sequence with no masked pair for any query of the wave skips the per-element tests
+    const bool plain = k0 + kBlk <= s && __builtin_amdgcn_ballot_w64((mw[0] | mw[1] | mw[2] | mw[3]) != 0u) == 0ull;
     float bm = -INFINITY;
+    if (plain) {
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
+      for (int kt = 0; kt < 8; ++kt) bm = fmaxf(bm, fmaxf(fmaxf(acc[kt][0], acc[kt][1]), fmaxf(acc[kt][2], acc[kt][3])));
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = 16 * kt + 4 * j + i;
-        const bool dead = k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u);
-        acc[kt][i] = dead ? -INFINITY : acc[kt][i];
-        bm = fmaxf(bm, acc[kt][i]);
-      }
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = 16 * kt + 4 * j + i;
+          const bool dead = k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u);
+          acc[kt][i] = dead ? -INFINITY : acc[kt][i];
+          bm = fmaxf(bm, acc[kt][i]);
+        }
+    }
     const float m_new = fmaxf(m_run, group_max(bm));
     const float m_use = m_new == -INFINITY ? 0.f : m_new;   // nothing allowed so far: every p below is exp2(-inf) = 0
     float bs = 0.f;
@@ -525,10 +536,10 @@ __global__ void __launch_bounds__(256) attn_long_fwd_kernel(const LongOperands a
     for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[kt][i] = exp2f(acc[kt][i] - m_use);
+        acc[kt][i] = fast_exp2(acc[kt][i] - m_use);
         bs += acc[kt][i];
       }
-    const float alpha = exp2f(m_run - m_use);   // m_run = -inf -> 0
+    const float alpha = fast_exp2(m_run - m_use);   // m_run = -inf -> 0
     l_run = l_run * alpha + group_sum(bs);
     m_run = m_new;
 #pragma unroll
@@ -601,6 +612,7 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperand
 #pragma unroll
     for (int w = 0; w < 4; ++w) mw[w] = mw_nxt[w];
     if (k0 + kBlk < s) fetch(k0 + kBlk);
+    const bool plain = k0 + kBlk <= s && __builtin_amdgcn_ballot_w64((mw[0] | mw[1] | mw[2] | mw[3]) != 0u) == 0ull;
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
@@ -614,8 +626,8 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dq_kernel(const LongOperand
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int key = 16 * kt + 4 * j + i;
-        const bool dead = k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u);
-        const float p = dead ? 0.f : exp2f(sv[i] - l2);
+        const bool dead = !plain && (k0 + key >= s || ((mw[kt >> 1] >> (key & 31)) & 1u));
+        const float p = dead ? 0.f : fast_exp2(sv[i] - l2);
         ds[i] = p * (dp[i] - delta);
       }
       dq[0] = mfma_k4(ds, col_frag(Ks, 16 * kt + 4 * j, c), dq[0]);
@@ -698,7 +710,7 @@ __global__ void __launch_bounds__(256) attn_long_bwd_dkv_kernel(const LongOperan
         for (int i = 0; i < 4; ++i) {
           const int r = 16 * qt + 4 * j + i;
           const bool dead = (msk[wv][r] >> kbit) & 1u;
-          p[i] = dead ? 0.f : exp2f(sv[i] - l2s[r]);
+          p[i] = dead ? 0.f : fast_exp2(sv[i] - l2s[r]);
           ds[i] = p[i] * (dp[i] - dls[r]);
         }
         dv[0] = mfma_k4(p, col_frag(dOs, 16 * qt + 4 * j, c), dv[0]);
