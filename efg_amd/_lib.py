@@ -104,6 +104,7 @@ _SIGS = {
     "efg_attention_long_bwd_f32": (c_int, [c_void_p, c_int64, c_int64] * 3 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                                              c_int64, c_int, c_int, c_float, c_void_p, c_void_p,
                                                                              c_void_p, c_void_p, c_void_p]),
+    "efg_relu_bwd_colsum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_nms_segmented_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                       c_void_p]),
     "efg_gn_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -98,6 +98,63 @@ colsum_partial_kernel(const float* __restrict__ x, long long rows, int slots, lo
   }
 }
 
+// The same pass with the ReLU backward folded in: g_out = g where y > 0 else 0 (what autograd's threshold_backward
+// writes), column sums of g_out in the order of colsum_partial_kernel<true> -- the masked gradient of a Linear + ReLU is
+// written once and never re-read for its bias gradient (one 290 MB read less per FFN layer of the encoder).
+__global__ void __launch_bounds__(256)
+relu_bwd_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ y, long long rows, int slots,
+                               long long row_stride, int rows_per_block, int slot_log2, int cols, float* __restrict__ g_out,
+                               float* __restrict__ partial) {
+  __shared__ Acc<true> sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = 1 << slot_log2;
+  const int rps = 64 >> slot_log2;
+  const int slot = blockIdx.y * 64 + (lane & (width - 1));
+  const int rsub = lane >> slot_log2;
+  const bool ok = slot < slots;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  Acc<true> a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i].zero();
+  auto take = [&](Acc<true>& acc, long long r) {
+    const long long at = r * row_stride + (long long)slot * 4;
+    float4 t = *reinterpret_cast<const float4*>(g + at);
+    const float4 m = *reinterpret_cast<const float4*>(y + at);
+    t.x = m.x > 0.f ? t.x : 0.f;
+    t.y = m.y > 0.f ? t.y : 0.f;
+    t.z = m.z > 0.f ? t.z : 0.f;
+    t.w = m.w > 0.f ? t.w : 0.f;
+    *reinterpret_cast<float4*>(g_out + at) = t;
+    acc.v.x += t.x; acc.v.y += t.y; acc.v.z += t.z; acc.v.w += t.w;
+  };
+  if (ok) {
+    const long long step = 4ll * rps;
+    long long r = r0 + (long long)wave * rps + rsub;
+    for (; r + 7 * step < r1; r += 8 * step) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) take(a[i], r + i * step);
+    }
+    for (; r < r1; r += step) take(a[0], r);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i].add(a[i + 4]);
+  a[0].add(a[2]);
+  a[1].add(a[3]);
+  a[0].add(a[1]);
+  Acc<true>& a0 = a[0];
+  for (int m = width; m < 64; m <<= 1) a0.add(a0.xor_lane(m));
+  if (rsub == 0) sm[wave][lane] = a0;
+  __syncthreads();
+  if (wave == 0 && rsub == 0 && ok) {
+    Acc<true> s = sm[0][lane];
+    s.add(sm[1][lane]);
+    s.add(sm[2][lane]);
+    s.add(sm[3][lane]);
+    s.store(partial + (long long)blockIdx.x * cols + (long long)slot * 4);
+  }
+}
+
 // kWaves = 16 for long partial lists (the 70 688-row matrices), 4 for the decoder-sized ones.
 template <int kWaves>
 __global__ void __launch_bounds__(64 * kWaves)
@@ -186,6 +243,37 @@ extern "C" int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t ro
   } else if (p.nblocks > 1) {
     hipLaunchKernelGGL(colsum_final_kernel<4>, dim3((unsigned)ceil_div(cols, 64)), dim3(256), 0, st, partial,
                        p.nblocks, cols, out);
+    EFG_LAUNCH_CHECK();
+  }
+  return EFG_OK;
+}
+
+// g_out[r][c] = y[r][c] > 0 ? g[r][c] : 0 and out[c] = sum_r g_out[r][c]; contiguous [rows, cols] matrices, cols % 4 == 0,
+// 16-byte aligned; workspace as efg_colsum_workspace_bytes(rows, cols).  g_out may alias g.
+extern "C" int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t rows, int cols, float* g_out, float* out,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  EFG_CHECK_ARG(rows >= 0 && cols >= 4 && cols % 4 == 0, "relu_bwd_colsum: bad shape %lld x %d", (long long)rows, cols);
+  EFG_CHECK_ARG(out, "relu_bwd_colsum: null output");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) {
+    EFG_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+    return EFG_OK;
+  }
+  EFG_CHECK_ARG(g && y && g_out && ws, "relu_bwd_colsum: null pointer");
+  EFG_CHECK_ARG(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g_out)) & 15) == 0,
+                "relu_bwd_colsum: operands must be 16-byte aligned");
+  const ColsumPlan p = colsum_plan(rows, cols, cols, g);
+  EFG_CHECK_ARG(ws_bytes >= sizeof(float) * (size_t)cols * (size_t)p.nblocks, "relu_bwd_colsum: workspace too small");
+  float* partial = p.nblocks == 1 ? out : static_cast<float*>(ws);
+  hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(p.nblocks, p.ygroups), dim3(256), 0, st, g, y, (long long)rows, p.slots,
+                     (long long)cols, p.rows_per_block, p.slot_log2, cols, g_out, partial);
+  EFG_LAUNCH_CHECK();
+  if (p.nblocks > 64) {
+    hipLaunchKernelGGL(colsum_final_kernel<16>, dim3((unsigned)ceil_div(cols, 64)), dim3(1024), 0, st, partial, p.nblocks, cols,
+                       out);
+    EFG_LAUNCH_CHECK();
+  } else if (p.nblocks > 1) {
+    hipLaunchKernelGGL(colsum_final_kernel<4>, dim3((unsigned)ceil_div(cols, 64)), dim3(256), 0, st, partial, p.nblocks, cols, out);
     EFG_LAUNCH_CHECK();
   }
   return EFG_OK;

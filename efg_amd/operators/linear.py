@@ -32,6 +32,19 @@ def column_sum(x2):
     return out
 
 
+def relu_backward_column_sum(g2, y):
+    """(g2 * (y > 0), its column sums) for contiguous [rows, cols] fp32 GPU matrices: csrc/colsum.hip, one pass."""
+    L.require_gpu(g2)
+    rows, cols = g2.shape
+    masked = torch.empty_like(g2)
+    out = torch.empty(cols, dtype=torch.float32, device=g2.device)
+    ws_bytes = L.lib().efg_colsum_workspace_bytes(rows, cols)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g2.device)
+    L.check(L.lib().efg_relu_bwd_colsum_f32(L.ptr(g2), L.ptr(y), rows, cols, L.ptr(masked), L.ptr(out), L.ptr(ws), ws_bytes,
+                                            L.stream()))
+    return masked, out
+
+
 _SPLIT_MIN_ROWS = 32768
 _FUSED_MIN_ROWS = int(os.environ.get("EFG_LINEAR_MIN_ROWS", "16384"))  # linear(): rows from which the custom backward is used
 _SPLITS = 16
@@ -74,11 +87,17 @@ class LinearFunction(Function):
     def backward(ctx, grad):
         x2, weight, y = ctx.saved_tensors
         g2 = grad.reshape(-1, grad.shape[-1])
+        gb = None
         if ctx.relu:
-            g2 = torch.ops.aten.threshold_backward(g2, y, 0)  # what autograd runs for relu
+            if (ctx.needs_input_grad[2] and g2.is_contiguous() and y.is_contiguous() and g2.shape[1] % 4 == 0
+                    and g2.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+                g2, gb = relu_backward_column_sum(g2, y)   # threshold_backward + bias gradient in one pass
+            else:
+                g2 = torch.ops.aten.threshold_backward(g2, y, 0)  # what autograd runs for relu
         gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = weight_grad(x2, g2) if ctx.needs_input_grad[1] else None
-        gb = column_sum(g2) if ctx.needs_input_grad[2] else None  # bias=None -> needs_input_grad[2] is False
+        if gb is None and ctx.needs_input_grad[2]:  # bias=None -> needs_input_grad[2] is False
+            gb = column_sum(g2)
         return gx, gw, gb, None
 
 

@@ -446,6 +446,12 @@ int efg_gn_backward_f32(const float* dy, const float* x, const float* weight, co
 size_t efg_colsum_workspace_bytes(int64_t rows, int cols);
 int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t row_stride, float* out, void* ws, size_t ws_bytes,
                    void* stream);
+/* The ReLU backward of a Linear + ReLU folded into the same pass (operators/linear.py LinearFunction.backward): g_out =
+ * (y > 0) ? g : 0, what autograd's threshold_backward writes, and out[c] = column sums of g_out in efg_colsum_f32's order.
+ * Contiguous [rows, cols] matrices, cols % 4 == 0, 16-byte aligned; workspace efg_colsum_workspace_bytes(rows, cols);
+ * g_out may alias g. */
+int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t rows, int cols, float* g_out, float* out, void* ws,
+                            size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

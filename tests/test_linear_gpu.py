@@ -156,6 +156,23 @@ def test_linear_relu_epilogue():
     assert torch.equal(linear(xs, w, b, relu=True), torch.relu(torch.nn.functional.linear(xs, w, b)))
 
 
+@pytest.mark.parametrize("rows,cols", [(70688, 1024), (157696, 256), (33, 64), (1, 4), (5000, 200)])
+def test_relu_backward_column_sum(rows, cols):
+    """efg_relu_bwd_colsum_f32: the masked gradient is bit-identical to threshold_backward, its column sums to the
+    column-sum op on that masked gradient (same order) and to fp64 within rounding."""
+    from efg_amd.operators.linear import column_sum, relu_backward_column_sum
+
+    g = torch.Generator().manual_seed(rows + cols)
+    grad = torch.randn(rows, cols, generator=g).cuda()
+    y = torch.relu(torch.randn(rows, cols, generator=g)).cuda()
+    masked, sums = relu_backward_column_sum(grad, y)
+    want = torch.ops.aten.threshold_backward(grad, y, 0)
+    assert torch.equal(masked, want)
+    assert torch.equal(sums, column_sum(want))
+    ref = want.double().sum(0)
+    assert float((sums.double() - ref).abs().max()) <= 1e-5 * float(want.abs().double().sum(0).max()) + 1e-12
+
+
 def test_linear_refuses_nothing_on_cpu():
     """Host tensors run the plain PyTorch layer (dense layers are PyTorch plumbing, not a HIP op)."""
     from efg_amd.operators.linear import Linear
