@@ -346,10 +346,10 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
             pred_hypo = self.get_pred_motion(traj, pred_vel)[:, 0, :, 0]
         return pred_hypo, labels[:, 1], det_boxes3d, traj[:, 1:]
 
-    def get_pred_motion(self, traj, pred_vel=None):
+    def get_pred_motion(self, traj, pred_vel=None, valid_steps=None):
         """Forecast of every trajectory `num_future` frames ahead (:1090-1166): constant-velocity initialisation in
         the frame of the newest box plus the MotionEncoder's (x, y, heading) residuals.  traj [B, T, N, 8],
-        pred_vel [B, 1, N, 2] -> [B, num_future, N, 1, 8]."""
+        pred_vel [B, 1, N, 2] -> [B, num_future, N, 1, 8]; valid_steps [B] (optional): history length of each entry."""
         hist = traj.unsqueeze(3)
         b, t, n = hist.shape[:3]
         nf = self.num_future
@@ -368,6 +368,8 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         lines = torch.cat([hist_local[..., :2], hist_local[..., 6:7], vel_local, hist_local[..., 7:8]], -1)
         lines = lines.permute(0, 2, 3, 1, 4).reshape(b, n, t, -1)
         mask = ~empty.permute(0, 2, 3, 1).reshape(b, n, t)
+        if valid_steps is not None:   # [B]: batch entry i only has its first valid_steps[i] history frames (online.py)
+            mask = mask & (torch.arange(t, device=traj.device).view(1, 1, t) < valid_steps.view(b, 1, 1))
         delta = self.velboxembed(lines, mask).reshape(b, n, 1, nf, 3).permute(0, 3, 1, 2, 4)
         future = init_local.clone()
         future[..., [0, 1, 6]] = delta + init_local[..., [0, 1, 6]].detach()

@@ -57,3 +57,30 @@ def test_online_tracker_matches_reference_gpu(dev):
     import contextlib
 
     _run(dev, contextlib.nullcontext)
+
+
+@pytest.mark.gpu
+def test_batched_forecasts_equal_the_loop(dev, monkeypatch):
+    """get_pred_candi: the forecasts from the last frames run as one (zero-padded, step-masked) batch of the motion
+    model; same tracks, boxes and scores as the reference's loop over them, frame by frame over a 24-frame drive."""
+    from efg_amd.config import load_config
+    from efg_amd.tracking import TrajectoryFormer
+    from efg_amd.tracking.synthetic import make_tracking_sequence
+
+    seq = make_tracking_sequence(seed=11, frames=24, n_objects=14, n_ground=6000, per_object=200)
+
+    def drive(batch):
+        monkeypatch.setenv("EFG_TRACKER_BATCH", batch)
+        cfg = load_config(os.path.join(ROOT, "configs", "trajectoryformer_waymo_centerpoint.yaml"),
+                          {"model.device": str(dev), "task": "val", "model.eval_class": "VEHICLE"})
+        torch.manual_seed(0)
+        model = TrajectoryFormer(cfg)
+        model.load_state_dict(deterministic_state(model.state_dict()))
+        model.eval()
+        return [model([item])[0] for item in seq]
+
+    for f, (a, b) in enumerate(zip(drive("1"), drive("0"))):
+        assert a["track_ids"].tolist() == b["track_ids"].tolist(), f
+        np.testing.assert_array_equal(a["track_labels"].numpy(), b["track_labels"].numpy())
+        np.testing.assert_allclose(a["track_boxes3d"].numpy(), b["track_boxes3d"].numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(a["track_scores"].numpy(), b["track_scores"].numpy(), rtol=0, atol=2e-5)
