@@ -354,7 +354,11 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         b, t, n = hist.shape[:3]
         nf = self.num_future
         newest = hist[:, 0:1]
-        scale = torch.tensor([0.1 * (i + 1) for i in range(nf)], dtype=traj.dtype, device=traj.device)
+        key = (nf, traj.dtype, traj.device)   # built once: a tensor from a Python list is a blocking upload (stream sync)
+        cache = self.__dict__.setdefault("_future_scale", {})
+        if key not in cache:
+            cache[key] = torch.tensor([0.1 * (i + 1) for i in range(nf)], dtype=traj.dtype, device=traj.device)
+        scale = cache[key]
         init = newest.repeat(1, nf, 1, 1, 1)
         init[..., :2] = newest[..., :2] + scale.view(1, nf, 1, 1, 1) * pred_vel[:, 0].unsqueeze(2).unsqueeze(1)
         vel = 0.1 * pred_vel.unsqueeze(3).repeat(1, t, 1, 1, 1)
