@@ -52,9 +52,16 @@ def decode_torch(box_encodings, anchors):
 _CORNER_TEMPLATE = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
 
 
+@functools.lru_cache(maxsize=None)
+def _constant(values, dtype, device):
+    """A small constant tensor on `device`, built once: `tensor(list, device=gpu)` / `new_tensor(list)` are blocking uploads,
+    i.e. a host wait for everything queued on the stream (found with scripts/ubench/sync_points.py)."""
+    return torch.tensor(values, dtype=dtype, device=device)
+
+
 def boxes_to_corners_3d(boxes3d):
     """(N, 7) -> (N, 8, 3) corners, bottom face first (utils.py:107-144)."""
-    template = boxes3d.new_tensor(_CORNER_TEMPLATE) / 2
+    template = _constant(_CORNER_TEMPLATE, boxes3d.dtype, boxes3d.device) / 2
     corners = boxes3d[:, None, 3:6].repeat(1, 8, 1) * template[None]
     corners = rotate_points_along_z(corners, boxes3d[:, 6])
     return corners + boxes3d[:, None, 0:3]
@@ -101,7 +108,7 @@ def get_corner_points_of_roi(rois):
     (utils.py:301-325)."""
     rois = rois.reshape(-1, rois.shape[-1])
     size = rois[:, 3:6].unsqueeze(1)
-    bits = torch.tensor([[i >> 2 & 1, i >> 1 & 1, i & 1] for i in range(8)], dtype=rois.dtype, device=rois.device)
+    bits = _constant(tuple((i >> 2 & 1, i >> 1 & 1, i & 1) for i in range(8)), rois.dtype, rois.device)
     local = bits[None] * size - size / 2
     local = rotate_points_along_z(local, rois[:, 6])
     return local + rois[:, None, 0:3], local

@@ -45,12 +45,15 @@ def get_corner_loss_lidar(pred_bbox3d, gt_bbox3d):
     return WeightedSmoothL1Loss.smooth_l1_loss(dist, beta=1.0).mean(dim=1)
 
 
-def get_corner_loss(rcnn_reg, roi_boxes3d, gt_of_rois_src, fg_mask):
+def get_corner_loss(rcnn_reg, roi_boxes3d, gt_of_rois_src, fg):
     """Decode the foreground residuals in their ROI frames, move them back to the scene, corner loss against the
-    ground truth (losses.py:106-130).  Mean over an empty foreground set is NaN, as in the reference."""
-    rois = roi_boxes3d[fg_mask]
+    ground truth (losses.py:106-130).  `fg`: the reference's boolean mask, or the (ascending) row indices it selects
+    -- no `nonzero` read-back per selection then.  Mean over an empty foreground set is NaN, as in the reference."""
+    if fg.dtype == torch.bool:
+        fg = fg.nonzero().view(-1)
+    rois = roi_boxes3d.index_select(0, fg)
     anchors = torch.cat([torch.zeros_like(rois[:, :3]), rois[:, 3:]], dim=1).detach()
-    boxes = decode_torch(rcnn_reg[fg_mask], anchors)
+    boxes = decode_torch(rcnn_reg.index_select(0, fg), anchors)
     boxes = rotate_points_along_z(boxes.unsqueeze(1), rois[:, 6]).squeeze(1)
     boxes = torch.cat([boxes[:, 0:3] + rois[:, 0:3], boxes[:, 3:]], dim=1)
-    return get_corner_loss_lidar(boxes[:, 0:7], gt_of_rois_src[fg_mask][:, 0:7]).mean()
+    return get_corner_loss_lidar(boxes[:, 0:7], gt_of_rois_src.index_select(0, fg)[:, 0:7]).mean()

@@ -189,7 +189,7 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         point_reg = self.point_reg(all_tokens).reshape(1, -1, 7)
         loss_cls, loss_reg = self.get_loss(rois, prep["gt_boxes"], point_cls, joint_cls, boxes_cls, point_reg,
                                            prep["ious_targets"], prep["reg_targets"], prep["fg_reg_mask"],
-                                           prep["fg_iou_mask"])
+                                           prep["fg_iou_mask"], prep["fg_reg_idx"], prep["fg_iou_idx"])
         if prep["gt_boxes"].shape[0] > 0:
             return {"loss_cls": loss_cls, "loss_reg": loss_reg}
         return {"loss_cls": loss_cls, "loss_reg": zero}
@@ -211,6 +211,7 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         rois = candidates[..., :7].reshape(-1, 7)
         return {"hypotheses": hypotheses, "rois": rois, "points": points, "pred_labels": pred_labels,
                 "fg_iou_mask": fg_iou_mask, "fg_reg_mask": fg_reg_mask, "ious_targets": ious_targets,
+                "fg_iou_idx": fg_iou_mask.nonzero().view(-1), "fg_reg_idx": fg_reg_mask.nonzero().view(-1),
                 "gt_boxes": gt_boxes, "reg_targets": self.get_reg_targets(rois, gt_boxes)}
 
     def _on_prep_stream(self, fn, batched_inputs):
@@ -538,18 +539,28 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         return encode_boxes_res_torch(gt, local).repeat(self.num_encoder_layers, 1).reshape(1, -1, 7)
 
     def get_loss(self, rois, gt_boxes, point_cls, joint_cls, boxes_cls, point_reg, ious_targets, reg_targets,
-                 fg_reg_mask, fg_iou_mask):
+                 fg_reg_mask, fg_iou_mask, fg_reg_idx=None, fg_iou_idx=None):
         """(:929-972) smooth-L1 + corner loss over the hypotheses that overlap a ground-truth box; BCE of the point
-        tokens (all hypotheses), of the box-sequence features and of the joint features (foreground tracks)."""
+        tokens (all hypotheses), of the box-sequence features and of the joint features (foreground tracks).
+        The foreground selections go through index lists (the preparation makes them, `_prepare`): indexing with the
+        boolean masks themselves is a `nonzero` = a device-to-host read-back per selection, nine in this forward and four
+        more in its backward, each one stopping the host at that point of the stream."""
         layers = self.num_encoder_layers
-        loss_reg = self.reg_loss_func(point_reg, reg_targets)[:, fg_reg_mask]
+        if fg_reg_idx is None:
+            fg_reg_idx = fg_reg_mask.nonzero().view(-1)
+        if fg_iou_idx is None:
+            fg_iou_idx = fg_iou_mask.nonzero().view(-1)
+        loss_reg = self.reg_loss_func(point_reg, reg_targets).index_select(1, fg_reg_idx)
         loss_reg = loss_reg.sum() / fg_reg_mask.sum().clamp(min=1)
         loss_corner = get_corner_loss(point_reg.reshape(-1, 7), rois.repeat(layers, 1), gt_boxes.repeat(layers, 1),
-                                      fg_reg_mask)
+                                      fg_reg_idx)
         loss_point_cls = F.binary_cross_entropy(point_cls.sigmoid().reshape(-1), ious_targets)
         per_track = ious_targets[:ious_targets.shape[0] // layers].reshape(self.batch_size * self.num_track,
                                                                           self.num_hypo_train)
-        loss_box_cls = F.binary_cross_entropy(boxes_cls.sigmoid()[fg_iou_mask], per_track[fg_iou_mask])
-        fg_all = fg_iou_mask.repeat(layers)
-        loss_joint_cls = F.binary_cross_entropy(joint_cls.sigmoid()[fg_all], per_track.repeat(layers, 1)[fg_all])
+        loss_box_cls = F.binary_cross_entropy(boxes_cls.sigmoid().index_select(0, fg_iou_idx),
+                                              per_track.index_select(0, fg_iou_idx))
+        n = fg_iou_mask.shape[0]
+        fg_all = torch.cat([fg_iou_idx + n * i for i in range(layers)])        # == fg_iou_mask.repeat(layers).nonzero()
+        loss_joint_cls = F.binary_cross_entropy(joint_cls.sigmoid().index_select(0, fg_all),
+                                                per_track.repeat(layers, 1).index_select(0, fg_all))
         return loss_joint_cls + loss_point_cls + loss_box_cls, loss_reg + loss_corner
