@@ -48,7 +48,10 @@ def show(message, category, filename, lineno, file=None, line=None):
     if "synchroniz" not in str(message):
         return
     stack = [f for f in traceback.extract_stack() if "/efg_amd/" in f.filename]
-    where = " <- ".join("%s:%d" % (os.path.relpath(f.filename, ROOT), f.lineno) for f in reversed(stack[-3:])) or "(autograd thread / outside efg_amd)"
+    where = " <- ".join("%s:%d" % (os.path.relpath(f.filename, ROOT), f.lineno) for f in reversed(stack[-3:]))
+    if not where:   # no frame of ours: the innermost frames of whatever called
+        where = "(outside efg_amd) " + " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno)
+                                                   for f in reversed(traceback.extract_stack()[-6:-1]))
     seen[where] = seen.get(where, 0) + 1
 
 
