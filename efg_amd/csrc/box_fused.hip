@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(bt::kThreads)
 box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
                     const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ logits,
                     const float* __restrict__ kidx, const float* __restrict__ grad_out, BoxDims dm,
-                    float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits) {
+                    float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits,
+                    int* __restrict__ cursor, int2* __restrict__ entries) {
   using namespace bt;
   extern __shared__ float lds[];
   float* Vs = lds;                     // [NC][VS]
@@ -606,7 +607,10 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
         asm volatile("" ::: "memory");
       }
     }
-    // rare: corners outside the window go straight to global memory, channel by channel
+    // corners outside the window.  As the boxes grow with training these stop being rare, and 32 float atomics per corner
+    // are a cliff (2 x 35 344 queries with boxes 3x their anchors: 0.67 -> 39.8 ms per launch).  With the binned path
+    // (`cursor`: the launch code counted these corners per (cell, head) row and scanned the counts) a corner is ONE
+    // 8-byte entry (grad_out row, weight) that box_bin_reduce_kernel sums per row after this kernel.
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       if (e_cell[k] == -2) {
@@ -616,8 +620,13 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
         const float h_im = __fsub_rn(__fmul_rn(g.cy + (gx * g.sn + gy * g.cs), (float)Hm), 0.5f);
         const float w_im = __fsub_rn(__fmul_rn(g.cx + (gx * g.cs + gy * (-g.sn)), (float)Wm), 0.5f);
         const int cy = (int)floorf(h_im) + (corner >> 1), cx = (int)floorf(w_im) + (corner & 1);
-        float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D;
-        for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
+        const long long bin = ((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m;
+        if (cursor) {
+          entries[atomicAdd(cursor + bin, 1)] = make_int2((int)t, __float_as_int(e_w[k]));
+        } else {
+          float* gv = grad_value + bin * D;
+          for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
+        }
       }
     }
     __syncthreads();
@@ -664,8 +673,10 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
 __global__ void __launch_bounds__(256)
 box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __restrict__ starts,
                      const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ kidx,
-                     BoxDims dm, int* __restrict__ counts) {
-  // one thread per (query, head, level, point): the same location arithmetic as box_bwd_kernel
+                     BoxDims dm, int* __restrict__ counts, int outside_tile_window) {
+  // one thread per (query, head, level, point): the same location arithmetic as box_bwd_kernel.  outside_tile_window:
+  // queries are the cells of the (single) map and only the corners box_bwd_tile_kernel cannot keep in the 16 x 16 window
+  // of the query's 8 x 8 tile are counted
   const long long total = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
@@ -676,6 +687,27 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
   const long long bq = t / dm.h;
   const int bi = (int)(bq / dm.lq);
   const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
+  int wy0 = 0, wx0 = 0;
+  if (outside_tile_window) {
+    const int q = (int)(bq % dm.lq);
+    wy0 = (q / W) / bt::TQ * bt::TQ - bt::R;
+    wx0 = (q % W) / bt::TQ * bt::TQ - bt::R;
+    // the common case costs no trigonometry: the lattice offsets are below half a box side (|k| < 0.5) in each axis
+    // before the rotation, so no sampling point is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2
+    // for an upright box); a box whose
+    // whole reach (+ the bilinear neighbour, + 0.01 cell for rounding) stays inside the window has nothing to count
+    const float* r = ref + bq * 7;
+    const float* o = off + (t * dm.l + li) * dm.v;
+    const float rw = r[3], rh = r[4];
+    const float bw = fmaxf(rw + o[2] / 8.0f * rw, 0.f), bh = fmaxf(rh + o[3] / 8.0f * rh, 0.f);
+    const bool upright = dm.v != 5 && r[6] == 0.f;   // the encoder's boxes: no rotation at all, reach = half a side per axis
+    const float ex = upright ? 0.5f * bw : 0.5f * (bw + bh), ey = upright ? 0.5f * bh : 0.5f * (bw + bh);
+    const float bx = (r[0] + o[0] / 8.0f * rw) * (float)W - 0.5f, by = (r[1] + o[1] / 8.0f * rh) * (float)H - 0.5f;
+    const float rx = ex * (float)W + 0.01f, ry = ey * (float)H + 0.01f;
+    if (floorf(bx - rx) >= (float)wx0 && floorf(bx + rx) + 1.f <= (float)(wx0 + bt::WIN - 1) &&
+        floorf(by - ry) >= (float)wy0 && floorf(by + ry) + 1.f <= (float)(wy0 + bt::WIN - 1))
+      return;
+  }
   const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
   const float gx = kidx[pi * 2] * g.w, gy = kidx[pi * 2 + 1] * g.h;
   const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
@@ -687,8 +719,10 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
 #pragma unroll
   for (int cn = 0; cn < 4; ++cn) {
     const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
-    if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1)
+    if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1) {
+      if (outside_tile_window && (unsigned)(cy - wy0) < (unsigned)bt::WIN && (unsigned)(cx - wx0) < (unsigned)bt::WIN) continue;
       atomicAdd(counts + (((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m), 1);
+    }
   }
 }
 
@@ -851,10 +885,40 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     const int side = (int)std::ceil(std::sqrt((double)s));
     const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
     if (l * p <= bt::PMAX) {
+      // corners that leave the tile's window are binned per (cell, head) row when a workspace is given (see the kernel)
+      const BinPlan pl = bin_plan(b, s, h, l, lq, p);
+      hipStream_t st = (hipStream_t)stream;
+      const bool binned = ws != nullptr && pl.nentries < (1ll << 31) && pl.nbins < (1ll << 31);
+      int* cursor = nullptr;
+      int2* entries = nullptr;
+      int* offs = nullptr;
+      if (binned) {
+        EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
+        char* base = static_cast<char*>(ws);
+        offs = reinterpret_cast<int*>(base + pl.off_offsets);
+        cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+        int* totals = reinterpret_cast<int*>(base + pl.off_totals);
+        entries = reinterpret_cast<int2*>(base + pl.off_entries);
+        EFG_HIP_TRY(hipMemsetAsync(offs, 0, sizeof(int) * (size_t)pl.nbins, st));
+        const long long npts = (long long)b * lq * h * l * p;
+        hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st,
+                           (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, kernel_indices,
+                           dm, offs, 1);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals, cursor);
+        EFG_LAUNCH_CHECK();
+      }
       EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel, bt::kLdsBytes);
-      hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes,
-                         (hipStream_t)stream, value, (const long long*)shapes, ref_windows, offsets, logits,
-                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits);
+      hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes, st, value,
+                         (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                         grad_offsets, grad_logits, cursor, entries);
+      if (binned) {
+        EFG_LAUNCH_CHECK();
+        const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
+        hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out, pl.nbins,
+                           grad_value);
+      }
     }
     else
       hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
@@ -879,7 +943,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       const long long npts = (long long)b * lq * h * l * p;
       hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st,
                          (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, kernel_indices,
-                         dm, offs);
+                         dm, offs, 0);
       hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals);
       hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
       hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals, cursor);

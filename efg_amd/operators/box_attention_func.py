@@ -175,7 +175,9 @@ class BoxAttnFusedFunction(Function):
         name = ("box_bwd_tile_kernel" if l * p <= 32 else "box_bwd_kernel<32, true, 128>") if grid \
             else "box_bwd_kernel<32, false, 128>"
         ws, ws_bytes = None, 0
-        if not grid:  # free-position queries: scratch for the binned grad_value reduction (csrc/box_fused.hip)
+        if not grid or l * p <= 32:
+            # scratch for the binned grad_value reduction (csrc/box_fused.hip): every corner of the free-position
+            # (decoder) queries; for the encoder's tile kernel the corners that leave the window of their query tile
             ws_bytes = L.lib().efg_box_attn_fused_backward_workspace_bytes(b, s, h, l, lq, p)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
         with _prof.timed(name, cost):

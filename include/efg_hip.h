@@ -243,7 +243,10 @@ int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, co
                                    int v, float* out, void* stream);
 /* ws (optional, may be NULL): scratch of efg_box_attn_fused_backward_workspace_bytes(...) bytes.  With it, large
  * free-position (decoder) launches sum their grad_value contributions through sorted 8-byte entries instead of
- * d float atomics per corner; without it, or for small launches, atomics are used.  Same results either way. */
+ * d float atomics per corner; without it, or for small launches, atomics are used.  Same results either way.
+ * The encoder's tile kernel (queries = the cells of one map) uses the same scratch for the corners that leave the
+ * 16 x 16 window of their query tile; without it those corners are written with d float atomics each (a cliff once the
+ * boxes grow with training). */
 size_t efg_box_attn_fused_backward_workspace_bytes(int b, int s, int h, int l, int lq, int p);
 int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                                     const float* ref_windows, const float* offsets, const float* logits,

@@ -73,7 +73,9 @@ def bench_box():
             ref = torch.rand(b, lq, 7, generator=g)
             ref[..., 3:5] = ref[..., 3:5] * 0.05 + 0.01
         ref = ref.to(dev)
-        off = torch.rand(b, lq, h * v, generator=g).to(dev).requires_grad_(True)
+        # EFG_BOX_OFF_SCALE > 1: boxes grown far beyond their anchors, as after some training (the encoder's backward then
+        # leaves its 16 x 16 LDS window for many corners)
+        off = (torch.rand(b, lq, h * v, generator=g) * float(os.environ.get("EFG_BOX_OFF_SCALE", "1"))).to(dev).requires_grad_(True)
         logits = torch.randn(b, lq, h * p, generator=g).to(dev).requires_grad_(True)
         go = torch.randn(b, lq, h * d, generator=g).to(dev)
         out = BoxAttnFusedFunction.apply(value, shapes, start, ref, off, logits, kidx, v)
