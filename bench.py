@@ -207,13 +207,40 @@ def _geometry_report(trainer, batch):
     return {"points": n_points, "input_voxels": int(coords.shape[0]), "tables": tables}
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with one rank per
+    GPU (what the reference's efg/engine/launch.py:52-57 does with mp.spawn), rendezvous on 127.0.0.1, rank 0 prints the
+    one JSON line.  Fails up front, with the reason, when the node has fewer than N devices (EFG_DIST_BACKEND=gloo lets
+    ranks share a device: the one-GPU test of the N > 1 path)."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("EFG_DIST_BACKEND", "nccl") != "gloo":
+        raise SystemExit("bench.py: --gpus %d needs %d devices, this node has %d (RCCL cannot share a device between "
+                         "ranks)" % (n, n, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     from efg_amd import _prof
     from efg_amd.engine import Trainer, init_distributed, synthetic_batch
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus)   # bare `python bench.py --gpus N`: start the N ranks ourselves
     rank, local_rank, world = init_distributed()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or run `python bench.py --gpus %d` bare and it starts the ranks itself)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     if args.model == "trajectoryformer":
         from efg_amd.tracking.bench import run as run_tracking
@@ -280,6 +307,9 @@ def main():
             "global_batch": args.scenes * world,
             "parallelism": "dp%d" % world,
         },
+        # what the collective library saw (the driver can check that RCCL ran with N ranks)
+        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        "dist_backend": ("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if dist.is_initialized() else None,
     }
     # ---- per-kernel numbers: extra steps, outside the timed region ------------------------------------------------
     if args.profile_steps > 0:
@@ -347,4 +377,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

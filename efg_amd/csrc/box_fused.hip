@@ -37,29 +37,69 @@ struct BoxGeo {
   bool w_on, h_on;              // relu masks
 };
 
-// boxes = ref[x,y,l,w] + off/8 * ref[l,w,l,w]; angle = (ref_a + off_a/16) * 2pi (rotation) or ref_a
-__device__ __forceinline__ BoxGeo make_box(const float* __restrict__ ref, const float* __restrict__ off, int v) {
+// boxes = ref[x,y,l,w] + off/8 * ref[l,w,l,w]; angle = (ref_a + off_a/16) * 2pi (rotation) or ref_a.
+// ONE definition of the geometry for every kernel of this file, written with explicit IEEE roundings (no FMA
+// contraction, which the compiler may apply differently per kernel): box_bin_count_kernel and the backward
+// kernels must put every corner into the same cell bit for bit, or a bin's entries run into its neighbour's.
+// (The reference evaluates the same expressions as separate PyTorch elementwise ops, i.e. without FMA too.)
+__device__ __forceinline__ BoxGeo make_box_v(const float rf[5], const float of[5], int v) {
   BoxGeo g;
-  const float rx = ref[0], ry = ref[1];
-  g.rw = ref[3];
-  g.rh = ref[4];
-  g.cx = rx + off[0] / 8.0f * g.rw;
-  g.cy = ry + off[1] / 8.0f * g.rh;
-  const float w = g.rw + off[2] / 8.0f * g.rw, h = g.rh + off[3] / 8.0f * g.rh;
+  g.rw = rf[2];
+  g.rh = rf[3];
+  g.cx = __fadd_rn(rf[0], __fmul_rn(__fdiv_rn(of[0], 8.0f), g.rw));
+  g.cy = __fadd_rn(rf[1], __fmul_rn(__fdiv_rn(of[1], 8.0f), g.rh));
+  const float w = __fadd_rn(g.rw, __fmul_rn(__fdiv_rn(of[2], 8.0f), g.rw));
+  const float h = __fadd_rn(g.rh, __fmul_rn(__fdiv_rn(of[3], 8.0f), g.rh));
   g.w_on = w > 0.0f;
   g.h_on = h > 0.0f;
   g.w = g.w_on ? w : 0.0f;
   g.h = g.h_on ? h : 0.0f;
-  const float ang = (v == 5) ? (ref[6] + off[4] / 16.0f) * 2.0f * 3.14159274f : ref[6];
+  const float ang = (v == 5) ? __fmul_rn(__fmul_rn(__fadd_rn(rf[4], __fdiv_rn(of[4], 16.0f)), 2.0f), 3.14159274f) : rf[4];
   g.cs = cosf(ang);
   g.sn = sinf(ang);
   return g;
+}
+
+__device__ __forceinline__ BoxGeo make_box(const float* __restrict__ ref, const float* __restrict__ off, int v) {
+  const float rf[5] = {ref[0], ref[1], ref[3], ref[4], ref[6]};
+  const float of[5] = {off[0], off[1], off[2], off[3], v == 5 ? off[4] : 0.0f};
+  return make_box_v(rf, of, v);
+}
+
+// lattice point (kxn, kyn) of box g on an H x W map: offsets from the centre (gx, gy, in box-normalised units) and
+// the pixel position (h_im, w_im) = loc * size - 0.5
+struct BoxPx {
+  float gx, gy, h_im, w_im;
+};
+__device__ __forceinline__ BoxPx box_point(const BoxGeo& g, float kxn, float kyn, int H, int W) {
+  BoxPx p;
+  p.gx = __fmul_rn(kxn, g.w);
+  p.gy = __fmul_rn(kyn, g.h);
+  const float loc_w = __fadd_rn(g.cx, __fsub_rn(__fmul_rn(p.gx, g.cs), __fmul_rn(p.gy, g.sn)));
+  const float loc_h = __fadd_rn(g.cy, __fadd_rn(__fmul_rn(p.gx, g.sn), __fmul_rn(p.gy, g.cs)));
+  p.h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
+  p.w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
+  return p;
 }
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   const unsigned per = nblk >> 3;
   if (per == 0 || bid >= (per << 3)) return bid;
   return (bid & 7) * per + (bid >> 3);
+}
+
+// One (grad_out row, weight) entry into `bin`.  cursor[bin] was initialised to the bin's first slot and bin_end[bin]
+// is the first slot of the next bin (box_bin_count_kernel counted with the same geometry, so the slot is always
+// inside); an entry that does not fit is dropped and counted in *overflow, which the host-side tests read -- it
+// must never overwrite a neighbour's entries.
+__device__ __forceinline__ void bin_push(int* __restrict__ cursor, const int* __restrict__ bin_end,
+                                         int* __restrict__ overflow, int2* __restrict__ entries, long long bin,
+                                         int row, float w) {
+  const int slot = atomicAdd(cursor + bin, 1);
+  if (slot < bin_end[bin])
+    entries[slot] = make_int2(row, __float_as_int(w));
+  else
+    atomicAdd(overflow, 1);
 }
 
 // ---- forward ------------------------------------------------------------------------------------
@@ -107,12 +147,9 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     const float* v = value + (((long long)bi * dm.s + starts[li]) * dm.h + m) * dm.d + c0;
     const BoxGeo g = make_box(ref + bq * 7, off + (tt * dm.l + li) * dm.v, dm.v);
     for (int pi = 0; pi < dm.p; ++pi) {
-      const float gx = kidx[pi * 2] * g.w, gy = kidx[pi * 2 + 1] * g.h;
-      const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
-      const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
+      const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
       const float wgt = as[li * dm.p + pi] * inv;
-      const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
-      const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
+      const float h_im = px.h_im, w_im = px.w_im;
       const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
       if (inside && active) {
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
@@ -148,7 +185,8 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
                const long long* __restrict__ starts, const float* __restrict__ ref, const float* __restrict__ off,
                const float* __restrict__ logits, const float* __restrict__ kidx, const float* __restrict__ grad_out,
                BoxDims dm, float* __restrict__ grad_value, float* __restrict__ grad_off,
-               float* __restrict__ grad_logits, int* __restrict__ cursor, int2* __restrict__ entries) {
+               float* __restrict__ grad_logits, int* __restrict__ cursor, int2* __restrict__ entries,
+               const int* __restrict__ bin_end, int* __restrict__ overflow) {
   constexpr int LP = D / 4, SLOTS = 256 / LP;
   constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R;
   __shared__ double win[kWin ? WIN * WIN * D : 1];
@@ -229,12 +267,10 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
       float dcx = 0.f, dcy = 0.f, dw = 0.f, dh = 0.f, dth = 0.f;
       for (int pi = 0; pi < dm.p; ++pi) {
         const float kxn = kidx[pi * 2], kyn = kidx[pi * 2 + 1];
-        const float gx = kxn * g.w, gy = kyn * g.h;
-        const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
-        const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
+        const BoxPx px = box_point(g, kxn, kyn, H, W);
+        const float gx = px.gx, gy = px.gy;
         const float wgt = as[li * dm.p + pi] * inv;
-        const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
-        const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
+        const float h_im = px.h_im, w_im = px.w_im;
         const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
         float ga = 0.f, gwl = 0.f, ghl = 0.f;
         if (inside && active) {
@@ -270,8 +306,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
                 // entries are summed per (cell, head) by box_bin_reduce_kernel
                 if (sub == 0) {
                   const long long bin = ((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m;
-                  const int slot_e = atomicAdd(cursor + bin, 1);
-                  entries[slot_e] = make_int2((int)t, __float_as_int(wc[cn] * wgt));
+                  bin_push(cursor, bin_end, overflow, entries, bin, (int)t, wc[cn] * wgt);
                 }
               } else {
 #pragma unroll
@@ -379,29 +414,13 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ BoxGeo make_box_v(const float rf[5], const float of[5], int v) {
-  BoxGeo g;
-  g.rw = rf[2];
-  g.rh = rf[3];
-  g.cx = rf[0] + of[0] / 8.0f * g.rw;
-  g.cy = rf[1] + of[1] / 8.0f * g.rh;
-  const float w = g.rw + of[2] / 8.0f * g.rw, h = g.rh + of[3] / 8.0f * g.rh;
-  g.w_on = w > 0.0f;
-  g.h_on = h > 0.0f;
-  g.w = g.w_on ? w : 0.0f;
-  g.h = g.h_on ? h : 0.0f;
-  const float ang = (v == 5) ? (rf[4] + of[4] / 16.0f) * 2.0f * 3.14159274f : rf[4];
-  g.cs = cosf(ang);
-  g.sn = sinf(ang);
-  return g;
-}
-
 __global__ void __launch_bounds__(bt::kThreads)
 box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
                     const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ logits,
                     const float* __restrict__ kidx, const float* __restrict__ grad_out, BoxDims dm,
                     float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits,
-                    int* __restrict__ cursor, int2* __restrict__ entries) {
+                    int* __restrict__ cursor, int2* __restrict__ entries, const int* __restrict__ bin_end,
+                    int* __restrict__ overflow) {
   using namespace bt;
   extern __shared__ float lds[];
   float* Vs = lds;                     // [NC][VS]
@@ -535,12 +554,10 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
       e_w[k] = 0.f;
       if (qok && pi < np) {
         const float kxn = k_s[pi * 2], kyn = k_s[pi * 2 + 1];
-        const float gx = kxn * g.w, gy = kyn * g.h;
-        const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
-        const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
+        const BoxPx px = box_point(g, kxn, kyn, Hm, Wm);
+        const float gx = px.gx, gy = px.gy;
         const float wgt = as[pi] * inv;
-        const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)Hm), 0.5f);
-        const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)Wm), 0.5f);
+        const float h_im = px.h_im, w_im = px.w_im;
         const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
         const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
@@ -615,14 +632,11 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     for (int k = 0; k < EPT; ++k) {
       if (e_cell[k] == -2) {
         const int pi = half + 2 * k;
-        const float kxn = k_s[pi * 2], kyn = k_s[pi * 2 + 1];
-        const float gx = kxn * g.w, gy = kyn * g.h;
-        const float h_im = __fsub_rn(__fmul_rn(g.cy + (gx * g.sn + gy * g.cs), (float)Hm), 0.5f);
-        const float w_im = __fsub_rn(__fmul_rn(g.cx + (gx * g.cs + gy * (-g.sn)), (float)Wm), 0.5f);
-        const int cy = (int)floorf(h_im) + (corner >> 1), cx = (int)floorf(w_im) + (corner & 1);
+        const BoxPx px = box_point(g, k_s[pi * 2], k_s[pi * 2 + 1], Hm, Wm);
+        const int cy = (int)floorf(px.h_im) + (corner >> 1), cx = (int)floorf(px.w_im) + (corner & 1);
         const long long bin = ((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m;
         if (cursor) {
-          entries[atomicAdd(cursor + bin, 1)] = make_int2((int)t, __float_as_int(e_w[k]));
+          bin_push(cursor, bin_end, overflow, entries, bin, (int)t, e_w[k]);
         } else {
           float* gv = grad_value + bin * D;
           for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
@@ -688,32 +702,26 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
   const int bi = (int)(bq / dm.lq);
   const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
   int wy0 = 0, wx0 = 0;
+  const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
   if (outside_tile_window) {
     const int q = (int)(bq % dm.lq);
     wy0 = (q / W) / bt::TQ * bt::TQ - bt::R;
     wx0 = (q % W) / bt::TQ * bt::TQ - bt::R;
-    // the common case costs no trigonometry: the lattice offsets are below half a box side (|k| < 0.5) in each axis
-    // before the rotation, so no sampling point is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2
-    // for an upright box); a box whose
-    // whole reach (+ the bilinear neighbour, + 0.01 cell for rounding) stays inside the window has nothing to count
-    const float* r = ref + bq * 7;
-    const float* o = off + (t * dm.l + li) * dm.v;
-    const float rw = r[3], rh = r[4];
-    const float bw = fmaxf(rw + o[2] / 8.0f * rw, 0.f), bh = fmaxf(rh + o[3] / 8.0f * rh, 0.f);
-    const bool upright = dm.v != 5 && r[6] == 0.f;   // the encoder's boxes: no rotation at all, reach = half a side per axis
-    const float ex = upright ? 0.5f * bw : 0.5f * (bw + bh), ey = upright ? 0.5f * bh : 0.5f * (bw + bh);
-    const float bx = (r[0] + o[0] / 8.0f * rw) * (float)W - 0.5f, by = (r[1] + o[1] / 8.0f * rh) * (float)H - 0.5f;
+    // the common case is cheap: the lattice offsets are below half a box side (|k| < 0.5) in each axis before the
+    // rotation, so no sampling point is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2
+    // for an upright box); a box whose whole reach (+ the bilinear neighbour, + 0.01 cell: the per-point positions
+    // are rounded 4 more times, ~1e-4 cell at 200 cells) stays inside the window has nothing to count.  Centre and
+    // size come from the SAME make_box the backward kernel classifies with.
+    const bool upright = g.sn == 0.f;   // the encoder's boxes: no rotation at all, reach = half a side per axis
+    const float ex = upright ? 0.5f * g.w : 0.5f * (g.w + g.h), ey = upright ? 0.5f * g.h : 0.5f * (g.w + g.h);
+    const float bx = g.cx * (float)W - 0.5f, by = g.cy * (float)H - 0.5f;
     const float rx = ex * (float)W + 0.01f, ry = ey * (float)H + 0.01f;
     if (floorf(bx - rx) >= (float)wx0 && floorf(bx + rx) + 1.f <= (float)(wx0 + bt::WIN - 1) &&
         floorf(by - ry) >= (float)wy0 && floorf(by + ry) + 1.f <= (float)(wy0 + bt::WIN - 1))
       return;
   }
-  const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
-  const float gx = kidx[pi * 2] * g.w, gy = kidx[pi * 2 + 1] * g.h;
-  const float loc_w = g.cx + (gx * g.cs + gy * (-g.sn));
-  const float loc_h = g.cy + (gx * g.sn + gy * g.cs);
-  const float h_im = __fsub_rn(__fmul_rn(loc_h, (float)H), 0.5f);
-  const float w_im = __fsub_rn(__fmul_rn(loc_w, (float)W), 0.5f);
+  const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
+  const float h_im = px.h_im, w_im = px.w_im;
   if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) return;
   const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
 #pragma unroll
@@ -784,7 +792,7 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
                       const float* __restrict__ grad_out, long long nbins, float* __restrict__ grad_value) {
   const int c4 = (threadIdx.x & 7) * 4;
   for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
-    const int s = offsets[bin], e = cursor[bin];
+    const int s = offsets[bin], e = min(cursor[bin], offsets[bin + 1]);  // offsets has nbins + 1 entries
     if (s == e) continue;
     float4 acc = ld4(grad_value + bin * 32 + c4);
     for (int i = s; i < e; ++i) {
@@ -803,25 +811,51 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
 struct BinPlan {
   long long nbins, nentries;
   int ntiles;
-  size_t off_offsets, off_cursor, off_totals, off_entries, bytes;
+  size_t off_flag, off_offsets, off_cursor, off_totals, off_entries, bytes;
 };
 
+// workspace: [overflow counter (int, first word)] [offsets: nbins + 1] [cursor: nbins + 1] [scan totals] [entries]
 BinPlan bin_plan(int b, int s, int h, int l, int lq, int p) {
   BinPlan pl;
   pl.nbins = (long long)b * s * h;
   pl.nentries = (long long)b * lq * h * l * p * 4;
-  pl.ntiles = (int)ceil_div(pl.nbins, kScanTile);
+  pl.ntiles = (int)ceil_div(pl.nbins + 1, kScanTile);
   size_t o = 0;
+  pl.off_flag = o;
+  o += 256;
   pl.off_offsets = o;
-  o += align_up(sizeof(int) * (size_t)pl.nbins, 256);
+  o += align_up(sizeof(int) * (size_t)(pl.nbins + 1), 256);
   pl.off_cursor = o;
-  o += align_up(sizeof(int) * (size_t)pl.nbins, 256);
+  o += align_up(sizeof(int) * (size_t)(pl.nbins + 1), 256);
   pl.off_totals = o;
   o += align_up(sizeof(int) * (size_t)pl.ntiles, 256);
   pl.off_entries = o;
   o += align_up(sizeof(int2) * (size_t)pl.nentries, 256);
   pl.bytes = o;
   return pl;
+}
+
+// count -> exclusive scan over nbins + 1 counters (the last one stays 0, so offsets[nbins] = number of entries and
+// offsets[bin + 1] ends every bin); cursor = copy of offsets
+int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long long* starts, const float* ref,
+                const float* off, const float* kidx, const BoxDims& dm, int outside_tile_window, hipStream_t st,
+                int** offs, int** cursor, int2** entries, int** overflow) {
+  char* base = static_cast<char*>(ws);
+  *overflow = reinterpret_cast<int*>(base + pl.off_flag);
+  *offs = reinterpret_cast<int*>(base + pl.off_offsets);
+  *cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+  int* totals = reinterpret_cast<int*>(base + pl.off_totals);
+  *entries = reinterpret_cast<int2*>(base + pl.off_entries);
+  // flag + offsets are adjacent: one memset
+  EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
+  const long long npts = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
+  hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st, shapes, starts, ref,
+                     off, kidx, dm, *offs, outside_tile_window);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals);
+  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals, *cursor);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
 }
 
 constexpr long long kBinMinEntries = 200000;  // below this the extra launches cost more than the atomics
@@ -888,31 +922,19 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       // corners that leave the tile's window are binned per (cell, head) row when a workspace is given (see the kernel)
       const BinPlan pl = bin_plan(b, s, h, l, lq, p);
       hipStream_t st = (hipStream_t)stream;
-      const bool binned = ws != nullptr && pl.nentries < (1ll << 31) && pl.nbins < (1ll << 31);
-      int* cursor = nullptr;
+      const bool binned = ws != nullptr && pl.nentries < (1ll << 31) && pl.nbins + 1 < (1ll << 31);
+      int *cursor = nullptr, *offs = nullptr, *overflow = nullptr;
       int2* entries = nullptr;
-      int* offs = nullptr;
       if (binned) {
         EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
-        char* base = static_cast<char*>(ws);
-        offs = reinterpret_cast<int*>(base + pl.off_offsets);
-        cursor = reinterpret_cast<int*>(base + pl.off_cursor);
-        int* totals = reinterpret_cast<int*>(base + pl.off_totals);
-        entries = reinterpret_cast<int2*>(base + pl.off_entries);
-        EFG_HIP_TRY(hipMemsetAsync(offs, 0, sizeof(int) * (size_t)pl.nbins, st));
-        const long long npts = (long long)b * lq * h * l * p;
-        hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st,
-                           (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, kernel_indices,
-                           dm, offs, 1);
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals);
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals, cursor);
-        EFG_LAUNCH_CHECK();
+        if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
+                                 kernel_indices, dm, 1, st, &offs, &cursor, &entries, &overflow))
+          return rc;
       }
       EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel, bt::kLdsBytes);
       hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes, st, value,
                          (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
-                         grad_offsets, grad_logits, cursor, entries);
+                         grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
       if (binned) {
         EFG_LAUNCH_CHECK();
         const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
@@ -923,35 +945,26 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     else
       hipLaunchKernelGGL((box_bwd_kernel<32, true>), dim3(tiles_sq, h, b), dim3(256), 0, (hipStream_t)stream,
                          value, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
-                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, nullptr, nullptr);
+                         kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, nullptr, nullptr, nullptr, nullptr);
   } else {
     const BinPlan pl = bin_plan(b, s, h, l, lq, p);
     hipStream_t st = (hipStream_t)stream;
     const bool binned = ws != nullptr && pl.nentries >= kBinMinEntries && pl.nentries < (1ll << 31) &&
-                        pl.nbins < (1ll << 31);
-    int* cursor = nullptr;
+                        pl.nbins + 1 < (1ll << 31);
+    int *cursor = nullptr, *offs = nullptr, *overflow = nullptr;
     int2* entries = nullptr;
-    int* offs = nullptr;
     if (binned) {
       EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
-      char* base = static_cast<char*>(ws);
-      offs = reinterpret_cast<int*>(base + pl.off_offsets);
-      cursor = reinterpret_cast<int*>(base + pl.off_cursor);
-      int* totals = reinterpret_cast<int*>(base + pl.off_totals);
-      entries = reinterpret_cast<int2*>(base + pl.off_entries);
-      EFG_HIP_TRY(hipMemsetAsync(offs, 0, sizeof(int) * (size_t)pl.nbins, st));
-      const long long npts = (long long)b * lq * h * l * p;
-      hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st,
-                         (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, kernel_indices,
-                         dm, offs, 0);
-      hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals);
-      hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
-      hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins, totals, cursor);
-      EFG_LAUNCH_CHECK();
+      if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
+                               kernel_indices, dm, 0, st, &offs, &cursor, &entries, &overflow))
+        return rc;
+    } else if (ws != nullptr && ws_bytes >= sizeof(int)) {
+      EFG_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), st));  // the overflow word is defined whenever a workspace is given
     }
     hipLaunchKernelGGL((box_bwd_kernel<32, false>), dim3((unsigned)ceil_div(total, 32)), dim3(256), 0, st, value,
                        (const long long*)shapes, (const long long*)level_start, ref_windows, offsets, logits,
-                       kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, cursor, entries);
+                       kernel_indices, grad_out, dm, grad_value, grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr,
+                       overflow);
     if (binned) {
       EFG_LAUNCH_CHECK();
       const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);

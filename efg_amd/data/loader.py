@@ -91,7 +91,17 @@ class DeviceLoader:
     def __next__(self):
         if self._served == self.length:
             raise StopIteration
-        item = self._queue.get()
+        while True:   # never block for good: the producer may be gone (close(), or it died without a word)
+            try:
+                item = self._queue.get(timeout=0.2)
+                break
+            except queue.Empty:
+                if self._stop.is_set():
+                    raise StopIteration from None
+                if not self._thread.is_alive() and self._queue.empty():
+                    self._served = self.length
+                    raise RuntimeError("DeviceLoader: the producer thread exited after %d of %d batches without "
+                                       "reporting an error" % (self._served, self.length)) from None
         if isinstance(item, _Failure):
             self._served = self.length
             raise item.exc
@@ -105,7 +115,9 @@ class DeviceLoader:
                 self._queue.get_nowait()
             except queue.Empty:
                 break
-        self._thread.join(timeout=10)
+        self._thread.join(timeout=30)
+        if self._stream is not None and not self._thread.is_alive():
+            self._stream.synchronize()   # nothing of the loader is in flight once close() has returned
 
     def __enter__(self):
         return self

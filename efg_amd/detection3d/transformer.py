@@ -220,24 +220,16 @@ class Transformer(nn.Module):
             was_on = _prof.active()
             _prof._enabled = False  # event records do not belong into the graph (enable() would clear the records)
             try:
-                side, cur = torch.cuda.Stream(device=memory.device), torch.cuda.current_stream(memory.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    for _ in range(2):  # warm-up outside the capture (lazy inits, allocator)
-                        self.decoder_gt(None, None, static[0], static[1], static[2], static[3], static[4])
-                cur.wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                # thread_local: a DeviceLoader thread (data/loader.py) may allocate / launch on its own stream meanwhile
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = self.decoder_gt(None, None, static[0], static[1], static[2], static[3], static[4])
+                from ..hipgraph import capture
+                graph, out = capture(lambda: self.decoder_gt(None, None, static[0], static[1], static[2], static[3],
+                                                             static[4]), memory.device)
             except Exception as exc:  # noqa: BLE001 -- any capture problem: run eagerly from now on, say so once
-                if os.environ.get("EFG_GT_GRAPH_STRICT", "0") == "1":  # tests: a failed capture is a failure
-                    _prof._enabled = was_on
+                _prof._enabled = was_on
+                if os.environ.get("EFG_GT_GRAPH_STRICT", "0") == "1":  # tests/test_gt_graph_gpu.py: a failed capture is a failure
                     raise
                 import warnings
                 warnings.warn("efg_amd: HIP-graph capture of the momentum decoder failed (%s); running it eagerly" % exc)
                 self._gt_graph_off = True
-                _prof._enabled = was_on
                 return self.decoder_gt(None, None, memory, src_shape, src_start_index, gt_proposals, gt_attn_mask)
             _prof._enabled = was_on
             ent = cache[key] = (graph, static, out)

@@ -172,11 +172,6 @@ class FlatGradientAllReduce:
             p.grad = v
 
 
-# iterations of the reference ConQueR run: 6 epochs over the 158 081 Waymo training frames at 6 scenes x 8 GPUs
-# ($CQ/config.yaml:62-64,147-149); Trainer(max_iters=...) overrides it
-REFERENCE_MAX_ITERS = 6 * (158081 // (6 * 8))
-
-
 def build_optimizer(cfg, model):
     """`solver.optimizer.type`: AdamWMulti (ConQueR / Voxel-DETR: per-group rates, $CQ/modules/optimizer.py) or AdamW
     (CenterPoint, efg/solver/optimizers.py:23-40); torch's fused multi-tensor update on the GPU."""
@@ -193,6 +188,26 @@ def build_optimizer(cfg, model):
 
         return CachedFusedAdamW([{"params": params}], **oc)
     return torch.optim.AdamW(params, **oc)
+
+
+def resolve_max_iters(cfg, max_iters=None, iters_per_epoch=None):
+    """Length of the schedule, per CONFIG, as the reference's trainer derives it (efg/engine/trainer.py:158-161:
+    `max_iters = len(dataloader) * lr_scheduler.max_epochs`, written back as lr_scheduler.max_iters / epoch_iters).
+    Precedence: the `max_iters` argument; `solver.lr_scheduler.max_iters`; `max_epochs` x (`iters_per_epoch` argument
+    = len(loader), else `solver.lr_scheduler.epoch_iters` from the YAML).  No silent fallback: a config that gives
+    neither is an error (a ConQueR-sized constant would give CenterPoint's 36-epoch run the wrong rate and momentum)."""
+    if max_iters is not None:
+        return int(max_iters)
+    sc = cfg.solver.get("lr_scheduler") if hasattr(cfg.solver, "get") else None
+    if not sc:
+        return None
+    if sc.get("max_iters"):
+        return int(sc["max_iters"])
+    per_epoch = iters_per_epoch if iters_per_epoch is not None else sc.get("epoch_iters")
+    if sc.get("max_epochs") and per_epoch:
+        return int(sc["max_epochs"]) * int(per_epoch)
+    raise ValueError("solver.lr_scheduler needs max_iters, or max_epochs together with epoch_iters (or pass max_iters= / "
+                     "iters_per_epoch=len(loader) to Trainer): the schedule length cannot be guessed")
 
 
 def build_one_cycle(cfg, optimizer, max_iters):
@@ -220,7 +235,9 @@ class BucketedGradientAllReduce:
     FPN] -> [sparse backbone].  The trigger for the first two is ONE tensor hook each, on the activation that enters
     that part of the model (the projected BEV tokens; the dense BEV maps of the backbone): when its gradient exists,
     every backward node of the part has run and so have their AccumulateGrad nodes (the engine gives those the highest
-    priority); should a gradient of the bucket be missing at that moment it is simply picked up by the final call.
+    priority).  Membership is fixed on the first step (parameters that received a gradient, validated across ranks;
+    that step reduces all three buckets after backward); a member whose gradient is missing later sends zeros, so
+    every rank always issues the same three collectives with the same sizes.
     `reduce()` after backward handles the last bucket and joins the communication stream."""
 
     def __init__(self, model, world):
@@ -228,6 +245,7 @@ class BucketedGradientAllReduce:
         self.flat = FlatGradientAllReduce(model, world)  # (broadcasts the initial parameters)
         self.avg = self.flat.avg
         self.groups = None
+        self.layout = None  # {bucket: (params, flat buffer, views)}, frozen on the first step
         self.comm = None
         self.pending = []
         self.done = set()
@@ -246,24 +264,23 @@ class BucketedGradientAllReduce:
         self.groups = names
 
     def _launch(self, key):
-        """Pack the gradients of bucket `key` that exist and all-reduce them on the communication stream."""
+        """Pack bucket `key` and all-reduce it on the communication stream.  The bucket's membership and layout are FIXED
+        (see _freeze): every rank issues the same collective with the same element count every step; a member without
+        a gradient at this moment contributes zeros."""
         if key in self.done:
             return
-        params = [p for p in self.groups[key] if p.grad is not None]
         self.done.add(key)
+        if self.layout is None:   # first step: nothing is launched from the hooks, reduce() freezes the membership
+            return
+        params, buf, views = self.layout[key]
         if not params:
             return
-        dev = params[0].device
+        dev = buf.device
         main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-        total = sum(p.numel() for p in params)
-        buf = self.__dict__.setdefault("_bufs", {}).get(key)
-        if buf is None or buf.numel() != total:
-            buf = self._bufs[key] = torch.empty(total, dtype=params[0].dtype, device=dev)
-        views, off = [], 0
-        for p in params:
-            views.append(buf[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        torch._foreach_copy_(views, [p.grad for p in params])  # on the compute stream, right behind the producers
+        grads = [p.grad for p in params]
+        if any(g is None for g in grads):
+            grads = [v.zero_() if g is None else g for g, v in zip(grads, views)]
+        torch._foreach_copy_(views, grads)  # on the compute stream, right behind the producers
         if main is not None:
             if self.comm is None:
                 self.comm = torch.cuda.Stream(device=dev)
@@ -273,6 +290,30 @@ class BucketedGradientAllReduce:
         else:
             work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
         self.pending.append((work, buf, params, views))
+
+    def _freeze(self):
+        """First step, after backward: the members of each bucket are the parameters that received a gradient, checked
+        across ranks with a MIN / MAX all-reduce exactly as FlatGradientAllReduce does (ranks that disagreed would issue
+        collectives of different sizes: a hang, or silently mis-paired gradients).  Buffers and views are built once."""
+        named = [(key, p) for key in ("transformer", "neck", "backbone") for p in self.groups[key]]
+        dev = named[0][1].device
+        used = torch.tensor([1.0 if p.grad is not None else 0.0 for _, p in named], device=dev)
+        lo, hi = used.clone(), used.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("BucketedGradientAllReduce: ranks disagree on which parameters receive a gradient "
+                               "(%d parameters); use EFG_DDP_MODE=find_unused" % int((lo != hi).sum()))
+        self.layout = {}
+        for key in ("transformer", "neck", "backbone"):
+            params = [p for p in self.groups[key] if p.grad is not None]
+            total = sum(p.numel() for p in params)
+            buf = torch.empty(total, dtype=params[0].dtype if params else torch.float32, device=dev)
+            views, off = [], 0
+            for p in params:
+                views.append(buf[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.layout[key] = (params, buf, views)
 
     def watch(self, key, tensor):
         """Called by the model hooks installed in Trainer: `tensor` is the activation entering part `key`."""
@@ -288,20 +329,11 @@ class BucketedGradientAllReduce:
 
     @torch.no_grad()
     def reduce(self):
+        if self.layout is None:
+            self._freeze()
+            self.done.clear()
         for key in ("transformer", "neck", "backbone"):  # whatever the hooks did not launch (always: backbone)
             self._launch(key)
-        # gradients that appeared after their bucket was packed (should not happen; correctness does not depend on it)
-        late = [p for key in self.groups for p in self.groups[key]
-                if p.grad is not None and not any(p is q for _, _, ps, _ in self.pending for q in ps)]
-        if late:
-            flat = torch.cat([p.grad.reshape(-1) for p in late])
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM)
-            if not self.avg:
-                flat.div_(self.world)
-            off = 0
-            for p in late:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
         for work, buf, params, views in self.pending:
             work.wait()  # orders the compute stream after the collective (device side)
             if not self.avg:
@@ -317,7 +349,8 @@ class Trainer:
     (efg/engine/trainer.py:278-305, efg/engine/hooks.py:68-81,118-121): zero_grad, forward, sum of the differentiable
     losses, non-finite check, backward, gradient exchange, optional clipping, optimizer step, scheduler step."""
 
-    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None, model_cls=None):
+    def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None, model_cls=None,
+                 iters_per_epoch=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
         if str(cfg.model.device if device is None else device).startswith("cuda"):
             configure_hip_runtime()
@@ -335,7 +368,8 @@ class Trainer:
         self.model = (model_cls or VoxelDETR)(cfg)
         self.model.train()
         self.optimizer = build_optimizer(cfg, self.model)
-        self.lr_scheduler = build_one_cycle(cfg, self.optimizer, max_iters or REFERENCE_MAX_ITERS)
+        self.max_iters = resolve_max_iters(cfg, max_iters, iters_per_epoch)
+        self.lr_scheduler = build_one_cycle(cfg, self.optimizer, self.max_iters)
         gc_cfg = cfg.solver.get("grad_clipper") if hasattr(cfg.solver, "get") else None
         self.grad_clipper = gc_cfg if (gc_cfg and gc_cfg.get("enabled")) else None
         self.anomaly_every = int(os.environ.get("EFG_ANOMALY_EVERY", "50"))

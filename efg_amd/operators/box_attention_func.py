@@ -6,6 +6,7 @@ efg/operators/src/deform_attn/ms_deform_attn.h:22-63); both names run the same H
 (csrc/msda.hip).  fp32 only, like the ConQueR path (`custom_fwd(cast_inputs=torch.float32)`).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -13,6 +14,8 @@ from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
 from .. import _prof
+
+_CHECK_BINS = os.environ.get("EFG_CHECK_BINS", "0") == "1"
 
 
 def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
@@ -187,4 +190,11 @@ class BoxAttnFusedFunction(Function):
                                                             d, l, lq, p, ctx.num_var, L.ptr(grad_value),
                                                             L.ptr(grad_off), L.ptr(grad_logits), L.ptr(ws), ws_bytes,
                                                             L.stream()))
+        if ws is not None and _CHECK_BINS:
+            # first word of the scratch: entries that did not fit the bin box_bin_count_kernel sized for them (a
+            # disagreement between the counting and the writing kernel).  Must be 0; reading it is a sync, so only
+            # the tests (EFG_CHECK_BINS=1) do.
+            dropped = int(ws[:4].view(torch.int32).item())
+            if dropped:
+                raise RuntimeError("box_attn_fused backward: %d binned grad_value entries overflowed their bin" % dropped)
         return grad_value, None, None, None, grad_off, grad_logits, None, None

@@ -246,7 +246,10 @@ int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, co
  * d float atomics per corner; without it, or for small launches, atomics are used.  Same results either way.
  * The encoder's tile kernel (queries = the cells of one map) uses the same scratch for the corners that leave the
  * 16 x 16 window of their query tile; without it those corners are written with d float atomics each (a cliff once the
- * boxes grow with training). */
+ * boxes grow with training).
+ * The first int32 of ws is an overflow counter the call zeroes and the kernels bump when an entry does not fit the
+ * bin the counting pass sized for it (the entry is dropped, never written into a neighbour's bin).  It is 0 unless the
+ * counting and the writing kernel disagree about a corner's cell; the tests read it after every call. */
 size_t efg_box_attn_fused_backward_workspace_bytes(int b, int s, int h, int l, int lq, int p);
 int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                                     const float* ref_windows, const float* offsets, const float* logits,

@@ -6,7 +6,7 @@ loudly when its HIP library is missing.
 
 * ``liboracle.so``      -- our plain-C restatement (``oracle/efg_oracle.c``; every function
   cites the reference file:line it follows).
-* ``_ref/libefg_ref.so`` -- the reference's *own* ``voxelization_cpu.cpp`` compiled in place from
+* ``_ref/libefg_ref.so`` -- the reference's *own* ``voxelization_cpu.cpp`` and ``scatter_points_cpu.cpp`` compiled in place from
   ``/root/reference`` by ``oracle/Makefile`` (git-ignored build output; it travels to the GPU box
   like any other built ``.so``).  Used to pin the restatement and as the ``"reference"`` CPU
   baseline for voxelization.
@@ -60,6 +60,8 @@ def ref():
 
         _REF = ctypes.CDLL(os.path.join(_HERE, "_ref", "libefg_ref.so"))
         _REF.ref_hard_voxelize_cpu.restype = ctypes.c_int
+        if hasattr(_REF, "ref_dynamic_point_to_voxel_run"):
+            _REF.ref_dynamic_point_to_voxel_run.restype = ctypes.c_int
     return _REF
 
 
@@ -144,6 +146,23 @@ def scatter_forward(feats, coors, reduce_type):
                                      _REDUCE[reduce_type], _p(vf, _f32p), _p(vc, _i32p), _p(p2v, _i32p),
                                      _p(cnt, _i32p))
     return vf[:m], vc[:m], p2v, cnt[:m]
+
+
+def ref_dynamic_point_to_voxel(points, coors, voxel_size, coors_range):
+    """The REFERENCE's own CPU grouping (scatter_points_cpu.cpp:62-119, compiled into oracle/_ref): every point of
+    each voxel, voxels in first-occurrence order.  coors i32 [n,3] (z,y,x), all rows inside the grid.
+    Returns (voxels [M, max_points, F] zero padded, voxel_coors [M,3], num_points_per_voxel [M])."""
+    points, coors = _f(points), _i(coors)
+    assert coors.min() >= 0, "the reference kernel indexes its grid with every row: no -1 rows"
+    n, f = points.shape
+    vs, cr = _f(voxel_size), _f(coors_range)
+    mp = ctypes.c_int(0)
+    m = ref().ref_dynamic_point_to_voxel_run(_p(points, _f32p), ctypes.c_long(n), f, _p(coors, _i32p), _p(vs, _f32p),
+                                             _p(cr, _f32p), ctypes.byref(mp))
+    voxels = np.zeros((m, mp.value, f), np.float32)
+    vc, npv = np.zeros((m, 3), np.int32), np.zeros((m,), np.int32)
+    ref().ref_dynamic_point_to_voxel_fetch(_p(voxels, _f32p), _p(vc, _i32p), _p(npv, _i32p))
+    return voxels, vc, npv
 
 
 def scatter_backward(grad_voxel, feats, voxel_feats, p2v, count, reduce_type):

@@ -77,3 +77,103 @@ def test_fused_matches_reference_sequence(dev, case):
     close(q2, q1, "grad query")
     for n in p1:
         close(p2[n], p1[n], n)
+
+
+# ---- fused HIP kernels directly against the CPU oracle (no HIP op on the expected side) ------------------------------
+class _OracleSampling(torch.autograd.Function):
+    """oracle.msda_forward / msda_backward (the C restatement of box_attn_kernel.cuh:274-472, pinned to
+    ms_deform_attn_core_pytorch by tests/test_oracle_msda.py) as a CPU autograd node, so that torch's CPU autograd carries
+    the gradient on through the reference's geometry + softmax ($CQ/modules/box_attention.py:62-115)."""
+
+    @staticmethod
+    def forward(ctx, value, shapes, start, loc, attn):
+        import oracle
+
+        ctx.save_for_backward(value, shapes, start, loc, attn)
+        return torch.from_numpy(oracle.msda_forward(value.numpy(), shapes.numpy(), start.numpy(), loc.numpy(), attn.numpy()))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import oracle
+
+        value, shapes, start, loc, attn = ctx.saved_tensors
+        gv, gl, ga = oracle.msda_backward(value.numpy(), shapes.numpy(), start.numpy(), loc.numpy(), attn.numpy(),
+                                          grad_out.contiguous().numpy())
+        return torch.from_numpy(gv), None, None, torch.from_numpy(gl), torch.from_numpy(ga)
+
+
+def _oracle_case(case, g):
+    H, W, heads, P = 40, 36, 8, 25
+    S = H * W
+    rot = case in ("decoder_rot_binned", "encoder_mixed_rot")
+    nvar = 5 if rot else 4
+    if case.startswith("encoder"):
+        lq = S
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        ref = torch.zeros(2, S, 7)
+        ref[..., 0], ref[..., 1] = (xs / W).reshape(-1), (ys / H).reshape(-1)
+        ref[..., 2] = ref[..., 5] = 0.5
+        if case == "encoder_big":      # 14-cell boxes: nearly every corner leaves the 16x16 tile window (binned path)
+            ref[..., 3] = ref[..., 4] = 0.4
+        else:                          # a mix: most queries stay inside the window, the larger ones straddle it
+            size = torch.rand(2, S, generator=g) ** 2 * 0.5 + 0.04
+            ref[..., 3] = size
+            ref[..., 4] = size * (0.7 + 0.6 * torch.rand(2, S, generator=g))
+        if rot:
+            ref[..., 6] = torch.rand(2, S, generator=g)
+    else:
+        lq = 400                       # 2 * 400 * 8 * 25 * 4 corners > kBinMinEntries: the decoder's binned path
+        ref = torch.rand(2, lq, 7, generator=g)
+        ref[..., 3:5] = ref[..., 3:5] * 0.2 + 0.02
+    value = torch.randn(2, S, heads, 32, generator=g)
+    offsets = torch.randn(2, lq, heads * nvar, generator=g) * 0.5
+    logits = torch.randn(2, lq, heads * P, generator=g)
+    idx = torch.linspace(-2, 2, 5) / 5.0   # any fixed 5 x 5 lattice inside (-0.5, 0.5) will do for this comparison
+    ky, kx = torch.meshgrid(idx, idx, indexing="ij")
+    kidx = torch.stack((kx, ky), -1).reshape(-1, 2).contiguous()
+    return value, ref, offsets, logits, kidx, (H, W, heads, P, rot, nvar, lq)
+
+
+@pytest.mark.parametrize("case", ["encoder_big", "encoder_mixed", "encoder_mixed_rot", "decoder_rot_binned"])
+def test_fused_kernels_match_oracle(dev, oracle_mod, case):
+    """out, grad_value, grad_offsets and grad_logits of the fused kernels (tile backward + the binned out-of-window
+    path, decoder binned path) against the CPU oracle's sampling op chained with the reference geometry in torch-CPU
+    autograd.  The mixed cases assert that a real share of the corners leaves the tile window."""
+    import efg_amd.operators.box_attention_func as baf
+
+    g = torch.Generator().manual_seed(11)
+    value, ref, offsets, logits, kidx, (H, W, heads, P, rot, nvar, lq) = _oracle_case(case, g)
+    shapes, start = torch.tensor([[H, W]]), torch.zeros(1, dtype=torch.int64)
+    gout = torch.randn(2, lq, heads * 32, generator=g)
+
+    # expected: CPU, oracle sampling
+    v_c, o_c, l_c = (t.clone().requires_grad_(True) for t in (value, offsets, logits))
+    grid = baf.box_sampling_grid(ref, o_c, kidx, heads, 1, rot)
+    attn = torch.softmax(l_c.view(2, lq, heads, P), dim=-1).view(2, lq, heads, 1, P)
+    exp = _OracleSampling.apply(v_c, shapes, start, grid, attn)
+    exp.backward(gout)
+
+    if case.startswith("encoder_mixed"):   # how many corners fall outside the 16 x 16 window of their 8 x 8 query tile
+        px = grid.detach()[..., 0] * W - 0.5
+        py = grid.detach()[..., 1] * H - 0.5
+        q = torch.arange(lq)
+        wx0 = ((q % W) // 8 * 8 - 4).view(1, lq, 1, 1, 1)
+        wy0 = ((q // W) // 8 * 8 - 4).view(1, lq, 1, 1, 1)
+        out_of_win = ((torch.floor(px) < wx0) | (torch.floor(px) + 1 > wx0 + 15) | (torch.floor(py) < wy0)
+                      | (torch.floor(py) + 1 > wy0 + 15))
+        frac = float(out_of_win.float().mean())
+        assert 0.03 < frac < 0.5, "the case should mix in-window and out-of-window corners, got %.3f" % frac
+
+    # actual: the fused HIP op
+    v_d, o_d, l_d = (t.to(dev).requires_grad_(True) for t in (value, offsets, logits))
+    out = baf.BoxAttnFusedFunction.apply(v_d, shapes.to(dev), start.to(dev), ref.to(dev), o_d, l_d, kidx.to(dev), nvar)
+    out.backward(gout.to(dev))
+
+    def close(a, b, name, tol):
+        scale = float(b.abs().max()) + 1e-12
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=tol, atol=tol * scale, err_msg=name)
+
+    close(out, exp, "out", 1e-5)
+    close(v_d.grad, v_c.grad, "grad_value", 1e-4)
+    close(o_d.grad, o_c.grad, "grad_offsets", 1e-4)
+    close(l_d.grad, l_c.grad, "grad_logits", 1e-4)

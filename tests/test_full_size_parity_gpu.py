@@ -58,14 +58,18 @@ def test_trajectoryformer_full_size_step(dev, oracle_mod):
                                                 n_objects=60, n_false=20), dev, oracle_mod, rel=2e-4)
 
 
-def test_conquer_full_size_step(dev, oracle_mod):
-    """The headline configuration itself: one 180k-point scene, 1000 queries, 31 loss terms + the gradient norm."""
+@pytest.mark.parametrize("model,queries,scenes", [("conquer", 1000, 1), ("conquer", 900, 1), ("voxeldetr", 1000, 2)])
+def test_conquer_full_size_step(dev, oracle_mod, model, queries, scenes):
+    """The headline configurations themselves (BASELINE.json configs[1], configs[2]): 180k-point scenes, ConQueR with the
+    YAML's 1000 queries and with BASELINE's 900, Voxel-DETR at its batch of 2; every loss term + the gradient norm."""
     from efg_amd.engine import Trainer, synthetic_batch
 
+    cfg = None if model == "conquer" else os.path.join(ROOT, "configs", "voxeldetr_waymo_res18.yaml")
+
     def trainer(d):
-        tr = Trainer(device=d, seed=0, ddp=False, overrides={"model.transformer.num_queries": 1000})
+        tr = Trainer(config=cfg, device=d, seed=0, ddp=False, overrides={"model.transformer.num_queries": queries})
         tr.model.noise_generator = torch.Generator().manual_seed(4321)      # the CDN noise, drawn on the host
         return tr
 
-    _compare(trainer, lambda d: synthetic_batch(1000, 1, n_points=180000, device=d if d.type == "cuda" else None), dev,
-             oracle_mod, rel=1e-4)
+    _compare(trainer, lambda d: synthetic_batch(1000, scenes, n_points=180000, device=d if d.type == "cuda" else None),
+             dev, oracle_mod, rel=1e-4)

@@ -8,6 +8,8 @@ pytestmark = pytest.mark.gpu
 def test_gt_decoder_graph_matches_eager(monkeypatch):
     from efg_amd.engine import Trainer
 
+    # here (and only here) a capture that silently falls back to eager launches is a failure
+    monkeypatch.setenv("EFG_GT_GRAPH_STRICT", "1")
     tr = Trainer(device="cuda:0", overrides={"model.transformer.num_queries": 60}, seed=0)
     t = tr.model.transformer
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -32,3 +34,76 @@ def test_gt_decoder_graph_matches_eager(monkeypatch):
     # with autograd on (not the momentum decoder's situation) the eager path is taken: nothing new is captured
     t._run_gt_decoder(memory, shape, start, props, mask)
     assert t._gt_graph_stats == [1, 2]
+
+
+def _run_child(code):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                          env=dict(os.environ, PYTHONPATH=ROOT))
+
+
+_CYCLE_WITH_GRAPH = """
+import gc, torch
+from efg_amd.hipgraph import capture, CaptureFailed
+x = torch.zeros(1024, device="cuda")
+class Holder: pass
+def make_dead_cycle():                 # what a dropped model leaves behind: a reference cycle that owns a captured graph
+    g, _ = capture(lambda: x + 1, "cuda:0")
+    h = Holder(); h.graph = g; h.me = h
+gc.disable()
+make_dead_cycle()
+"""
+
+
+def test_capture_collects_dead_graphs_before_not_during():
+    """A dead reference cycle owning an older graph must be destroyed BEFORE the next capture starts and the collector
+    must be off during it: on ROCm ~CUDAGraph synchronises the device, which inside a capture throws from a destructor
+    and aborts the process (GPUTEST_r02: rc 134).  In a child process, so that a regression is a named failure."""
+    r = _run_child(_CYCLE_WITH_GRAPH + """
+seen = []
+def region():
+    seen.append(gc.isenabled())
+    gc.collect()                       # stands for an automatic collection falling into the captured region
+    return x * 2
+gc.enable()
+g, y = capture(region, "cuda:0")
+assert seen and not any(seen), seen    # collector off during warm-up and capture
+assert gc.isenabled()                  # and restored afterwards
+g.replay(); torch.cuda.synchronize()
+assert float(y.sum()) == 0.0
+print("CHILD_OK")
+""")
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_failed_capture_restores_the_stream_and_raises_capture_failed():
+    r = _run_child("""
+import torch
+from efg_amd.hipgraph import capture, CaptureFailed
+x = torch.zeros(1024, device="cuda")
+cur = torch.cuda.current_stream()
+calls = []
+def region():
+    calls.append(1)
+    if len(calls) == 3:                # warm-up passes are fine, the captured pass is not
+        return float(x.sum())          # a D2H read-back is illegal inside a capture
+    return x + 1
+try:
+    capture(region, "cuda:0")
+    raise SystemExit("capture of an illegal region did not fail")
+except CaptureFailed as exc:
+    assert exc.__cause__ is not None
+assert torch.cuda.current_stream() == cur          # not left on the capture stream
+assert not torch.cuda.is_current_stream_capturing()
+y = (x + 3).sum().item()                           # the device is usable, eagerly ...
+g, z = capture(lambda: x + 2, "cuda:0")            # ... and for the next capture
+g.replay(); torch.cuda.synchronize()
+assert y == 3 * 1024 and float(z.sum()) == 2 * 1024
+print("CHILD_OK")
+""")
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])

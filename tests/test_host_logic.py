@@ -146,3 +146,23 @@ def test_batched_contrastive_loss_matches_reference_loop():
                                - pos_pair).mean()
         ref = m.contras_loss_coeff * loss / num_gts
         assert float(got[f"loss_contrastive_dec_{li}"]) == pytest.approx(float(ref), rel=1e-5)
+
+
+def test_bench_bare_multi_gpu_command_names_the_missing_devices():
+    """`python bench.py --gpus 8` (no launcher) on a node with fewer devices: a clear message, not a rendezvous hang or
+    an assert about torchrun (the bare command starts its own ranks when the devices exist; GPU test in
+    test_multirank_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    from conftest import ROOT
+
+    n = torch.cuda.device_count() + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EFG_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "needs %d devices" % n in r.stderr, r.stderr[-2000:]

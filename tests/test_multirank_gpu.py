@@ -31,14 +31,33 @@ def _torchrun(script_args, mode):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
 
 
-def test_bench_two_ranks_one_gpu(dev):
-    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "30000", "--queries", "100",
-                   "--scenes", "1", "--no-cpu-baseline", "--profile-steps", "1"], "flat")
+_BENCH_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "30000", "--queries", "100", "--scenes", "1",
+               "--no-cpu-baseline", "--profile-steps", "1"]
+
+
+def _check_line(r):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert line["rccl_ranks"] == 2 and line["dist_backend"] == "gloo"
+
+
+def test_bench_two_ranks_one_gpu(dev):
+    """launched exactly as the driver launches N > 1: under torch.distributed.run"""
+    _check_line(_torchrun(["bench.py"] + _BENCH_ARGS, "flat"))
+
+
+def test_bench_bare_command_starts_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with no launcher in front: bench.py spawns the ranks itself"""
+    env = dict(os.environ, EFG_DIST_BACKEND="gloo", EFG_DDP_MODE="flat", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py"] + _BENCH_ARGS, capture_output=True, text=True, timeout=900, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    _check_line(r)
 
 
 def test_two_rank_gradients_and_parameters_agree(dev):

@@ -60,3 +60,38 @@ def test_empty_and_all_outside(oracle_mod):
     v, c, n = oracle_mod.hard_voxelize(pts, vs, cr, 3, 10)
     assert v.shape[0] == 0
     assert (oracle_mod.dynamic_voxelize(pts, vs, cr) == -1).all()
+
+
+@pytest.mark.parametrize("reduce", ["max", "mean", "sum"])
+def test_scatter_oracle_pinned_to_reference_cpu_grouping(oracle_mod, reduce):
+    """The scatter restatement (oracle_scatter_forward, after scatter_points_cuda.cu:209-290) against the REFERENCE's
+    own CPU grouping dynamic_point_to_voxel_cpu (scatter_points_cpu.cpp:62-119, compiled in place into oracle/_ref):
+    same voxel set, same counts, same membership; max exact, sum / mean vs an fp64 sum of the reference's groups."""
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(5)
+    n, c = 30000, 5
+    pts = np.empty((n, c), np.float32)
+    pts[:, 0:2] = rng.uniform(-10, 10, (n, 2))
+    pts[:, 2] = rng.uniform(-1, 1, n)
+    pts[:, 3:] = rng.standard_normal((n, c - 3))
+    vs, cr = [0.25, 0.25, 0.5], [-10, -10, -1, 10, 10, 1]
+    coors = oracle_mod.dynamic_voxelize(pts, vs, cr, use_ref=True)
+    keep = coors[:, 0] >= 0   # fp32 rounding puts a few points ON the upper range; the reference grouping takes no -1 rows
+    pts, coors = np.ascontiguousarray(pts[keep]), np.ascontiguousarray(coors[keep])
+    groups, vc, npv = oracle_mod.ref_dynamic_point_to_voxel(pts, coors, vs, cr)
+    order = np.lexsort((vc[:, 2], vc[:, 1], vc[:, 0]))
+    groups, vc, npv = groups[order], vc[order], npv[order]
+    vf, ovc, p2v, cnt = oracle_mod.scatter_forward(pts, coors, reduce)
+    assert np.array_equal(ovc, vc)
+    if reduce == "mean":   # the CUDA reference counts only for the mean (scatter_points_cuda.cu:101-133)
+        assert np.array_equal(cnt, npv)
+    assert np.array_equal(vc[p2v], coors)
+    valid = np.arange(groups.shape[1])[None, :, None] < npv[:, None, None]
+    if reduce == "max":
+        assert np.array_equal(vf, np.where(valid, groups, -np.inf).max(1).astype(np.float32))
+    else:
+        exp = groups.astype(np.float64).sum(1)
+        if reduce == "mean":
+            exp = exp / npv[:, None]
+        np.testing.assert_allclose(vf, exp, rtol=1e-5, atol=1e-5)

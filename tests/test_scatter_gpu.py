@@ -126,3 +126,48 @@ def test_forward_backward_vs_torch_unique_scatter_reduce(dev, reduce, n, c):
     vf.backward(torch.from_numpy(g).to(dev))
     ref.backward(torch.from_numpy(g).double())
     np.testing.assert_allclose(f.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _ref_groups(oracle_mod, n, c, seed):
+    """A cloud voxelized by the reference's own dynamic_voxelize_cpu and grouped by the reference's own
+    dynamic_point_to_voxel_cpu (scatter_points_cpu.cpp:62-119; both compiled in place into oracle/_ref): per voxel,
+    ALL its points.  Sorted by linearised key, the order scatter_points_cuda.cu:209-290 and the HIP path emit."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((n, c), np.float32)
+    pts[:, 0:2] = rng.uniform(-10, 10, (n, 2))
+    pts[:, 2] = rng.uniform(-1, 1, n)
+    pts[:, 3:] = rng.standard_normal((n, c - 3))
+    vs, cr = [0.25, 0.25, 0.5], [-10, -10, -1, 10, 10, 1]
+    coors = oracle_mod.dynamic_voxelize(pts, vs, cr, use_ref=True)
+    keep = coors[:, 0] >= 0
+    pts, coors = np.ascontiguousarray(pts[keep]), np.ascontiguousarray(coors[keep])
+    groups, vc, npv = oracle_mod.ref_dynamic_point_to_voxel(pts, coors, vs, cr)
+    order = np.lexsort((vc[:, 2], vc[:, 1], vc[:, 0]))
+    return pts, coors, groups[order], vc[order], npv[order]
+
+
+@pytest.mark.parametrize("reduce", ["max", "mean", "sum"])
+def test_reduce_pinned_to_reference_cpu_grouping(dev, oracle_mod, reduce):
+    """a3 pinned to the REFERENCE: voxel set, per-voxel counts and the reduce over exactly the reference's point groups.
+    max is exact; sum / mean are compared with an fp64 sum of the reference's groups at 1e-5 (fp32 atomics, any order)."""
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from efg_amd.operators.scatter_points import dynamic_point_to_voxel_forward
+
+    pts, coors, groups, vc, npv = _ref_groups(oracle_mod, 40000, 6, seed=21)
+    vf, hvc, p2v, cnt = dynamic_point_to_voxel_forward(torch.from_numpy(pts).to(dev), torch.from_numpy(coors).to(dev),
+                                                       reduce)
+    assert np.array_equal(hvc.cpu().numpy(), vc)
+    if reduce == "mean":   # the CUDA reference counts only for the mean (scatter_points_cuda.cu:101-133)
+        assert np.array_equal(cnt.cpu().numpy(), npv)
+    # every point sits in the voxel the reference put it in
+    assert np.array_equal(vc[p2v.cpu().numpy()], coors)
+    valid = np.arange(groups.shape[1])[None, :, None] < npv[:, None, None]
+    if reduce == "max":
+        exp = np.where(valid, groups, -np.inf).max(1)
+        assert np.array_equal(vf.cpu().numpy(), exp.astype(np.float32))
+    else:
+        exp = groups.astype(np.float64).sum(1)   # padding rows are zero
+        if reduce == "mean":
+            exp = exp / npv[:, None]
+        np.testing.assert_allclose(vf.cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
