@@ -149,6 +149,8 @@ def _lookup(expr, root, stack):
         raise ValueError("config interpolation cycle through ${%s}" % expr)
     cur = root
     for part in expr.split("."):
+        if isinstance(cur, str) and "${" in cur:   # the path runs THROUGH another interpolation (dataset.source.root)
+            cur = _resolve(cur, root, stack + (expr,))
         cur = cur[int(part)] if isinstance(cur, list) else cur[part]
     return _resolve(copy.deepcopy(cur), root, stack + (expr,))
 
@@ -172,8 +174,8 @@ def _expand_env_only(text):
                        text)
 
 
-def load_yaml(path):
-    """One file with its `includes` merged under it and interpolations resolved (efg/config/__init__.py:11-31)."""
+def _load_raw(path):
+    """(the file with its includes merged under it, UNRESOLVED; the top-level keys only the includes define)."""
     with open(path) as f:
         raw = yaml.safe_load(f) or {}
     included = {}
@@ -183,11 +185,18 @@ def load_yaml(path):
             # the reference joins with "./" (the experiment directory is its cwd); fall back to the including file's folder
             inc = inc if os.path.exists(inc) else os.path.join(os.path.dirname(os.path.abspath(path)), inc)
         included = _merge(included, load_yaml(inc))
-    merged = _merge(included, raw)
+    return _merge(included, raw), [k for k in included if k not in raw]
+
+
+def load_yaml(path, edit=None):
+    """One file with its `includes` merged under it and interpolations resolved (efg/config/__init__.py:11-31).
+    edit(tree): optional change of the merged tree BEFORE interpolation."""
+    merged, include_only = _load_raw(path)
+    if edit is not None:
+        edit(merged)
     merged = _resolve(merged, merged)
-    for key in included:   # "known keys to remove": what the include defined only feeds interpolations
-        if key in merged and key not in raw:
-            del merged[key]
+    for key in include_only:   # "known keys to remove": what the include defined only feeds interpolations
+        merged.pop(key, None)
     return merged
 
 
@@ -238,17 +247,23 @@ def _apply_override(root, dotted, value):
 
 
 def load_config(path, overrides=None, defaults=True):
-    """path: this repo's configs/*.yaml or a reference experiment's config.yaml, unchanged.  overrides: {dotted: value}
-    or the reference's `opts` list (`[k1, v1, k2, v2, ...]` / `["k1=v1", ...]`)."""
-    cfg = load_yaml(path)
+    """path: this repo's configs/*.yaml or a reference experiment's config.yaml, unchanged.
+
+    overrides as a dict {dotted: value} (this package's callers): applied to the tree BEFORE interpolation, so
+    `${dataset.pc_range}` inside a processor follows an overridden `dataset.pc_range`.
+    overrides as the reference's `opts` list (`[k1, v1, k2, v2, ...]` / `["k1=v1", ...]`): applied AFTER the merge and
+    the interpolation, values decoded with literal_eval, exactly like Configuration._merge_with_dotlist (:72-147)."""
+    if isinstance(overrides, dict):
+        early = lambda tree: [_apply_override(tree, k, v) for k, v in overrides.items()]  # noqa: E731
+        cfg = load_yaml(path, early)
+        overrides = None
+    else:
+        cfg = load_yaml(path)
     if defaults:
         cfg = _merge(copy.deepcopy(_DEFAULTS), cfg)
     if overrides:
-        if not isinstance(overrides, dict):
-            opts = list(overrides)
-            pairs = [o.split("=", 1) for o in opts] if "=" in opts[0] else list(zip(opts[0::2], opts[1::2]))
-            overrides = dict(pairs)
-        for dotted, value in overrides.items():
+        opts = list(overrides)
+        pairs = [o.split("=", 1) for o in opts] if "=" in opts[0] else list(zip(opts[0::2], opts[1::2]))
+        for dotted, value in pairs:
             _apply_override(cfg, dotted, value)
-        cfg = _resolve(cfg, cfg)
     return to_attr(cfg)
