@@ -123,6 +123,21 @@ def lib_path():
     return _LIB_PATH
 
 
+def _warn_if_stale():
+    """A library older than its sources measures (and tests) yesterday's kernels: say so, loudly, once."""
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    try:
+        built = os.path.getmtime(_LIB_PATH)
+        newer = [f for f in os.listdir(csrc) if os.path.getmtime(os.path.join(csrc, f)) > built + 1.0]
+    except OSError:
+        return
+    if newer:
+        import warnings
+
+        warnings.warn("efg_amd: %s is OLDER than %s -- rebuild with `python -m efg_amd.build`"
+                      % (os.path.basename(_LIB_PATH), ", ".join(sorted(newer)[:4])), RuntimeWarning, stacklevel=3)
+
+
 def lib():
     """Load libefg_hip.so (once).  Raises if it has not been built -- there is no fallback."""
     global _lib
@@ -131,6 +146,7 @@ def lib():
             raise RuntimeError(
                 "efg_amd: %s is missing. Build it with `python -m efg_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback on the product path." % _LIB_PATH)
+        _warn_if_stale()
         _lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)

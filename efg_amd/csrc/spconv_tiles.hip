@@ -20,7 +20,11 @@
 // The prologue is three coalesced loads (rows, neighbour block, masks) -- no ballots, no index arithmetic.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace efg {
 namespace {
@@ -29,14 +33,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChunkRows = 1024;  // rows sorted together (one workgroup of the plan kernel)
 constexpr int kCKt = 64;          // channels per staged chunk
+constexpr int kStreamKMaxGrid = 4096;  // workgroups of a stream-K launch (256 CUs x at most 16)
 
 // ---- plan -------------------------------------------------------------------------------------------------
 // layout of the plan buffer for (m rows, kvol offsets), n_tiles = round_up(m, 1024) / 16:
 //   rows i32 [n_tiles][16] | nb i32 [n_tiles][kvol][16] | vm u32 [n_tiles][32]   (vm[.][31] = active offsets)
+//   | pfx1 i32 [n_tiles + 1] | pfx2 i32 [n_tiles / 2 + 1]
+// pfxR: exclusive prefix sums of the item counts of the units of R consecutive tiles (stream-K, conv_tile_kernel): a
+// unit's items are its active offsets (the union over its tiles); a unit with rows but no offset counts one item, so
+// that its rows are still written.
 struct PlanView {
   int* rows;
   int* nb;
   unsigned* vm;
+  int* pfx1;
+  int* pfx2;
   long long n_tiles;
 };
 
@@ -44,7 +55,7 @@ __host__ __device__ inline long long plan_tiles(long long m) { return (m + kChun
 
 inline size_t plan_bytes(long long m, int kvol) {
   const long long t = plan_tiles(m);
-  return (size_t)t * 16 * 4 + (size_t)t * kvol * 16 * 4 + (size_t)t * 32 * 4;
+  return (size_t)t * 16 * 4 + (size_t)t * kvol * 16 * 4 + (size_t)t * 32 * 4 + (size_t)(t + 1) * 4 + (size_t)(t / 2 + 1) * 4;
 }
 
 inline PlanView plan_view(void* p, long long m, int kvol) {
@@ -53,7 +64,41 @@ inline PlanView plan_view(void* p, long long m, int kvol) {
   v.rows = static_cast<int*>(p);
   v.nb = v.rows + v.n_tiles * 16;
   v.vm = reinterpret_cast<unsigned*>(v.nb + v.n_tiles * kvol * 16);
+  v.pfx1 = reinterpret_cast<int*>(v.vm + v.n_tiles * 32);
+  v.pfx2 = v.pfx1 + v.n_tiles + 1;
   return v;
+}
+
+// one workgroup: pfx[u] = items of the units before u, for units of R tiles (n_tiles is a multiple of 64)
+template <int R>
+__global__ void __launch_bounds__(1024) tile_prefix_kernel(const int* __restrict__ rows, const unsigned* __restrict__ vm,
+                                                            long long n_tiles, int* __restrict__ pfx) {
+  __shared__ int sm[17];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const long long n_units = n_tiles / R;
+  for (long long base = 0; base < n_units; base += 1024) {
+    const long long u = base + threadIdx.x;
+    int items = 0;
+    if (u < n_units) {
+      unsigned cols = 0;
+      bool has_rows = false;
+      for (int s = 0; s < R; ++s) {
+        cols |= vm[(u * R + s) * 32 + 31];
+        has_rows |= rows[(u * R + s) * 16] >= 0;   // a tile's rows are sorted with the padding last
+      }
+      items = max(__popc(cols), has_rows ? 1 : 0);
+    }
+    int tot;
+    const int pre = block_exclusive_scan(items, sm, &tot);
+    const int carry = carry_s;
+    if (u < n_units) pfx[u] = carry + pre;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pfx[n_units] = carry_s;
 }
 
 __global__ void __launch_bounds__(256) tile_plan_kernel(const int* __restrict__ nbr, long long m, int kvol, int* __restrict__ rows,
@@ -128,6 +173,14 @@ struct TileArgs {
   int cin, cout, kvol;
   int c16n, np;
   int pipe, deal, xcd;   // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL, EFG_TILE_XCD)
+  int xp;                // EFG_TILE_XP: weight fragments prefetched across the (column, chunk) step boundary
+  // stream-K (MODE & 2)
+  const int* sk_prefix;  // [ux + 1] exclusive prefix of the units' item counts (from the plan, for this R)
+  float* sk_scratch;     // [grid][R * NT * 256] shares of units that straddle a cut
+  int* sk_flags;         // [grid] epoch of the last share a workgroup published
+  int sk_epoch;
+  int sk_polls;          // polls of a share's flag before the unit is recomputed instead (EFG_TILE_SK_POLLS, default 20000)
+  unsigned ux, uy;       // the unit grid (what gridDim is otherwise)
   long long zero_off;    // byte offset from `in` of 16 zero bytes (absent rows / channel pieces past cin gather those)
   int v4;                // 1: 16-byte gathers, natural-order packed weights (cin % 4 == 0)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
@@ -141,31 +194,28 @@ __device__ float4 g_zero_piece;  // (zero-initialised, never written; not const:
 // (4 rows x 16 pieces per instruction instead of one row), the A tile is stored as 16-byte pieces at slot
 // piece ^ row (conflict-free 16-byte writes and fragment reads without padding) and a lane's four A operands of a
 // 16-channel step come from ONE ds_read_b128.  V4 = 0: the 4-byte path (any channel count).
-template <int NT, int R, int KS, int V4>
-__global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
+template <int NT, int R, int KS, int V4, int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 2) ? (R == 2 ? 4 : 5) : 1)))
+conv_tile_kernel(TileArgs a) {
+  constexpr int XP = MODE & 1;       // weight fragments prefetched across the (column, chunk) step boundary
+  constexpr int SK = (MODE >> 1) & 1;  // stream-K: the (unit, offset) items are cut into equal shares, one per workgroup
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
   constexpr int kAStr = V4 ? kCKt : kCKt + 2;        // LDS row stride of the A tile (V4: swizzled pieces, no padding)
   __shared__ __attribute__((aligned(16))) float a_tile[4][R * 16 * kAStr];  // wave-private A staging
   __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
+  __shared__ int s_redo_flag;                        // stream-K: a share did not arrive in time, recompute the unit
+  int* s_redo = &s_redo_flag;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wt = wv / KS, part = wv % KS;
-  // XCD-aware order: consecutive workgroups (neighbouring sorted chunks re-read the same input rows) on one XCD
-  unsigned bx = blockIdx.x, by = blockIdx.y;
-  {
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
-    if (a.xcd == 1 && per > 0 && lin < (per << 3)) {          // one contiguous range of workgroups per XCD
-      const unsigned nl = (lin & 7) * per + (lin >> 3);
-      bx = nl % gridDim.x;
-      by = nl / gridDim.x;
-    } else if (a.xcd == 2 && per > 0 && lin < (per << 3)) {   // ranges of 64 workgroups dealt round-robin to the XCDs
-      const unsigned blk = lin >> 9, in = lin & 511;           // 512 consecutive ids = 8 XCDs x 64
-      const unsigned nl = blk * 512 + (in & 7) * 64 + (in >> 3);
-      if (blk * 512 + 512 <= (per << 3)) {
-        bx = nl % gridDim.x;
-        by = nl / gridDim.x;
-      }
-    }
-  }
+  // j0 / j1: the ranks (among the unit's active table columns) this call multiplies, [0, 32) = all; g_first: stream-K,
+  // the first workgroup that holds a share of the unit
+  auto body = [&](unsigned bx, unsigned by, int j0, int j1, unsigned g_first) {
+  // stream-K calls this in a loop: launder the lane id per call, or every lane-derived address component of the body
+  // becomes a loop invariant that is hoisted and kept alive across it (+70 VGPRs: two waves per SIMD instead of four)
+  int tid_l = threadIdx.x;
+  if (SK) asm volatile("" : "+v"(tid_l));
+  const int lane = tid_l & 63, wv = tid_l >> 6;
+  const int wt = wv / KS, part = wv % KS;
   const long long t0 = ((long long)bx * WT + wt) * R;  // first 16-row tile of this wave tile
   const bool tile_ok = t0 < a.n_tiles;
   if (KS == 1 && !tile_ok) return;
@@ -194,6 +244,20 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
   unsigned cols = 0;  // table columns any sub-tile of this wave tile needs
 #pragma unroll
   for (int s = 0; s < R; ++s) cols |= (unsigned)__builtin_amdgcn_readlane((int)vmr[s], 31);
+  bool sk_first = true, sk_last = true;
+  if (SK) {   // this workgroup's share of the unit: the active columns of rank [j0, j1)
+    const int ncols = __popc(cols);
+    sk_first = j0 == 0;
+    sk_last = j1 >= ncols;
+    unsigned sub = cols;
+    for (int i = 0; i < j0; ++i) sub &= sub - 1;
+    unsigned keep = 0;
+    for (int i = j0; i < j1 && sub; ++i) {
+      keep |= sub & (0u - sub);
+      sub &= sub - 1;
+    }
+    cols = keep;
+  }
   if (KS > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -204,7 +268,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
     for (int t = 0; t < NT; ++t) {
       float b = 0.0f;
       const int co = (n_tile0 + t) * 16 + (lane & 15);
-      if (a.bias && co < a.cout && part == 0) b = a.bias[co];
+      if (a.bias && co < a.cout && part == 0 && sk_first) b = a.bias[co];
       acc[s][t] = f32x4{b, b, b, b};
     }
 
@@ -271,20 +335,30 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
         for (int j = 0; j < 16; ++j) at[(s * 16 + j) * kAStr + lane] = ((pre_m[s] >> j) & 1u) ? pre[s * 16 + j] : 0.0f;
       }
   };
-  auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
+  // Weight fragments: b_cur always holds the fragment of the NEXT 16-channel step to multiply, loaded one step ahead --
+  // across the (column, chunk) boundary too (XP = 1): the first fragment of a step used to be requested at the top
+  // of compute(), an exposed L2 / Infinity-Cache round trip per step.
+  float4 b_cur[XP ? NT : 1], b_nxt[XP ? NT : 1];
+  auto b_offset = [&](int col, int ch) {
     const int k = a.flip ? (a.kvol - 1 - col) : col;  // weight offset of this table column
     const int c16_lo = ch * (kCKt / 16);
     const int m = lane & 15, kk = lane >> 4;
     // packed weights of (k, c16, n-tile t): 16-byte fragment per lane, 1 KB per n-tile, np * 64 bytes per c16
-    const unsigned boff0 = ((((unsigned)k * (unsigned)a.c16n + (unsigned)c16_lo) * (unsigned)a.np + (unsigned)(n_tile0 * 16 + m)) * 16u +
-                            (unsigned)(kk * 4)) * 4u;
-    const unsigned bstep = (unsigned)a.np * 64u;
-    const int nc = min(kCKt / 16, a.c16n - c16_lo);  // 16-channel steps of this chunk (4 unless the tail)
-    auto load_b = [&](float4* b, int i) {
+    return ((((unsigned)k * (unsigned)a.c16n + (unsigned)c16_lo) * (unsigned)a.np + (unsigned)(n_tile0 * 16 + m)) * 16u +
+            (unsigned)(kk * 4)) * 4u;
+  };
+  const unsigned bstep = (unsigned)a.np * 64u;
+  auto load_b = [&](float4* b, unsigned boff0, int i) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
-    };
+    for (int t = 0; t < NT; ++t)
+      b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
+  };
+  auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1, int col_n, int ch_n, bool more) {
+    const int c16_lo = ch * (kCKt / 16);
+    const int m = lane & 15, kk = lane >> 4;
+    const unsigned boff0 = b_offset(col, ch);
+    const unsigned boff_n = more ? b_offset(col_n, ch_n) : boff0;
+    const int nc = min(kCKt / 16, a.c16n - c16_lo);  // 16-channel steps of this chunk (4 unless the tail)
     auto mfmas = [&](const float4* b, int i) {
 #pragma unroll
       for (int s = 0; s < R; ++s) {
@@ -307,21 +381,43 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
         for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[t].w, acc[s][t], 0, 0, 0);
       }
     };
+    if (XP) {
+      // b_cur = fragment 0 of this step (loaded during the previous step, or before the loop)
+      if (nc == 4) {
+        load_b(b_nxt, boff0, 1);
+        mfmas(b_cur, 0);
+        load_b(b_cur, boff0, 2);
+        mfmas(b_nxt, 1);
+        load_b(b_nxt, boff0, 3);
+        mfmas(b_cur, 2);
+        if (more) load_b(b_cur, boff_n, 0);
+        mfmas(b_nxt, 3);
+      } else {
+        for (int i = 0; i < nc; ++i) {
+          if (i + 1 < nc) load_b(b_nxt, boff0, i + 1);
+          else if (more) load_b(b_nxt, boff_n, 0);
+          mfmas(b_cur, i);
+#pragma unroll
+          for (int t = 0; t < (XP ? NT : 1); ++t) b_cur[t] = b_nxt[t];
+        }
+      }
+      return;
+    }
     // software pipeline over the (up to) four 16-channel steps: the weights of step i+1 are in flight during the
     // MFMAs of step i (they come from L2: ~200+ cycles, a 16-MFMA step is 512)
     float4 b0[NT], b1[NT];
-    load_b(b0, 0);
+    load_b(b0, boff0, 0);
     if (nc == 4 && a.pipe) {
-      load_b(b1, 1);
+      load_b(b1, boff0, 1);
       mfmas(b0, 0);
-      load_b(b0, 2);
+      load_b(b0, boff0, 2);
       mfmas(b1, 1);
-      load_b(b1, 3);
+      load_b(b1, boff0, 3);
       mfmas(b0, 2);
       mfmas(b1, 3);
     } else {
       for (int i = 0; i < nc; ++i) {
-        if (i > 0) load_b(b0, i);
+        if (i > 0) load_b(b0, boff0, i);
         mfmas(b0, i);
       }
     }
@@ -360,6 +456,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
     };
     if (a.deal) advance(c_cur, ch_cur, part);
     gather(c_cur, ch_cur);
+    if (XP) load_b(b_cur, b_offset(c_cur, ch_cur), 0);
     stash(at0);
     unsigned cm0 = pre_m[0], cm1 = pre_m[R - 1];
     for (int s = 0; s < nsteps; ++s) {
@@ -371,7 +468,7 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      compute(at0, c_cur, ch_cur, cm0, cm1);
+      compute(at0, c_cur, ch_cur, cm0, cm1, c_nxt, ch_nxt, more);
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (more) {
@@ -411,6 +508,69 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
       }
     if (part != 0 || !tile_ok) return;
   }
+  if (SK && !(sk_first && sk_last)) {
+    // A shared unit.  Every share but the last is written (raw accumulator layout, 1 KB per register row) to the
+    // workgroup's slot of the scratch and published with a release store of the launch epoch; the workgroup with the
+    // LAST share -- the highest index, so it only ever waits for workgroups dispatched before it -- adds the shares in
+    // workgroup order (a fixed order: the result does not depend on timing) and stores the rows.
+    // Coherence without fences: the shares and the flags are written and read with agent-scope RELAXED atomics (sc1
+    // stores write through the XCD's L2, sc1 loads do not hit its stale lines).  A release / acquire pair would
+    // write back / invalidate the whole L2 of the XCD -- per workgroup, and an acquire per poll of the flag: measured
+    // 30-50x slower than the convolution itself.  Order: the share's stores have completed (s_waitcnt vmcnt(0)) before
+    // the flag is stored; the reader's loads of the share are issued after it has seen the flag.
+    constexpr int kSlot = R * NT * 4 * 64;
+    if (!sk_last) {
+      float* dst = a.sk_scratch + (size_t)blockIdx.x * kSlot + lane;
+#pragma unroll
+      for (int s = 0; s < R; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(dst + ((s * NT + t) * 4 + r) * 64, acc[s][t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(a.sk_flags + blockIdx.x, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    for (unsigned gp = g_first; gp < blockIdx.x; ++gp) {
+      // A share is published by a workgroup dispatched before this one, early in its life and without waiting for
+      // anybody, so this normally does not spin at all.  The bound is for a chip shared with ANOTHER process that
+      // spins too (two ranks on one device): after ~20 ms the unit is recomputed here from scratch instead (s_redo;
+      // the same sum in a different order), so the launch always ends.
+      int ok = 1;
+      if (lane == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(a.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.sk_epoch) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++polls > a.sk_polls) {
+            ok = 0;
+            break;
+          }
+        }
+      }
+      ok = __builtin_amdgcn_readfirstlane(ok);
+      if (!ok) {
+        if (lane == 0) *s_redo = 1;
+        return;
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      const float* src = a.sk_scratch + (size_t)gp * kSlot + lane;
+#pragma unroll
+      for (int s = 0; s < R; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[r] = __hip_atomic_load(src + ((s * NT + t) * 4 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[s][t][r] += v[r];
+          asm volatile("" ::: "memory");   // four loads in flight at a time: the 32 of a share would cost 28 more VGPRs
+        }
+    }
+  }
   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
   for (int s = 0; s < R; ++s)
@@ -424,17 +584,145 @@ __global__ void __launch_bounds__(256) conv_tile_kernel(TileArgs a) {
         if (row >= 0 && co < a.cout) a.out[(long long)row * a.cout + co] = acc[s][t][r];
       }
     }
+  };  // body
+
+  if (!SK) {
+    // XCD-aware order: consecutive workgroups (neighbouring sorted chunks re-read the same input rows) on one XCD
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, total = gridDim.x * gridDim.y, per = total >> 3;
+    if (a.xcd == 1 && per > 0 && lin < (per << 3)) {          // one contiguous range of workgroups per XCD
+      const unsigned nl = (lin & 7) * per + (lin >> 3);
+      bx = nl % gridDim.x;
+      by = nl / gridDim.x;
+    } else if (a.xcd == 2 && per > 0 && lin < (per << 3)) {   // ranges of 64 workgroups dealt round-robin to the XCDs
+      const unsigned blk = lin >> 9, in = lin & 511;           // 512 consecutive ids = 8 XCDs x 64
+      const unsigned nl = blk * 512 + (in & 7) * 64 + (in >> 3);
+      if (blk * 512 + 512 <= (per << 3)) {
+        bx = nl % gridDim.x;
+        by = nl / gridDim.x;
+      }
+    }
+    body(bx, by, 0, 32, 0u);
+    return;
+  }
+  // Stream-K.  A (16R-row tile group, n-slice) unit costs its number of active offsets (8 .. 27 on a submanifold
+  // level) and the levels have 2-6 units per CU: with one unit per workgroup the launch lasts as long as the CU that
+  // drew the most, heaviest units (PMC, res4: waves alive 63 % of the kernel's cycles, the matrix pipe 82 % busy
+  // while they are; scripts/tile_density.py models the same 0.65-0.70).  Here the launch is as many workgroups as the
+  // chip holds at once, and the list of (unit, active offset) items -- prefix sums of the units' offset counts come
+  // with the plan -- is cut into equal shares.  A unit that straddles a cut is summed by the workgroup holding its last
+  // share (see the epilogue of body).
+  static_assert(!SK || KS == 4, "stream-K: one unit per workgroup");
+  const int* P = a.sk_prefix;                       // [units_x + 1] exclusive prefix of the units' item counts
+  const long long C = P[a.ux], T = C * (long long)a.uy;
+  // (fewer items than workgroups: the surplus workgroups leave; every remaining one owns at least one item, so a
+  // workgroup never waits for a share nobody writes)
+  const unsigned G = (unsigned)min((long long)gridDim.x, T), g = blockIdx.x;
+  if (g >= G) return;
+  auto lo_of = [&](unsigned gg) { return (long long)(((unsigned long long)gg * (unsigned long long)T) / G); };
+  auto unit_of = [&](long long x) {                 // largest w with P[w] <= x (x < C): 64-ary search, wave-uniform
+    unsigned lo = 0, hi = a.ux;                     // invariant: P[lo] <= x < P[hi]
+    while (hi - lo > 1) {
+      const unsigned span = hi - lo, step = (span + 63) / 64;
+      const unsigned pos = min(lo + (unsigned)(lane + 1) * step, hi);
+      const bool le = pos < hi ? ((long long)P[pos] <= x) : false;
+      const unsigned long long bal = __ballot(le);
+      const int nle = __popcll(bal);                // lanes are monotone: the first nle probes are <= x
+      const unsigned nlo = nle ? min(lo + (unsigned)nle * step, hi) : lo;
+      const unsigned nhi = min(lo + (unsigned)(nle + 1) * step, hi);
+      lo = nlo;
+      hi = nhi;
+    }
+    return lo;
+  };
+  // The share is walked from its END to its start.  The unit at the end (it continues in workgroup g + 1) comes
+  // first, so its share is published early in this workgroup's life; the unit at the start -- where this workgroup may
+  // hold the last share and has to collect the others -- comes last, when the workgroups before it have long
+  // published theirs.  (Walked forwards, workgroup g would wait at its first unit for the LAST thing workgroup g - 1
+  // does, which waits for g - 2, ...: the launch serialises -- measured 15-20x slower.)
+  if (threadIdx.x == 0) *s_redo = 0;
+  __syncthreads();
+  const long long lo_i = lo_of(g);
+  long long e = lo_of(g + 1);                       // exclusive end of what is left
+  long long y = (e - 1) / C;
+  unsigned w = unit_of((e - 1) - y * C);
+  bool redo = false;
+  while (e > lo_i) {
+    const long long base = y * C + P[w];            // first item of the unit
+    const int n = P[w + 1] - P[w];
+    const int j1 = (int)(e - base);
+    const int j0 = (int)max(0ll, lo_i - base);
+    unsigned g_first = g;
+    if (j0 > 0) {                                   // the workgroup that holds the unit's first item
+      long long cand = (long long)(((unsigned long long)base * G) / (unsigned long long)T);
+      while (cand + 1 <= (long long)g && lo_of((unsigned)cand + 1) <= base) ++cand;
+      while (cand > 0 && lo_of((unsigned)cand) > base) --cand;
+      g_first = (unsigned)cand;
+    }
+    body(w, (unsigned)y, redo ? 0 : j0, redo ? n : min(j1, n), g_first);
+    __syncthreads();
+    if (!redo && *s_redo) {                         // (uniform: read after the barrier) once more: the whole unit, alone
+      __syncthreads();
+      if (threadIdx.x == 0) *s_redo = 0;
+      redo = true;
+      continue;
+    }
+    redo = false;
+    e = base + j0;
+    if (e > lo_i) {                                 // on to the previous unit that has items (e > 0: there is one)
+      do {
+        if (w == 0) {
+          w = a.ux;
+          --y;
+        }
+        --w;
+      } while (P[w + 1] == P[w]);
+    }
+    __syncthreads();  // the LDS tiles are reused by the next unit
+  }
+}
+
+// workgroups of `kernel` one CU holds at once (LDS / VGPR bound), x the CUs of the device
+template <typename K>
+int resident_workgroups(K kernel) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  return per_cu * cus;
+}
+
+template <int NT, int R, int KS, int V4, int MODE>
+void launch_tiles_k(TileArgs a, unsigned gx, unsigned gy, hipStream_t stream) {
+  if (MODE & 2) {
+    static const int resident = resident_workgroups(conv_tile_kernel<NT, R, KS, V4, MODE>);
+    a.ux = gx;
+    a.uy = gy;
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, KS, V4, MODE>), dim3((unsigned)std::min(resident, kStreamKMaxGrid)), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((conv_tile_kernel<NT, R, KS, V4, MODE>), dim3(gx, gy), dim3(256), 0, stream, a);
+  }
+}
+
+template <int NT, int R, int V4, int MODE>
+void launch_tiles_x(const TileArgs& a, int ny, int ks, hipStream_t stream) {
+  const long long wave_tiles = (a.n_tiles + R - 1) / R;
+  // (stream-K exists for the split-K shape only: one unit per workgroup)
+  if (ks == 4) launch_tiles_k<NT, R, 4, V4, MODE>(a, (unsigned)wave_tiles, ny, stream);
+  else if (ks == 2) launch_tiles_k<NT, R, 2, V4, MODE & 1>(a, (unsigned)ceil_div(wave_tiles, 2), ny, stream);
+  else launch_tiles_k<NT, R, 1, V4, MODE & 1>(a, (unsigned)ceil_div(wave_tiles, 4), ny, stream);
 }
 
 template <int NT, int R, int V4>
 void launch_tiles_v(const TileArgs& a, int ny, int ks, hipStream_t stream) {
-  const long long wave_tiles = (a.n_tiles + R - 1) / R;
-  if (ks == 4) {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 4, V4>), dim3((unsigned)wave_tiles, ny), dim3(256), 0, stream, a);
-  } else if (ks == 2) {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 2, V4>), dim3((unsigned)ceil_div(wave_tiles, 2), ny), dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((conv_tile_kernel<NT, R, 1, V4>), dim3((unsigned)ceil_div(wave_tiles, 4), ny), dim3(256), 0, stream, a);
+  // the experimental modes exist for the 64-channel-wide wave tiles with 4-byte gathers only (the default shapes)
+  constexpr bool kModes = (NT == 4 && V4 == 0);
+  const int mode = kModes ? ((a.xp ? 1 : 0) | (a.sk_scratch && ks == 4 ? 2 : 0)) : 0;
+  switch (mode) {
+    case 1: launch_tiles_x<NT, R, V4, kModes ? 1 : 0>(a, ny, ks, stream); break;
+    case 2: launch_tiles_x<NT, R, V4, kModes ? 2 : 0>(a, ny, ks, stream); break;
+    case 3: launch_tiles_x<NT, R, V4, kModes ? 3 : 0>(a, ny, ks, stream); break;
+    default: launch_tiles_x<NT, R, V4, 0>(a, ny, ks, stream); break;
   }
 }
 
@@ -463,6 +751,33 @@ void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* n
   *r_out = r;
   *ks_out = ks;
   *pipe_out = pipe_env >= 0 ? pipe_env : (r == 2 ? 1 : 0);
+}
+
+// Stream-K scratch per (device, stream): kernels of one stream are serialised, so they can share it.  Allocated on first
+// use, kept for the life of the process (a few MB).  The flags are monotonic: a launch publishes its own epoch.
+struct StreamKState {
+  float* scratch = nullptr;
+  int* flags = nullptr;
+  int epoch = 0;
+};
+
+int streamk_for_stream(hipStream_t stream, StreamKState** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, StreamKState> pool;
+  int dev = 0;
+  EFG_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, stream);
+  auto it = pool.find(key);
+  if (it == pool.end()) {
+    StreamKState st;
+    EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.scratch), (size_t)kStreamKMaxGrid * 2 * 4 * 256 * sizeof(float)));
+    EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.flags), (size_t)kStreamKMaxGrid * sizeof(int)));
+    EFG_HIP_TRY(hipMemset(st.flags, 0, (size_t)kStreamKMaxGrid * sizeof(int)));
+    it = pool.emplace(key, st).first;
+  }
+  *out = &it->second;
+  return EFG_OK;
 }
 
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
@@ -521,6 +836,27 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.deal = deal_env;
   static const int xcd_env = getenv("EFG_TILE_XCD") ? atoi(getenv("EFG_TILE_XCD")) : 1;
   a.xcd = xcd_env;
+  static const int xp_env = getenv("EFG_TILE_XP") ? atoi(getenv("EFG_TILE_XP")) : 0;
+  a.xp = xp_env;
+  // Stream-K (see the kernel): on by default where it was measured to win -- the 64-channel-wide split-K shape on
+  // submanifold tables (every level: -3 % at 64 channels, -5 % at 128, -9 % at 256) and on the strided tables with
+  // at least 128 channels on both sides (-11 %); the other strided tables lose with it (short units, many of them).
+  static const int sk_env = getenv("EFG_TILE_STREAMK") ? atoi(getenv("EFG_TILE_STREAMK")) : 1;
+  static const int sk_polls_env = getenv("EFG_TILE_SK_POLLS") ? atoi(getenv("EFG_TILE_SK_POLLS")) : 20000;
+  a.sk_prefix = nullptr;
+  a.sk_scratch = nullptr;
+  a.sk_flags = nullptr;
+  a.sk_epoch = 0;
+  a.ux = a.uy = 0;
+  a.sk_polls = sk_polls_env;
+  if (sk_env && nt == 4 && ks == 4 && !a.v4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
+    StreamKState* st = nullptr;
+    if (int rc = streamk_for_stream(stream, &st)) return rc;
+    a.sk_prefix = r == 2 ? pv.pfx2 : pv.pfx1;
+    a.sk_scratch = st->scratch;
+    a.sk_flags = st->flags;
+    a.sk_epoch = ++st->epoch;   // (under the caller's serialisation of the stream)
+  }
   if (r == 2) {
     switch (nt) {
       case 4: launch_tiles<4, 2>(a, ny, ks, stream); break;
@@ -557,6 +893,8 @@ extern "C" int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, voi
   const PlanView pv = plan_view(plan, m, kvol);
   hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)ceil_div(m, kChunkRows)), dim3(256), 0, stream, nbr, (long long)m, kvol,
                      pv.rows, pv.nb, pv.vm);
+  hipLaunchKernelGGL(tile_prefix_kernel<1>, dim3(1), dim3(1024), 0, stream, pv.rows, pv.vm, pv.n_tiles, pv.pfx1);
+  hipLaunchKernelGGL(tile_prefix_kernel<2>, dim3(1), dim3(1024), 0, stream, pv.rows, pv.vm, pv.n_tiles, pv.pfx2);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

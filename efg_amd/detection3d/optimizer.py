@@ -43,6 +43,10 @@ class CachedFusedAdamW(torch.optim.AdamW):
                 self._plan = None  # the set of trained parameters changed: let torch sort it out
                 return super().step()
             todo.append((group, params, grads, exp_avgs, exp_avg_sqs, steps))
+        # `found_inf` (set by the Trainer: a 1-element device tensor, 1.0 when this step's loss is not finite): the
+        # fused kernel then leaves parameters and moments untouched, and the step counters are taken back -- the same
+        # device-side guard GradScaler uses; no read-back
+        found_inf = getattr(self, "found_inf", None)
         for group, params, grads, exp_avgs, exp_avg_sqs, steps in todo:
             if not params:
                 continue
@@ -50,7 +54,9 @@ class CachedFusedAdamW(torch.optim.AdamW):
             torch._foreach_add_(steps, 1)
             torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group["lr"],
                                 beta1=beta1, beta2=beta2, weight_decay=group["weight_decay"], eps=group["eps"],
-                                maximize=False, grad_scale=None, found_inf=None)
+                                maximize=False, grad_scale=None, found_inf=found_inf)
+            if found_inf is not None:
+                torch._foreach_sub_(steps, [found_inf.reshape(()).to(steps[0].dtype)] * len(steps))
         return None
 
 

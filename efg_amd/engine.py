@@ -470,6 +470,13 @@ class Trainer:
             loss_dict = self.wrapped(batch)
             # one stack + sum instead of 31 chained scalar adds (and as many backward nodes)
             losses = torch.stack([v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad]).sum()
+        if losses.device.type == "cpu":
+            if not bool(torch.isfinite(losses)):   # the reference's check (trainer.py:307-311); free on the host
+                raise FloatingPointError("Loss became infinite or NaN at iteration=%d!" % self._steps)
+        elif hasattr(self.optimizer, "_plan"):
+            # on the GPU the error is REPORTED every `anomaly_every` steps (_check_anomaly), but a non-finite step never
+            # reaches the weights: the fused AdamW skips its update on a device-side flag
+            self.optimizer.found_inf = torch.logical_not(torch.isfinite(losses.detach())).to(torch.float32).reshape(1)
         with record_function("efg::backward"):
             losses.backward()
             if self.grad_sync is not None:

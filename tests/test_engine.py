@@ -94,3 +94,34 @@ def test_grad_clipper_norm(oracle_mod):
     with cpu_backend.install():
         tr.step(_batch())
     assert seen["norm"] <= 0.5 * (1 + 1e-4)
+
+
+@pytest.mark.gpu
+def test_non_finite_step_never_reaches_the_weights_gpu(dev):
+    """On the GPU the non-finite-loss error is reported at the next periodic check (no per-step read-back), but the
+    update itself is skipped on the device: parameters, Adam moments and step counters after a NaN step are those of
+    before it."""
+    from efg_amd.engine import Trainer
+
+    ov = {"model.transformer.num_queries": 40, "model.transformer.enc_layers": 1,
+          "dataset.pc_range": [-12.8, -12.8, -2.0, 12.8, 12.8, 4.0]}
+    tr = Trainer(device=dev, overrides=ov, seed=0, ddp=False, max_iters=10)
+    batch = [({"points": b[0]["points"].to(dev)}, b[1]) for b in _batch()]
+    tr.step(batch)                                   # a clean step (also the always-checked first one)
+    before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    state = tr.optimizer.state[next(iter(tr.model.transformer.decoder.parameters()))]
+    m_before, s_before = state["exp_avg"].clone(), state["step"].clone()
+    with torch.no_grad():
+        saved = tr.model.projector[0].weight.clone()
+        tr.model.projector[0].weight.fill_(float("nan"))   # contrastive terms NaN: matching stays feasible, loss is NaN
+    tr.step(batch)                                   # step 2: not a checked step -> no exception yet
+    torch.cuda.synchronize()
+    for n, p in tr.model.named_parameters():
+        if n == "projector.0.weight" or ".decoder_gt." in n:   # (the momentum decoder is an EMA updated in forward)
+            continue
+        assert torch.equal(p.detach(), before[n]), n
+    assert torch.equal(state["exp_avg"], m_before) and torch.equal(state["step"], s_before)
+    with torch.no_grad():
+        tr.model.projector[0].weight.copy_(saved)
+    with pytest.raises(FloatingPointError):          # ... and the failure is still reported
+        tr.close()
