@@ -69,12 +69,14 @@ inline PlanView plan_view(void* p, long long m, int kvol) {
   return v;
 }
 
-// one workgroup: pfx[u] = items of the units before u, for units of R tiles (n_tiles is a multiple of 64)
-template <int R>
+// pfx[u] = items of the units before u, for units of R tiles (n_tiles is a multiple of 64).  Two workgroups, one launch:
+// blockIdx.x = 0 -> R = 1 (pfx1), 1 -> R = 2 (pfx2).
 __global__ void __launch_bounds__(1024) tile_prefix_kernel(const int* __restrict__ rows, const unsigned* __restrict__ vm,
-                                                            long long n_tiles, int* __restrict__ pfx) {
+                                                            long long n_tiles, int* __restrict__ pfx1, int* __restrict__ pfx2) {
   __shared__ int sm[17];
   __shared__ int carry_s;
+  const int R = blockIdx.x + 1;
+  int* pfx = blockIdx.x ? pfx2 : pfx1;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const long long n_units = n_tiles / R;
@@ -893,8 +895,7 @@ extern "C" int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, voi
   const PlanView pv = plan_view(plan, m, kvol);
   hipLaunchKernelGGL(tile_plan_kernel, dim3((unsigned)ceil_div(m, kChunkRows)), dim3(256), 0, stream, nbr, (long long)m, kvol,
                      pv.rows, pv.nb, pv.vm);
-  hipLaunchKernelGGL(tile_prefix_kernel<1>, dim3(1), dim3(1024), 0, stream, pv.rows, pv.vm, pv.n_tiles, pv.pfx1);
-  hipLaunchKernelGGL(tile_prefix_kernel<2>, dim3(1), dim3(1024), 0, stream, pv.rows, pv.vm, pv.n_tiles, pv.pfx2);
+  hipLaunchKernelGGL(tile_prefix_kernel, dim3(2), dim3(1024), 0, stream, pv.rows, pv.vm, pv.n_tiles, pv.pfx1, pv.pfx2);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
