@@ -13,12 +13,22 @@ batches ahead; each sample leaves with its batch's `ready_event` recorded on tha
 CenterPoint / TrajectoryFormer wait on before their first kernel (operators/voxelize.py `wait_for_points`), so no stream
 ever waits for the host.
 One producer thread (not a pool) keeps the reference's NumPy random stream in order: sample i draws before sample
-i+1, as with num_workers=0.  The model's own NumPy draws, if any, must use their own generator.
+i+1, as with num_workers=0.  The model's own NumPy draws, if any, must use their own generator or hold
+`NUMPY_GLOBAL_RNG_LOCK` (below).
 """
 import queue
 import threading
 
 import torch
+
+
+# The reference's processors (and their mirrors here: gpu_pipeline.py, gt_database.py, tracking/aug.py,
+# TrajectoryFormer.prepare) draw from NumPy's GLOBAL generator, some of them rewinding it with get_state / set_state --
+# kept, because the goldens pin exactly those draws.  The producer thread holds this lock while it makes a batch;
+# anything else in the process that uses the global generator while a DeviceLoader is alive (none of this package's
+# model code does: CDN noise is a torch.Generator, the synthetic scenes use default_rng) must take it too, or use its
+# own np.random.Generator.
+NUMPY_GLOBAL_RNG_LOCK = threading.RLock()
 
 
 class _Failure:
@@ -56,11 +66,12 @@ class DeviceLoader:
 
     def _make(self, b):
         batch = []
-        for i in range(b * self.batch_size, (b + 1) * self.batch_size):
-            if self._stop.is_set():
-                return None
-            batch.append(self.produce(i))
-        return self.collate(batch) if self.collate is not None else batch
+        with NUMPY_GLOBAL_RNG_LOCK:
+            for i in range(b * self.batch_size, (b + 1) * self.batch_size):
+                if self._stop.is_set():
+                    return None
+                batch.append(self.produce(i))
+            return self.collate(batch) if self.collate is not None else batch
 
     def _work(self):
         try:

@@ -19,7 +19,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             m = re.match(r"conv_fwd_kernel<(\d+), \d+(, \d+)?>$", name)
             if m:
                 name = "conv_fwd_kernel<%s>" % m.group(1)
-            m = re.match(r"conv_tile_kernel<(\d+), \d+, \d+(, \d+)?>$", name)  # <NT, R, KS[, V4]>: bench.py labels by NT
+            m = re.match(r"conv_tile_kernel<(\d+), \d+, \d+(, \d+){0,2}>$", name)  # <NT, R, KS[, V4[, MODE]]>: bench.py labels by NT
             if m:
                 name = "conv_tile_kernel<%s>" % m.group(1)
             v = vals.setdefault(name, {})
