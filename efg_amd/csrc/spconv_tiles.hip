@@ -211,7 +211,7 @@ conv_tile_kernel(TileArgs a) {
   const int wt = wv / KS, part = wv % KS;
   // j0 / j1: the ranks (among the unit's active table columns) this call multiplies, [0, 32) = all; g_first: stream-K,
   // the first workgroup that holds a share of the unit
-  auto body = [&](unsigned bx, unsigned by, int j0, int j1, unsigned g_first) {
+  auto body = [&](unsigned bx, unsigned by, int j0, int j1, unsigned g_first, unsigned sk_pos) {
   // stream-K calls this in a loop: launder the lane id per call, or every lane-derived address component of the body
   // becomes a loop invariant that is hoisted and kept alive across it (+70 VGPRs: two waves per SIMD instead of four)
   int tid_l = threadIdx.x;
@@ -522,7 +522,7 @@ conv_tile_kernel(TileArgs a) {
     // the flag is stored; the reader's loads of the share are issued after it has seen the flag.
     constexpr int kSlot = R * NT * 4 * 64;
     if (!sk_last) {
-      float* dst = a.sk_scratch + (size_t)blockIdx.x * kSlot + lane;
+      float* dst = a.sk_scratch + (size_t)sk_pos * kSlot + lane;
 #pragma unroll
       for (int s = 0; s < R; ++s)
 #pragma unroll
@@ -532,10 +532,10 @@ conv_tile_kernel(TileArgs a) {
             __hip_atomic_store(dst + ((s * NT + t) * 4 + r) * 64, acc[s][t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) __hip_atomic_store(a.sk_flags + blockIdx.x, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(a.sk_flags + sk_pos, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    for (unsigned gp = g_first; gp < blockIdx.x; ++gp) {
+    for (unsigned gp = g_first; gp < sk_pos; ++gp) {
       // A share is published by a workgroup dispatched before this one, early in its life and without waiting for
       // anybody, so this normally does not spin at all.  The bound is for a chip shared with ANOTHER process that
       // spins too (two ranks on one device): after ~20 ms the unit is recomputed here from scratch instead (s_redo;
@@ -604,7 +604,7 @@ conv_tile_kernel(TileArgs a) {
         by = nl / gridDim.x;
       }
     }
-    body(bx, by, 0, 32, 0u);
+    body(bx, by, 0, 32, 0u, 0u);
     return;
   }
   // Stream-K.  A (16R-row tile group, n-slice) unit costs its number of active offsets (8 .. 27 on a submanifold
@@ -619,8 +619,16 @@ conv_tile_kernel(TileArgs a) {
   const long long C = P[a.ux], T = C * (long long)a.uy;
   // (fewer items than workgroups: the surplus workgroups leave; every remaining one owns at least one item, so a
   // workgroup never waits for a share nobody writes)
-  const unsigned G = (unsigned)min((long long)gridDim.x, T), g = blockIdx.x;
-  if (g >= G) return;
+  const unsigned G = (unsigned)min((long long)gridDim.x, T);
+  if (blockIdx.x >= G) return;
+  // Position of this workgroup in the item list: XCD x (= blockIdx.x & 7, the hardware deals workgroups round-robin)
+  // takes the x-th contiguous eighth, so that the neighbouring chunks' input rows and a layer's weights are fetched by
+  // ONE L2 instead of all eight (FETCH_SIZE per launch 58 -> 2x MB with positions = blockIdx).  The workgroup before
+  // position g is then blockIdx - 8 -- dispatched earlier on the same XCD -- except at the 7 range boundaries, where
+  // it is a later-dispatched one: fine while all workgroups are resident (the grid is sized for that), and covered by
+  // the bounded wait otherwise.
+  const unsigned per8 = G >> 3;
+  const unsigned g = blockIdx.x < (per8 << 3) ? (blockIdx.x & 7) * per8 + (blockIdx.x >> 3) : blockIdx.x;
   auto lo_of = [&](unsigned gg) { return (long long)(((unsigned long long)gg * (unsigned long long)T) / G); };
   auto unit_of = [&](long long x) {                 // largest w with P[w] <= x (x < C): 64-ary search, wave-uniform
     unsigned lo = 0, hi = a.ux;                     // invariant: P[lo] <= x < P[hi]
@@ -661,7 +669,7 @@ conv_tile_kernel(TileArgs a) {
       while (cand > 0 && lo_of((unsigned)cand) > base) --cand;
       g_first = (unsigned)cand;
     }
-    body(w, (unsigned)y, redo ? 0 : j0, redo ? n : min(j1, n), g_first);
+    body(w, (unsigned)y, redo ? 0 : j0, redo ? n : min(j1, n), g_first, g);
     __syncthreads();
     if (!redo && *s_redo) {                         // (uniform: read after the barrier) once more: the whole unit, alone
       __syncthreads();

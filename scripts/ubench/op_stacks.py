@@ -28,5 +28,6 @@ for e in prof.events():
             key = (e.name, str(e.input_shapes)[:110], "bwd" if e.thread != prof.events()[0].thread else "fwd")
             agg[key][0] += 1
             agg[key][1] += k.duration
-for (name, shapes, th), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print("%7.1f us total %3d x  %-28s %s" % (us, n, name, shapes))
+top = int(os.environ.get("OP_STACKS_TOP", "40"))
+for (name, shapes, th), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+    print("%7.1f us total %3d x  %s %-28s %s" % (us, n, th, name, shapes))
