@@ -13,6 +13,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace efg {
 namespace {
@@ -395,15 +396,31 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
 //
 // G and W share one LDS buffer (pass A reads G, pass B rebuilds the geometry and fills W).  Sampling points
 // that leave the window (boxes grown past R = 4 cells) take a per-channel global path, as before.
+// Tile geometry of box_bwd_tile_kernel: TQY x 8 queries of one head, the window of R cells around them.
+//   TQY = 8: 64 queries, 16 x 16 window, 512 threads, 132 KB of LDS -> ONE workgroup per CU, all of its waves in the same
+//            phase (the round-2 kernel);
+//   TQY = 4: 32 queries, 12 x 16 window, 256 threads,  68 KB of LDS -> TWO workgroups per CU, whose phases (MFMA / LDS
+//            scatter / global flush) overlap; 1.5x the halo cells per query.
+template <int TQY_>
+struct BT {
+  static constexpr int TQY = TQY_, TQX = 8, R = 4, WINY = TQY + 2 * R, WINX = TQX + 2 * R, NQ = TQY * TQX, NC = WINY * WINX, D = 32;
+  static constexpr int VS = 36;        // row stride of V / GO tiles (floats, 16-byte aligned rows)
+  static constexpr int GS = NC + 4;    // G[q][cell]
+  static constexpr int WS = NQ + 4;    // W[cell][q]
+  static constexpr int kThreads = NQ * 8;
+  static constexpr int kGW = (NQ * GS > NC * WS) ? NQ * GS : NC * WS;
+  static constexpr int NW = kThreads / 64, MB = NQ / 16, NB = NC / 16;   // waves, 16-query blocks, 16-cell blocks
+  static constexpr int WPM = NW / MB, NBW = NB / WPM, CBW = NB / NW;     // S1: waves per query block, cell blocks per wave; S5
+  static_assert(MB * WPM == NW && WPM * NBW == NB && NW * CBW == NB && NBW % 2 == 0, "tile shape does not divide over the waves");
+};
 namespace bt {
-constexpr int TQ = 8, R = 4, WIN = TQ + 2 * R, NQ = TQ * TQ, NC = WIN * WIN, D = 32;
-constexpr int VS = 36;    // row stride of V / GO tiles (floats, 16-byte aligned rows)
-constexpr int GS = 260;   // G[q][cell]
-constexpr int WS = 68;    // W[cell][q]
 constexpr int PMAX = 32;  // L * P of the fused encoder path
-constexpr int kThreads = 512;
-constexpr int kGW = (NQ * GS > NC * WS) ? NQ * GS : NC * WS;
-constexpr size_t kLdsBytes = sizeof(float) * (NC * VS + NQ * VS + kGW + 2 * NQ * PMAX + 2 * PMAX);
+constexpr int TQX = 8, R = 4;
+template <int TQY>
+constexpr size_t lds_bytes() {
+  using B = BT<TQY>;
+  return sizeof(float) * (B::NC * B::VS + B::NQ * B::VS + B::kGW + 2 * B::NQ * PMAX + 2 * PMAX);
+}
 }  // namespace bt
 
 template <int K>
@@ -414,14 +431,17 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(bt::kThreads)
+template <int TQY>
+__global__ void __launch_bounds__(BT<TQY>::kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
                     const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ logits,
                     const float* __restrict__ kidx, const float* __restrict__ grad_out, BoxDims dm,
                     float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits,
                     int* __restrict__ cursor, int2* __restrict__ entries, const int* __restrict__ bin_end,
                     int* __restrict__ overflow) {
-  using namespace bt;
+  using B = BT<TQY>;
+  constexpr int TQX = B::TQX, R = B::R, WINY = B::WINY, WINX = B::WINX, NQ = B::NQ, NC = B::NC, D = B::D, VS = B::VS, GS = B::GS,
+                WS = B::WS, kThreads = B::kThreads, kGW = B::kGW, PMAX = bt::PMAX;
   extern __shared__ float lds[];
   float* Vs = lds;                     // [NC][VS]
   float* GOs = Vs + NC * VS;           // [NQ][VS]
@@ -436,8 +456,8 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   const int slot = tid >> 3, sub = tid & 7, corner = sub & 3, half = sub >> 2;
   const int m = blockIdx.y, bi = blockIdx.z;
   const int np = dm.p;  // single level
-  const int tiles_x = (Wm + TQ - 1) / TQ;
-  const int ntiles = ((Hm + TQ - 1) / TQ) * tiles_x;
+  const int tiles_x = (Wm + TQX - 1) / TQX;
+  const int ntiles = ((Hm + TQY - 1) / TQY) * tiles_x;
   const long long S = dm.s;
   constexpr int VPT = NC * (D / 4) / kThreads;  // float4 of the value window per thread (4)
   constexpr int EPT = PMAX / 2;                 // points per lane (one half of the lattice)
@@ -450,15 +470,15 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     float lg[4], rf[5], of[5];
   } pre;
   auto fetch = [&](int tile) {
-    const int ty0 = (tile / tiles_x) * TQ, tx0 = (tile % tiles_x) * TQ;
+    const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
 #pragma unroll
     for (int it = 0; it < VPT; ++it) {
       const int idx = tid + it * kThreads;
       const int cell = idx >> 3, c4 = (idx & 7) * 4;
-      const int cy = min(max(ty0 - R + cell / WIN, 0), Hm - 1), cx = min(max(tx0 - R + cell % WIN, 0), Wm - 1);
+      const int cy = min(max(ty0 - R + cell / WINX, 0), Hm - 1), cx = min(max(tx0 - R + cell % WINX, 0), Wm - 1);
       pre.v[it] = ld4(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + c4);
     }
-    const int qy = min(ty0 + slot / TQ, Hm - 1), qx = min(tx0 + slot % TQ, Wm - 1);
+    const int qy = min(ty0 + slot / TQX, Hm - 1), qx = min(tx0 + slot % TQX, Wm - 1);
     const long long bq = (long long)bi * dm.lq + (long long)qy * Wm + qx, t = bq * dm.h + m;
     pre.go = ld4(grad_out + t * D + sub * 4);
 #pragma unroll
@@ -475,7 +495,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int ty0 = (tile / tiles_x) * TQ, tx0 = (tile % tiles_x) * TQ;
+    const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
     const int wy0 = ty0 - R, wx0 = tx0 - R;
     __syncthreads();  // previous item's GEMM-2 is done with GOs / W
     // ---- S0: registers -> LDS ------------------------------------------------------------------------------
@@ -483,11 +503,11 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     for (int it = 0; it < VPT; ++it) {
       const int idx = tid + it * kThreads;
       const int cell = idx >> 3, c4 = (idx & 7) * 4;
-      const int cy = wy0 + cell / WIN, cx = wx0 + cell % WIN;
+      const int cy = wy0 + cell / WINX, cx = wx0 + cell % WINX;
       const bool in = cy >= 0 && cy < Hm && cx >= 0 && cx < Wm;
       *reinterpret_cast<float4*>(Vs + cell * VS + c4) = in ? pre.v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int qy = ty0 + slot / TQ, qx = tx0 + slot % TQ;
+    const int qy = ty0 + slot / TQX, qx = tx0 + slot % TQX;
     const bool qok = qy < Hm && qx < Wm;
     const long long t = qok ? (((long long)bi * dm.lq + (long long)qy * Wm + qx) * dm.h + m) : 0;
     *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? pre.go : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -516,13 +536,13 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
 
     // ---- S1: G = GO . V^T ----------------------------------------------------------------------------------
     {
-      const int mb = wave >> 1, nb0 = (wave & 1) * 8;
+      const int mb = wave / B::WPM, nb0 = (wave % B::WPM) * B::NBW;
       const int r16 = lane & 15, kk = lane >> 4;
       float a[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) a[ks] = GOs[(16 * mb + r16) * VS + 4 * ks + kk];
 #pragma unroll
-      for (int nbi = 0; nbi < 8; nbi += 2) {
+      for (int nbi = 0; nbi < B::NBW; nbi += 2) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float* b0 = Vs + (16 * (nb0 + nbi) + r16) * VS + kk;
         const float* b1 = b0 + 16 * VS;
@@ -565,12 +585,12 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
         const int cy = h_low + (corner >> 1), cx = w_low + (corner & 1);
         const bool ok = inside && cy >= 0 && cy <= Hm - 1 && cx >= 0 && cx <= Wm - 1;
         const int ly = cy - wy0, lx = cx - wx0;
-        const bool in_win = (unsigned)ly < (unsigned)WIN && (unsigned)lx < (unsigned)WIN;
+        const bool in_win = (unsigned)ly < (unsigned)WINY && (unsigned)lx < (unsigned)WINX;
         float gval = 0.f;
         if (ok) {
           e_w[k] = wgt * (((corner >> 1) ? lh : hh) * ((corner & 1) ? lwf : hw));
           if (in_win) {
-            e_cell[k] = ly * WIN + lx;
+            e_cell[k] = ly * WINX + lx;
             gval = GW[slot * GS + e_cell[k]];
           } else {  // the box has grown out of the window: dot product against the global value row
             e_cell[k] = -2;
@@ -648,25 +668,28 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     // ---- S5: GV = W . GO, flushed with one atomic per touched (cell, channel) -------------------------------
     {
       const int r16 = lane & 15, kk = lane >> 4;
-      f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-      const float* a0p = GW + (16 * (2 * wave) + r16) * WS + kk;
-      const float* a1p = a0p + 16 * WS;
+      constexpr int CBW = B::CBW;   // 16-cell blocks of W per wave
+      f32x4 acc[CBW][2];
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* ap = GW + (16 * (CBW * wave) + r16) * WS + kk;
       const float* bp = GOs + kk * VS + r16;
 #pragma unroll
       for (int ks = 0; ks < NQ / 4; ++ks) {
-        const float a0 = a0p[4 * ks], a1 = a1p[4 * ks];
         const float b0 = bp[4 * ks * VS], b1 = bp[4 * ks * VS + 16];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CBW; ++i) {
+          const float av = ap[i * 16 * WS + 4 * ks];
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[i][1], 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < CBW; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int cell = 16 * (2 * wave + i) + 4 * kk + r;
-          const int cy = wy0 + cell / WIN, cx = wx0 + cell % WIN;
+          const int cell = 16 * (CBW * wave + i) + 4 * kk + r;
+          const int cy = wy0 + cell / WINX, cx = wx0 + cell % WINX;
           if (cy >= 0 && cy < Hm && cx >= 0 && cx < Wm) {
             float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
             if (acc[i][0][r] != 0.0f) unsafeAtomicAdd(gv, acc[i][0][r]);
@@ -687,7 +710,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
 __global__ void __launch_bounds__(256)
 box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __restrict__ starts,
                      const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ kidx,
-                     BoxDims dm, int* __restrict__ counts, int outside_tile_window) {
+                     BoxDims dm, int* __restrict__ counts, int outside_tile_window, int tqy) {
   // one thread per (query, head, level, point): the same location arithmetic as box_bwd_kernel.  outside_tile_window:
   // queries are the cells of the (single) map and only the corners box_bwd_tile_kernel cannot keep in the 16 x 16 window
   // of the query's 8 x 8 tile are counted
@@ -702,11 +725,12 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
   const int bi = (int)(bq / dm.lq);
   const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
   int wy0 = 0, wx0 = 0;
+  const int winy = tqy + 2 * bt::R, winx = bt::TQX + 2 * bt::R;
   const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
   if (outside_tile_window) {
     const int q = (int)(bq % dm.lq);
-    wy0 = (q / W) / bt::TQ * bt::TQ - bt::R;
-    wx0 = (q % W) / bt::TQ * bt::TQ - bt::R;
+    wy0 = (q / W) / tqy * tqy - bt::R;
+    wx0 = (q % W) / bt::TQX * bt::TQX - bt::R;
     // the common case is cheap: the lattice offsets are below half a box side (|k| < 0.5) in each axis before the
     // rotation, so no sampling point is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2
     // for an upright box); a box whose whole reach (+ the bilinear neighbour, + 0.01 cell: the per-point positions
@@ -716,8 +740,8 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
     const float ex = upright ? 0.5f * g.w : 0.5f * (g.w + g.h), ey = upright ? 0.5f * g.h : 0.5f * (g.w + g.h);
     const float bx = g.cx * (float)W - 0.5f, by = g.cy * (float)H - 0.5f;
     const float rx = ex * (float)W + 0.01f, ry = ey * (float)H + 0.01f;
-    if (floorf(bx - rx) >= (float)wx0 && floorf(bx + rx) + 1.f <= (float)(wx0 + bt::WIN - 1) &&
-        floorf(by - ry) >= (float)wy0 && floorf(by + ry) + 1.f <= (float)(wy0 + bt::WIN - 1))
+    if (floorf(bx - rx) >= (float)wx0 && floorf(bx + rx) + 1.f <= (float)(wx0 + winx - 1) &&
+        floorf(by - ry) >= (float)wy0 && floorf(by + ry) + 1.f <= (float)(wy0 + winy - 1))
       return;
   }
   const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
@@ -728,7 +752,7 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
   for (int cn = 0; cn < 4; ++cn) {
     const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
     if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1) {
-      if (outside_tile_window && (unsigned)(cy - wy0) < (unsigned)bt::WIN && (unsigned)(cx - wx0) < (unsigned)bt::WIN) continue;
+      if (outside_tile_window && (unsigned)(cy - wy0) < (unsigned)winy && (unsigned)(cx - wx0) < (unsigned)winx) continue;
       atomicAdd(counts + (((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m), 1);
     }
   }
@@ -838,7 +862,7 @@ BinPlan bin_plan(int b, int s, int h, int l, int lq, int p) {
 // count -> exclusive scan over nbins + 1 counters (the last one stays 0, so offsets[nbins] = number of entries and
 // offsets[bin + 1] ends every bin); cursor = copy of offsets
 int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long long* starts, const float* ref,
-                const float* off, const float* kidx, const BoxDims& dm, int outside_tile_window, hipStream_t st,
+                const float* off, const float* kidx, const BoxDims& dm, int outside_tile_window, int tqy, hipStream_t st,
                 int** offs, int** cursor, int2** entries, int** overflow) {
   char* base = static_cast<char*>(ws);
   *overflow = reinterpret_cast<int*>(base + pl.off_flag);
@@ -850,7 +874,7 @@ int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long
   EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
   const long long npts = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
   hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st, shapes, starts, ref,
-                     off, kidx, dm, *offs, outside_tile_window);
+                     off, kidx, dm, *offs, outside_tile_window, tqy);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals);
   hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals, *cursor);
@@ -917,7 +941,10 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     // encoder self-attention (queries on the value map): fp64 LDS window per 8x8 query tile.  H, W are
     // device-side, so the launch is sized for a square map and the kernel strides over the tiles.
     const int side = (int)std::ceil(std::sqrt((double)s));
-    const unsigned tiles_sq = (unsigned)(((side + 7) / 8) * ((side + 7) / 8));
+    // tile shape: 4 x 8 queries (two workgroups per CU) unless EFG_BOX_TQY=8 asks for the 8 x 8 tile of round 2
+    static const int tqy_env = getenv("EFG_BOX_TQY") ? atoi(getenv("EFG_BOX_TQY")) : 4;
+    const int tqy = tqy_env == 8 ? 8 : 4;
+    const unsigned tiles_sq = (unsigned)(((side + tqy - 1) / tqy) * ((side + 7) / 8));
     if (l * p <= bt::PMAX) {
       // corners that leave the tile's window are binned per (cell, head) row when a workspace is given (see the kernel)
       const BinPlan pl = bin_plan(b, s, h, l, lq, p);
@@ -928,13 +955,20 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       if (binned) {
         EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
         if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
-                                 kernel_indices, dm, 1, st, &offs, &cursor, &entries, &overflow))
+                                 kernel_indices, dm, 1, tqy, st, &offs, &cursor, &entries, &overflow))
           return rc;
       }
-      EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel, bt::kLdsBytes);
-      hipLaunchKernelGGL(box_bwd_tile_kernel, dim3(tiles_sq, h, b), dim3(bt::kThreads), bt::kLdsBytes, st, value,
-                         (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
-                         grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
+      if (tqy == 8) {
+        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
+        hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(tiles_sq, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
+                           (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                           grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
+      } else {
+        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<4>, bt::lds_bytes<4>());
+        hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(tiles_sq, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,
+                           (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                           grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
+      }
       if (binned) {
         EFG_LAUNCH_CHECK();
         const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
@@ -956,7 +990,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     if (binned) {
       EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
       if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
-                               kernel_indices, dm, 0, st, &offs, &cursor, &entries, &overflow))
+                               kernel_indices, dm, 0, 8, st, &offs, &cursor, &entries, &overflow))
         return rc;
     } else if (ws != nullptr && ws_bytes >= sizeof(int)) {
       EFG_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), st));  // the overflow word is defined whenever a workspace is given

@@ -153,14 +153,17 @@ def test_fused_kernels_match_oracle(dev, oracle_mod, case):
     exp = _OracleSampling.apply(v_c, shapes, start, grid, attn)
     exp.backward(gout)
 
-    if case.startswith("encoder_mixed"):   # how many corners fall outside the 16 x 16 window of their 8 x 8 query tile
+    if case.startswith("encoder_mixed"):   # how many corners fall outside the window of their TQY x 8 query tile
+        import os
+
+        tqy = 8 if os.environ.get("EFG_BOX_TQY") == "8" else 4      # csrc/box_fused.hip: BT<TQY>, window = tile + 4 cells
         px = grid.detach()[..., 0] * W - 0.5
         py = grid.detach()[..., 1] * H - 0.5
         q = torch.arange(lq)
         wx0 = ((q % W) // 8 * 8 - 4).view(1, lq, 1, 1, 1)
-        wy0 = ((q // W) // 8 * 8 - 4).view(1, lq, 1, 1, 1)
+        wy0 = ((q // W) // tqy * tqy - 4).view(1, lq, 1, 1, 1)
         out_of_win = ((torch.floor(px) < wx0) | (torch.floor(px) + 1 > wx0 + 15) | (torch.floor(py) < wy0)
-                      | (torch.floor(py) + 1 > wy0 + 15))
+                      | (torch.floor(py) + 1 > wy0 + tqy + 7))
         frac = float(out_of_win.float().mean())
         assert 0.03 < frac < 0.5, "the case should mix in-window and out-of-window corners, got %.3f" % frac
 
