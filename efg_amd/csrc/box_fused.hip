@@ -711,15 +711,15 @@ __global__ void __launch_bounds__(256)
 box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __restrict__ starts,
                      const float* __restrict__ ref, const float* __restrict__ off, const float* __restrict__ kidx,
                      BoxDims dm, int* __restrict__ counts, int outside_tile_window, int tqy) {
-  // one thread per (query, head, level, point): the same location arithmetic as box_bwd_kernel.  outside_tile_window:
-  // queries are the cells of the (single) map and only the corners box_bwd_tile_kernel cannot keep in the 16 x 16 window
-  // of the query's 8 x 8 tile are counted
-  const long long total = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
+  // one thread per (query, head, level): the box (its trigonometry) once, then the P lattice points -- the same
+  // location arithmetic as the backward kernels (make_box / box_point).  outside_tile_window: queries are the cells of
+  // the (single) map and only the corners box_bwd_tile_kernel cannot keep in the window of the query's TQY x 8 tile are
+  // counted; a box that cannot reach outside its window -- nearly all of them -- costs nothing beyond make_box.
+  const long long total = (long long)dm.b * dm.lq * dm.h * dm.l;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  const int pi = (int)(e % dm.p);
-  const int li = (int)((e / dm.p) % dm.l);
-  const long long t = e / ((long long)dm.p * dm.l);
+  const int li = (int)(e % dm.l);
+  const long long t = e / dm.l;
   const int m = (int)(t % dm.h);
   const long long bq = t / dm.h;
   const int bi = (int)(bq / dm.lq);
@@ -731,11 +731,11 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
     const int q = (int)(bq % dm.lq);
     wy0 = (q / W) / tqy * tqy - bt::R;
     wx0 = (q % W) / bt::TQX * bt::TQX - bt::R;
-    // the common case is cheap: the lattice offsets are below half a box side (|k| < 0.5) in each axis before the
-    // rotation, so no sampling point is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2
-    // for an upright box); a box whose whole reach (+ the bilinear neighbour, + 0.01 cell: the per-point positions
-    // are rounded 4 more times, ~1e-4 cell at 200 cells) stays inside the window has nothing to count.  Centre and
-    // size come from the SAME make_box the backward kernel classifies with.
+    // the lattice offsets are below half a box side (|k| < 0.5) in each axis before the rotation, so no sampling point
+    // is further than (w + h) / 2 from the box centre in x or in y (w / 2 and h / 2 for an upright box); a box whose
+    // whole reach (+ the bilinear neighbour, + 0.01 cell: the per-point positions are rounded 4 more times, ~1e-4 cell
+    // at 200 cells) stays inside the window has nothing to count.  Centre and size come from the SAME make_box the
+    // backward kernel classifies with.
     const bool upright = g.sn == 0.f;   // the encoder's boxes: no rotation at all, reach = half a side per axis
     const float ex = upright ? 0.5f * g.w : 0.5f * (g.w + g.h), ey = upright ? 0.5f * g.h : 0.5f * (g.w + g.h);
     const float bx = g.cx * (float)W - 0.5f, by = g.cy * (float)H - 0.5f;
@@ -744,16 +744,19 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
         floorf(by - ry) >= (float)wy0 && floorf(by + ry) + 1.f <= (float)(wy0 + winy - 1))
       return;
   }
-  const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
-  const float h_im = px.h_im, w_im = px.w_im;
-  if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) return;
-  const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+  int* row = counts + ((long long)bi * dm.s + starts[li]) * dm.h + m;
+  for (int pi = 0; pi < dm.p; ++pi) {
+    const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
+    const float h_im = px.h_im, w_im = px.w_im;
+    if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) continue;
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
 #pragma unroll
-  for (int cn = 0; cn < 4; ++cn) {
-    const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
-    if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1) {
-      if (outside_tile_window && (unsigned)(cy - wy0) < (unsigned)winy && (unsigned)(cx - wx0) < (unsigned)winx) continue;
-      atomicAdd(counts + (((long long)bi * dm.s + starts[li] + (long long)cy * W + cx) * dm.h + m), 1);
+    for (int cn = 0; cn < 4; ++cn) {
+      const int cy = h_low + (cn >> 1), cx = w_low + (cn & 1);
+      if (cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1) {
+        if (outside_tile_window && (unsigned)(cy - wy0) < (unsigned)winy && (unsigned)(cx - wx0) < (unsigned)winx) continue;
+        atomicAdd(row + ((long long)cy * W + cx) * dm.h, 1);
+      }
     }
   }
 }
@@ -872,8 +875,8 @@ int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long
   *entries = reinterpret_cast<int2*>(base + pl.off_entries);
   // flag + offsets are adjacent: one memset
   EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
-  const long long npts = (long long)dm.b * dm.lq * dm.h * dm.l * dm.p;
-  hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(npts, 256)), dim3(256), 0, st, shapes, starts, ref,
+  const long long nboxes = (long long)dm.b * dm.lq * dm.h * dm.l;
+  hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(nboxes, 256)), dim3(256), 0, st, shapes, starts, ref,
                      off, kidx, dm, *offs, outside_tile_window, tqy);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals);
   hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);

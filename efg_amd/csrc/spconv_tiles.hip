@@ -114,8 +114,14 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int* __restrict__ 
     const long long r = c0 + li;
     unsigned long long key = ~0ull;  // padding rows sort last
     if (r < m) {
+      // all (<= 31) loads of the row's table column issued before the first is used: a loop with a runtime trip count
+      // waits for every load in turn (27 round trips per row; the kernel was 57 us per launch, 15 launches per step)
+      int nv[31];
+#pragma unroll
+      for (int k = 0; k < 31; ++k) nv[k] = k < kvol ? nbr[(long long)k * m + r] : -1;
       unsigned mask = 0;
-      for (int k = 0; k < kvol; ++k) mask |= (nbr[(long long)k * m + r] >= 0 ? 1u : 0u) << k;
+#pragma unroll
+      for (int k = 0; k < 31; ++k) mask |= (nv[k] >= 0 ? 1u : 0u) << k;
       key = ((unsigned long long)mask << 10) | (unsigned)li;
     }
     keys[li] = key;
@@ -147,13 +153,19 @@ __global__ void __launch_bounds__(256) tile_plan_kernel(const int* __restrict__ 
     const int j = p & 15;
     rows[tile * 16 + j] = (int)r;
     unsigned active = 0;
-    for (int k = 0; k < kvol; ++k) {
-      const int v = (r >= 0) ? nbr[(long long)k * m + r] : -1;
-      nb[(tile * kvol + k) * 16 + j] = v;
-      const unsigned long long bal = __ballot(v >= 0);
-      const unsigned m16 = (unsigned)(bal >> (lane & 48)) & 0xffffu;
-      if (j == 0) vm[tile * 32 + k] = m16;
-      active |= (m16 ? 1u : 0u) << k;
+    int nv[31];
+#pragma unroll
+    for (int k = 0; k < 31; ++k) nv[k] = (k < kvol && r >= 0) ? nbr[(long long)k * m + r] : -1;
+#pragma unroll
+    for (int k = 0; k < 31; ++k) {
+      if (k < kvol) {   // (wave-uniform)
+        const int v = nv[k];
+        nb[(tile * kvol + k) * 16 + j] = v;
+        const unsigned long long bal = __ballot(v >= 0);
+        const unsigned m16 = (unsigned)(bal >> (lane & 48)) & 0xffffu;
+        if (j == 0) vm[tile * 32 + k] = m16;
+        active |= (m16 ? 1u : 0u) << k;
+      }
     }
     if (j == 0) {
       for (int k = kvol; k < 31; ++k) vm[tile * 32 + k] = 0;
