@@ -822,14 +822,22 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
     const int s = offsets[bin], e = min(cursor[bin], offsets[bin + 1]);  // offsets has nbins + 1 entries
     if (s == e) continue;
     float4 acc = ld4(grad_value + bin * 32 + c4);
-    for (int i = s; i < e; ++i) {
-      const int2 en = entries[i];
-      const float w = __int_as_float(en.y);
-      const float4 g = ld4(grad_out + (long long)en.x * 32 + c4);
-      acc.x = fmaf(w, g.x, acc.x);
-      acc.y = fmaf(w, g.y, acc.y);
-      acc.z = fmaf(w, g.z, acc.z);
-      acc.w = fmaf(w, g.w, acc.w);
+    for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight, accumulated in list order
+      int2 en[4];
+      float4 g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) en[u] = entries[min(i0 + u, e - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = ld4(grad_out + (long long)en[u].x * 32 + c4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u < e) {
+          const float w = __int_as_float(en[u].y);
+          acc.x = fmaf(w, g[u].x, acc.x);
+          acc.y = fmaf(w, g[u].y, acc.y);
+          acc.z = fmaf(w, g[u].z, acc.z);
+          acc.w = fmaf(w, g[u].w, acc.w);
+        }
     }
     *reinterpret_cast<float4*>(grad_value + bin * 32 + c4) = acc;
   }

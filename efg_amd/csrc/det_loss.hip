@@ -112,10 +112,21 @@ focal_sum_kernel(const float* __restrict__ logits, const int* __restrict__ tcls,
   const float* lg = logits + (long long)l * N * C;
   const int* tc = tcls + (long long)l * N;
   float acc = 0.f;
-  for (long long e = threadIdx.x; e < N * C; e += 1024) {
-    const long long i = e / C;
-    const int c = (int)(e % C);
-    acc += focal_elem(lg[e], tc[i] == c, alpha, gamma);
+  const long long total = N * C;
+  for (long long e0 = threadIdx.x; e0 < total; e0 += 4 * 1024) {   // four elements in flight, added in the same order
+    float x[4];
+    bool hit[4], on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = e0 + 1024ll * u;
+      on[u] = e < total;
+      const long long ec = on[u] ? e : 0;
+      x[u] = lg[ec];
+      hit[u] = tc[ec / C] == (int)(ec % C);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (on[u]) acc += focal_elem(x[u], hit[u], alpha, gamma);
   }
   const float s = block_sum_1024(acc, sm);
   if (threadIdx.x == 0) out[l] = s / denom[0];

@@ -399,9 +399,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   };
 
   int qn = 0;  // block-uniform queue length
+  // the table column of the NEXT 256 rows is requested before this segment's pairs are multiplied (its round trip used
+  // to sit between two drains)
+  int r_nxt = (row_lo + threadIdx.x < row_hi) ? a.nbr[(long long)k * a.m_out + row_lo + threadIdx.x] : -1;
   for (long long seg = row_lo; seg < row_hi; seg += 256) {
     const long long row = seg + threadIdx.x;
-    const int r = (row < row_hi) ? a.nbr[(long long)k * a.m_out + row] : -1;
+    const int r = r_nxt;
+    r_nxt = (row + 256 < row_hi) ? a.nbr[(long long)k * a.m_out + row + 256] : -1;
     const unsigned long long mask = __ballot(r >= 0);
     if (lane == 0) wave_cnt[wv] = __popcll(mask);
     __syncthreads();

@@ -247,9 +247,19 @@ conv_tile_kernel(TileArgs a) {
     if (lane < R * 16) prow = a.rows[t0 * 16 + lane];
     // neighbour block of the R sub-tiles: contiguous in the plan -> coalesced; row number -> byte offset
     const int* src = a.nb + t0 * a.kvol * 16;
-    for (int e = lane + 64 * part; e < R * a.kvol * 16; e += 64 * KS) {
-      const int s = e / (a.kvol * 16), rem = e - s * (a.kvol * 16);
-      nbs[s * 512 + rem] = (int)((unsigned)max(src[e], 0) * (unsigned)a.cin * 4u);
+    const int ne = R * a.kvol * 16;
+    for (int e0 = lane + 64 * part; e0 < ne; e0 += 4 * 64 * KS) {   // (four loads in flight: one round trip, not four)
+      int ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ev[u] = src[min(e0 + u * 64 * KS, ne - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 64 * KS;
+        if (e < ne) {
+          const int s = e / (a.kvol * 16), rem = e - s * (a.kvol * 16);
+          nbs[s * 512 + rem] = (int)((unsigned)max(ev[u], 0) * (unsigned)a.cin * 4u);
+        }
+      }
     }
   } else {
 #pragma unroll
