@@ -187,7 +187,6 @@ struct TileArgs {
   int cin, cout, kvol;
   int c16n, np;
   int pipe, deal, xcd;   // experiment switches (EFG_TILE_PIPE, EFG_TILE_DEAL, EFG_TILE_XCD)
-  int xp;                // EFG_TILE_XP: weight fragments prefetched across the (column, chunk) step boundary
   // stream-K (MODE & 2)
   const int* sk_prefix;  // [ux + 1] exclusive prefix of the units' item counts (from the plan, for this R)
   float* sk_scratch;     // [grid][R * NT * 256] shares of units that straddle a cut
@@ -211,7 +210,6 @@ __device__ float4 g_zero_piece;  // (zero-initialised, never written; not const:
 template <int NT, int R, int KS, int V4, int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 2) ? (R == 2 ? 4 : 5) : 1)))
 conv_tile_kernel(TileArgs a) {
-  constexpr int XP = MODE & 1;       // weight fragments prefetched across the (column, chunk) step boundary
   constexpr int SK = (MODE >> 1) & 1;  // stream-K: the (unit, offset) items are cut into equal shares, one per workgroup
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
   constexpr int kAStr = V4 ? kCKt : kCKt + 2;        // LDS row stride of the A tile (V4: swizzled pieces, no padding)
@@ -359,10 +357,6 @@ conv_tile_kernel(TileArgs a) {
         for (int j = 0; j < 16; ++j) at[(s * 16 + j) * kAStr + lane] = ((pre_m[s] >> j) & 1u) ? pre[s * 16 + j] : 0.0f;
       }
   };
-  // Weight fragments: b_cur always holds the fragment of the NEXT 16-channel step to multiply, loaded one step ahead --
-  // across the (column, chunk) boundary too (XP = 1): the first fragment of a step used to be requested at the top
-  // of compute(), an exposed L2 / Infinity-Cache round trip per step.
-  float4 b_cur[XP ? NT : 1], b_nxt[XP ? NT : 1];
   auto b_offset = [&](int col, int ch) {
     const int k = a.flip ? (a.kvol - 1 - col) : col;  // weight offset of this table column
     const int c16_lo = ch * (kCKt / 16);
@@ -377,11 +371,10 @@ conv_tile_kernel(TileArgs a) {
     for (int t = 0; t < NT; ++t)
       b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
   };
-  auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1, int col_n, int ch_n, bool more) {
+  auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
     const int c16_lo = ch * (kCKt / 16);
     const int m = lane & 15, kk = lane >> 4;
     const unsigned boff0 = b_offset(col, ch);
-    const unsigned boff_n = more ? b_offset(col_n, ch_n) : boff0;
     const int nc = min(kCKt / 16, a.c16n - c16_lo);  // 16-channel steps of this chunk (4 unless the tail)
     auto mfmas = [&](const float4* b, int i) {
 #pragma unroll
@@ -405,28 +398,6 @@ conv_tile_kernel(TileArgs a) {
         for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[t].w, acc[s][t], 0, 0, 0);
       }
     };
-    if (XP) {
-      // b_cur = fragment 0 of this step (loaded during the previous step, or before the loop)
-      if (nc == 4) {
-        load_b(b_nxt, boff0, 1);
-        mfmas(b_cur, 0);
-        load_b(b_cur, boff0, 2);
-        mfmas(b_nxt, 1);
-        load_b(b_nxt, boff0, 3);
-        mfmas(b_cur, 2);
-        if (more) load_b(b_cur, boff_n, 0);
-        mfmas(b_nxt, 3);
-      } else {
-        for (int i = 0; i < nc; ++i) {
-          if (i + 1 < nc) load_b(b_nxt, boff0, i + 1);
-          else if (more) load_b(b_nxt, boff_n, 0);
-          mfmas(b_cur, i);
-#pragma unroll
-          for (int t = 0; t < (XP ? NT : 1); ++t) b_cur[t] = b_nxt[t];
-        }
-      }
-      return;
-    }
     // software pipeline over the (up to) four 16-channel steps: the weights of step i+1 are in flight during the
     // MFMAs of step i (they come from L2: ~200+ cycles, a 16-MFMA step is 512)
     float4 b0[NT], b1[NT];
@@ -480,7 +451,6 @@ conv_tile_kernel(TileArgs a) {
     };
     if (a.deal) advance(c_cur, ch_cur, part);
     gather(c_cur, ch_cur);
-    if (XP) load_b(b_cur, b_offset(c_cur, ch_cur), 0);
     stash(at0);
     unsigned cm0 = pre_m[0], cm1 = pre_m[R - 1];
     for (int s = 0; s < nsteps; ++s) {
@@ -492,7 +462,7 @@ conv_tile_kernel(TileArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      compute(at0, c_cur, ch_cur, cm0, cm1, c_nxt, ch_nxt, more);
+      compute(at0, c_cur, ch_cur, cm0, cm1);
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (more) {
@@ -741,21 +711,16 @@ void launch_tiles_x(const TileArgs& a, int ny, int ks, hipStream_t stream) {
   const long long wave_tiles = (a.n_tiles + R - 1) / R;
   // (stream-K exists for the split-K shape only: one unit per workgroup)
   if (ks == 4) launch_tiles_k<NT, R, 4, V4, MODE>(a, (unsigned)wave_tiles, ny, stream);
-  else if (ks == 2) launch_tiles_k<NT, R, 2, V4, MODE & 1>(a, (unsigned)ceil_div(wave_tiles, 2), ny, stream);
-  else launch_tiles_k<NT, R, 1, V4, MODE & 1>(a, (unsigned)ceil_div(wave_tiles, 4), ny, stream);
+  else if (ks == 2) launch_tiles_k<NT, R, 2, V4, 0>(a, (unsigned)ceil_div(wave_tiles, 2), ny, stream);
+  else launch_tiles_k<NT, R, 1, V4, 0>(a, (unsigned)ceil_div(wave_tiles, 4), ny, stream);
 }
 
 template <int NT, int R, int V4>
 void launch_tiles_v(const TileArgs& a, int ny, int ks, hipStream_t stream) {
-  // the experimental modes exist for the 64-channel-wide wave tiles with 4-byte gathers only (the default shapes)
+  // stream-K exists for the 64-channel-wide wave tiles with 4-byte gathers and the split-K shape only (the default shapes)
   constexpr bool kModes = (NT == 4 && V4 == 0);
-  const int mode = kModes ? ((a.xp ? 1 : 0) | (a.sk_scratch && ks == 4 ? 2 : 0)) : 0;
-  switch (mode) {
-    case 1: launch_tiles_x<NT, R, V4, kModes ? 1 : 0>(a, ny, ks, stream); break;
-    case 2: launch_tiles_x<NT, R, V4, kModes ? 2 : 0>(a, ny, ks, stream); break;
-    case 3: launch_tiles_x<NT, R, V4, kModes ? 3 : 0>(a, ny, ks, stream); break;
-    default: launch_tiles_x<NT, R, V4, 0>(a, ny, ks, stream); break;
-  }
+  if (kModes && a.sk_scratch && ks == 4) launch_tiles_x<NT, R, V4, kModes ? 2 : 0>(a, ny, ks, stream);
+  else launch_tiles_x<NT, R, V4, 0>(a, ny, ks, stream);
 }
 
 template <int NT, int R>
@@ -868,8 +833,6 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.deal = deal_env;
   static const int xcd_env = getenv("EFG_TILE_XCD") ? atoi(getenv("EFG_TILE_XCD")) : 1;
   a.xcd = xcd_env;
-  static const int xp_env = getenv("EFG_TILE_XP") ? atoi(getenv("EFG_TILE_XP")) : 0;
-  a.xp = xp_env;
   // Stream-K (see the kernel): on by default where it was measured to win -- the 64-channel-wide split-K shape on
   // submanifold tables (every level: -3 % at 64 channels, -5 % at 128, -9 % at 256) and on the strided tables with
   // at least 128 channels on both sides (-11 %); the other strided tables lose with it (short units, many of them).

@@ -107,36 +107,6 @@ def _build_plan(table, m, kvol):
     return plan
 
 
-def _wg_shape(n_rows, n_out_channels, kvol):
-    """Workgroup-cooperative kernel (csrc/spconv_wg.hip) for this launch?  -> tm_tn code or None.
-    OFF by default: measured 30-60 % SLOWER than the independent-wave tiled kernel on every layer of the res18
-    backbone (profiles/r02_wg_sweep.txt) -- the lockstep barrier per step and 2 waves per SIMD (100+ KB of LDS per
-    workgroup) cost more than the 3x lower L1 traffic buys; these kernels are latency-bound, not L1-bound.  Kept
-    as a tested A/B arm: EFG_CONV_WG=1 enables it, EFG_WG_SHAPE forces a shape, EFG_WG_MIN_TILES sets the smallest
-    level it takes."""
-    if os.environ.get("EFG_CONV_WG", "0") != "1" or kvol > 31 or kvol < 8 or n_out_channels < 64:
-        return None
-    forced = int(os.environ.get("EFG_WG_SHAPE", "0"))
-    tiles = (n_rows + 15) // 16
-    groups = (n_out_channels + 63) // 64
-    if tiles * groups < int(os.environ.get("EFG_WG_MIN_TILES", "1500")):
-        return None
-    return forced or (24 if groups >= 4 else 42 if groups >= 2 else 81)
-
-
-def _conv_wg(inp, m_in, cin, w, bias, cout, kvol, plan, m_out, flip, for_dgrad, shape, cost):
-    lib = L.lib()
-    wc, wk, wi = w.shape
-    packed = torch.empty(lib.efg_spconv_packed_weight_lanes_bytes(wc, wk, wi, for_dgrad), dtype=torch.uint8,
-                         device=inp.device)
-    L.check(lib.efg_spconv_pack_weight_lanes_f32(L.ptr(w), wc, wk, wi, for_dgrad, L.ptr(packed), L.stream()))
-    out = torch.empty((m_out, cout), dtype=torch.float32, device=inp.device)
-    with _prof.timed("conv_wg_kernel", cost):
-        L.check(lib.efg_spconv_forward_wg_f32(L.ptr(inp), m_in, cin, L.ptr(packed), L.ptr(bias), cout, kvol,
-                                              L.ptr(plan), m_out, flip, shape, L.ptr(out), L.stream()))
-    return out
-
-
 def _natural_order(reduce_channels):
     """2 when the tile kernel should take its 16-byte-gather path for this reduction width (weights packed in natural
     channel order), else 0.  OFF by default: measured 3-13 % SLOWER than the 4-byte path on every res18 layer
@@ -150,11 +120,6 @@ def _conv_forward(features, w, bias, rb):
     """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
     lib = L.lib()
     cout, kvol, cin = w.shape
-    if _tiled() and rb.m_out > 0:
-        shape = _wg_shape(rb.m_out, cout, kvol)
-        if shape is not None:
-            return _conv_wg(features, rb.m_in, cin, w, bias, cout, kvol, rb.plan_fwd(), rb.m_out, 0, 0, shape,
-                            _Cost(rb, cin, cout, "fwd"))
     tiled = _tiled() and kvol <= 31 and rb.m_out > 0
     nat = _natural_order(cin) if tiled else 0
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
@@ -176,12 +141,6 @@ def _conv_forward(features, w, bias, rb):
 def _conv_dgrad(grad_out, w, rb):
     lib = L.lib()
     cout, kvol, cin = w.shape
-    if _tiled() and rb.m_in > 0:
-        shape = _wg_shape(rb.m_in, cin, kvol)
-        if shape is not None:
-            plan, flip = rb.plan_dgrad()
-            return _conv_wg(grad_out, rb.m_out, cout, w, None, cin, kvol, plan, rb.m_in, flip, 1, shape,
-                            _Cost(rb, cin, cout, "dgrad"))
     tiled = _tiled() and kvol <= 31 and rb.m_in > 0
     nat = _natural_order(cout) if tiled else 0
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8,

@@ -172,17 +172,6 @@ int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, co
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);
 
-/* Workgroup-cooperative variant for the large levels (csrc/spconv_wg.hip): same contract as
- * efg_spconv_forward_tiled_f32 over the same plan, weights packed in lane order by efg_spconv_pack_weight_lanes_f32.
- * tm_tn = 10 * TM + TN picks the workgroup shape (TM row tiles x TN groups of 64 output channels; 81, 41, 42, 22, 24),
- * 0 = from the channel count. */
-size_t efg_spconv_packed_weight_lanes_bytes(int cout, int kvol, int cin, int for_dgrad);
-int efg_spconv_pack_weight_lanes_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad, float* packed,
-                                     void* stream);
-int efg_spconv_forward_wg_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_lanes,
-                              const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
-                              int flip_offsets, int tm_tn, float* out_feat, void* stream);
-
 /* order[m]: the rows of `indices` (int32 [m][4] = b, z, y, x) grouped by the parity of (z, y, x) -- the rows of a
  * stride-2 layer's dgrad that share their set of reachable kernel offsets.  ws: 64 bytes. */
 int efg_spconv_parity_order(const int32_t* indices, int64_t m, int32_t* order, void* ws, size_t ws_bytes,

@@ -22,6 +22,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             m = re.match(r"conv_tile_kernel<(\d+), \d+, \d+(, \d+){0,2}>$", name)  # <NT, R, KS[, V4[, MODE]]>: bench.py labels by NT
             if m:
                 name = "conv_tile_kernel<%s>" % m.group(1)
+            m = re.match(r"box_bwd_tile_kernel<\d+>$", name)   # the tile height is a launch detail
+            if m:
+                name = "box_bwd_tile_kernel"
             v = vals.setdefault(name, {})
             n, mean = int(row["launches"]), float(row["mean_" + ctr])
             tot = v.get("launches_" + ctr, 0)

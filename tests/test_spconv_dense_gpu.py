@@ -157,18 +157,6 @@ def test_backbone_block_equals_dense(dev):
     _close("residual block", y.features.detach().cpu().numpy(), want, rel=1e-4)
 
 
-@pytest.mark.parametrize("shape", ["81", "42", "24"])
-def test_workgroup_cooperative_variant_equals_dense(dev, shape, monkeypatch):
-    """csrc/spconv_wg.hip (lockstep workgroups sharing weights through LDS; an A/B arm, off by default) computes the
-    same convolution: the fp64 conv3d comparison above with the variant forced on for every eligible launch."""
-    monkeypatch.setenv("EFG_CONV_WG", "1")
-    monkeypatch.setenv("EFG_WG_MIN_TILES", "0")
-    monkeypatch.setenv("EFG_WG_SHAPE", shape)
-    for geom in ("res18 subm k3", "res18 stem/stage conv k3 s2 p1", "centerpoint conv4 k3 s2 p(0,1,1)"):
-        for cin, cout in ((64, 64), (64, 128), (256, 256)):
-            test_sparse_conv_equals_fp64_dense_conv3d(dev, geom, cin, cout)
-
-
 def test_16_byte_gather_variant_equals_dense(dev, monkeypatch):
     """EFG_TILE_V4=1 (16-byte gathers, swizzled A tile, natural-order packed weights; an A/B arm, off by default:
     profiles/r02_v4_sweep.txt) computes the same convolution, forward and both gradients."""
