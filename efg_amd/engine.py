@@ -278,7 +278,8 @@ class BucketedGradientAllReduce:
         dev = buf.device
         main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         grads = [p.grad for p in params]
-        if any(g is None for g in grads):
+        missing = [i for i, g in enumerate(grads) if g is None]
+        if missing:
             grads = [v.zero_() if g is None else g for g, v in zip(grads, views)]
         torch._foreach_copy_(views, grads)  # on the compute stream, right behind the producers
         if main is not None:
@@ -289,7 +290,7 @@ class BucketedGradientAllReduce:
                 work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
         else:
             work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
-        self.pending.append((work, buf, params, views))
+        self.pending.append((work, buf, params, views, missing))
 
     def _freeze(self):
         """First step, after backward: the members of each bucket are the parameters that received a gradient, checked
@@ -334,7 +335,13 @@ class BucketedGradientAllReduce:
             self.done.clear()
         for key in ("transformer", "neck", "backbone"):  # whatever the hooks did not launch (always: backbone)
             self._launch(key)
-        for work, buf, params, views in self.pending:
+        for work, buf, params, views, missing in self.pending:
+            # a gradient that was absent when its bucket was packed and exists now arrived AFTER the bucket's hook fired:
+            # the hook placement is wrong for this model -- fail loudly, the exchange would silently drop it
+            late = [i for i in missing if params[i].grad is not None]
+            if late:
+                raise RuntimeError("BucketedGradientAllReduce: %d gradients were produced after their bucket had been "
+                                   "packed (the bucket hook fired too early); use EFG_DDP_MODE=flat" % len(late))
             work.wait()  # orders the compute stream after the collective (device side)
             if not self.avg:
                 buf.div_(self.world)
