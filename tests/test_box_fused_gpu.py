@@ -180,3 +180,19 @@ def test_fused_kernels_match_oracle(dev, oracle_mod, case):
     close(v_d.grad, v_c.grad, "grad_value", 1e-4)
     close(o_d.grad, o_c.grad, "grad_offsets", 1e-4)
     close(l_d.grad, l_c.grad, "grad_logits", 1e-4)
+
+
+def test_eight_by_eight_tile_variant_matches_oracle_too(dev):
+    """box_bwd_tile_kernel<8> (the 8 x 8-query tile of round 2, EFG_BOX_TQY=8; the library reads the switch once, hence the
+    child process): the same oracle comparison as above for the encoder cases."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, EFG_BOX_TQY="8", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_box_fused_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider", "-k", "test_fused_kernels_match_oracle and encoder"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
