@@ -40,10 +40,11 @@ def pytest_configure(config):
         _CRUMBS["fd"] = os.dup(2)
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        _CRUMBS["file"] = os.open(os.path.join(out, "gpu_test_progress.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        tag = os.environ.get("EFG_TEST_LOG_TAG", "")   # a pytest started BY a test logs next to, not over, its parent
+        _CRUMBS["file"] = os.open(os.path.join(out, "gpu_test_progress%s.log" % tag), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         # the interpreter's fatal-signal dump (all threads + the 3 kB extension-module list) goes to a file so
         # that it cannot push the breadcrumbs out of the log tail a driver keeps
-        _CRUMBS["fault"] = open(os.path.join(out, "gpu_test_faulthandler.log"), "w")
+        _CRUMBS["fault"] = open(os.path.join(out, "gpu_test_faulthandler%s.log" % tag), "w")
         faulthandler.enable(file=_CRUMBS["fault"], all_threads=True)
     except OSError:
         faulthandler.enable(all_threads=True)
