@@ -217,8 +217,7 @@ conv_tile_kernel(TileArgs a) {
   __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
   __shared__ int s_redo_flag;                        // stream-K: a share did not arrive in time, recompute the unit
   int* s_redo = &s_redo_flag;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wt = wv / KS, part = wv % KS;
+  const int lane = threadIdx.x & 63;   // (the stream-K driver below; body() derives its own, laundered, copies)
   // j0 / j1: the ranks (among the unit's active table columns) this call multiplies, [0, 32) = all; g_first: stream-K,
   // the first workgroup that holds a share of the unit
   auto body = [&](unsigned bx, unsigned by, int j0, int j1, unsigned g_first, unsigned sk_pos) {

@@ -54,14 +54,22 @@ def _compare(make_trainer, make_batch, dev, oracle_mod, rel):
     assert gpu_norm == pytest.approx(cpu_norm, rel=5e-4)
 
 
-def test_centerpoint_full_size_step(dev, oracle_mod):
+@pytest.mark.parametrize("sweeps,points", [(1, 180000), (4, 720000)])
+def test_centerpoint_full_size_step(dev, oracle_mod, sweeps, points):
+    """BASELINE configs[0] at the full scene size and configs[3]: the 4-sweep 720k x 6 cloud with the 200 000-voxel cap of
+    `...36e.4f.improved/config.yaml` (the voxelizer's `break` path inside a training step)."""
     from efg_amd.centerpoint import VoxelNet
     from efg_amd.engine import Trainer, synthetic_batch
 
     cfg = os.path.join(ROOT, "configs", "centerpoint_waymo_voxelnet.yaml")
-    _compare(lambda d: Trainer(config=cfg, device=d, seed=0, model_cls=VoxelNet, ddp=False, max_iters=100),
-             lambda d: synthetic_batch(3000, 1, n_points=180000, device=d if d.type == "cuda" else None), dev, oracle_mod,
-             rel=2e-4)
+    ov = {}
+    if sweeps > 1:
+        ov = {"dataset.nsweeps": sweeps, "model.reader.num_input_features": 6, "model.backbone.num_input_features": 6,
+              "dataset.processors.train.Voxelization.max_voxel_num": 200000,
+              "dataset.processors.val.Voxelization.max_voxel_num": 400000}
+    _compare(lambda d: Trainer(config=cfg, device=d, seed=0, model_cls=VoxelNet, ddp=False, max_iters=100, overrides=dict(ov)),
+             lambda d: synthetic_batch(3000, 1, n_points=points, n_sweeps=sweeps, device=d if d.type == "cuda" else None),
+             dev, oracle_mod, rel=2e-4)
 
 
 def test_trajectoryformer_full_size_step(dev, oracle_mod):
