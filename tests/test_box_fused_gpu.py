@@ -191,7 +191,7 @@ def test_eight_by_eight_tile_variant_matches_oracle_too(dev):
 
     from conftest import ROOT
 
-    env = dict(os.environ, EFG_BOX_TQY="8", PYTHONPATH=ROOT, EFG_TEST_LOG_TAG="_tqy8")
+    env = dict(os.environ, EFG_BOX_TQY="8", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), EFG_TEST_LOG_TAG="_tqy8")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_box_fused_gpu.py"), "-q", "-x", "-m", "gpu",
                         "-p", "no:cacheprovider", "-k", "test_fused_kernels_match_oracle and encoder"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)

@@ -44,7 +44,7 @@ def _run_child(code):
     from conftest import ROOT
 
     return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
-                          env=dict(os.environ, PYTHONPATH=ROOT))
+                          env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
 
 
 _CYCLE_WITH_GRAPH = """

@@ -52,7 +52,7 @@ print("CHILD_OK")
 
 def _run(tmp_path, name, env):
     path = str(tmp_path / (name + ".npz"))
-    e = dict(os.environ, PYTHONPATH=ROOT, **env)
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}, path], capture_output=True, text=True, timeout=600,
                        cwd=ROOT, env=e)
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, (name, r.stdout[-1000:], r.stderr[-3000:])
