@@ -163,7 +163,14 @@ int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, si
  * in = grad_out, cin/cout swapped by the caller), since the transposed table of a symmetric window is the table
  * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0.
  * flip_offsets | 2: `packed_weight` is in natural channel order (for_dgrad | 2) and cin % 4 == 0: the kernel gathers
- * 16 bytes per lane and reads its A fragments with one 16-byte LDS load per 16-channel step. */
+ * 16 bytes per lane and reads its A fragments with one 16-byte LDS load per 16-channel step.
+ * Stream-K (default; EFG_TILE_STREAMK=0 turns it off): on the 64-output-channel split-K shapes of submanifold tables
+ * (and of strided tables with >= 128 channels on both sides) the launch is as many workgroups as the device holds and
+ * the (row tile, active offset) items of the plan -- its prefix sums are part of the plan buffer -- are cut into equal
+ * shares; same sums in a fixed order (reproducible run to run).  This is the one entry point that owns device memory:
+ * 16 MB of share scratch + 16 KB of flags per (device, stream), allocated with hipMalloc on first use and kept for the
+ * life of the process; calls on ONE stream must be issued by one thread at a time (they are: PyTorch's forward and
+ * autograd threads never overlap on a stream). */
 /* The launch shape efg_spconv_forward_tiled_f32 uses for these sizes: n-tiles (of 16 output channels) per wave, row
  * sub-tiles per wave, split-K waves -- i.e. the conv_tile_kernel<NT, R, KS> instantiation; the host labels its timings
  * with it (one definition shared with the launcher, so labels cannot drift from what ran). */
