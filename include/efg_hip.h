@@ -168,7 +168,7 @@ int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, si
  * (and of strided tables with >= 128 channels on both sides) the launch is as many workgroups as the device holds and
  * the (row tile, active offset) items of the plan -- its prefix sums are part of the plan buffer -- are cut into equal
  * shares; same sums in a fixed order (reproducible run to run).  This is the one entry point that owns device memory:
- * 16 MB of share scratch + 16 KB of flags per (device, stream), allocated with hipMalloc on first use and kept for the
+ * 32 MB of share scratch + 16 KB of flags per (device, stream), allocated with hipMalloc on first use and kept for the
  * life of the process; calls on ONE stream must be issued by one thread at a time (they are: PyTorch's forward and
  * autograd threads never overlap on a stream). */
 /* The launch shape efg_spconv_forward_tiled_f32 uses for these sizes: n-tiles (of 16 output channels) per wave, row
