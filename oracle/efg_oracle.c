@@ -13,10 +13,12 @@
  *   msda / box attention       PINNED  against ms_deform_attn_core_pytorch
  *                                      (efg/operators/ms_deform_attn.py:55-76) golden vectors
  *                                      tests/golden/msda_*.npz (fwd) and autograd through it (bwd).
- *   dynamic scatter            PARITY UNPINNED: the reference has no CPU implementation and no
- *                                      tests (voxelization.h:106,127); restated from
- *                                      scatter_points_cuda.cu:209-352 and cross-checked against
- *                                      torch.unique / scatter_reduce in tests only.
+ *   dynamic scatter            FORWARD PINNED (voxel set, counts, point membership, max exactly, sum / mean vs an fp64
+ *                                      sum of the reference's own groups) against the reference's
+ *                                      dynamic_point_to_voxel_cpu (scatter_points_cpu.cpp:62-119) built in place into
+ *                                      oracle/_ref (tests/test_oracle_voxelize.py); the sorted output ORDER and the
+ *                                      BACKWARD are restated from scatter_points_cuda.cu:209-352 only (no CPU path in
+ *                                      the reference): PARITY UNPINNED for those two.
  *   sparse convolution         PARITY UNPINNED: spconv (traveller59/spconv, PyPI spconv-cu11x,
  *                                      version not pinned by the reference: README.md:26-27,
  *                                      sparse_net.py:6-11) is absent from /root/reference and from
