@@ -731,6 +731,12 @@ void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
 // The launch shape of a (cin, cout, kvol, rows) convolution: NT n-tiles per wave, R sub-tiles per wave, KS split-K
 // waves, pipelined weight loads.  ONE definition for the launcher below and for efg_spconv_tile_shape (what the host
 // side labels its timings with).
+// EFG_TILE_STREAMK: 0 off, 1 (default) where it wins, 2 every eligible shape (tests)
+int streamk_mode() {
+  static const int v = getenv("EFG_TILE_STREAMK") ? atoi(getenv("EFG_TILE_STREAMK")) : 1;
+  return v;
+}
+
 void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* nt_out, int* r_out, int* ks_out, int* pipe_out) {
   static const int r_env = getenv("EFG_TILE_R") ? atoi(getenv("EFG_TILE_R")) : 0;
   static const int ks_env = getenv("EFG_TILE_KS") ? atoi(getenv("EFG_TILE_KS")) : 0;
@@ -739,7 +745,10 @@ void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* n
   const int ntiles = (cout + 15) / 16;
   int nt = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
   if (nt_env > 0) nt = nt_env <= 1 ? 1 : (nt_env <= 2 ? 2 : 4);
-  int r = (cin >= 128 && nt >= 4 && kvol >= 8 && m_in == m_out) ? 2 : 1;  // (submanifold: dense tables)
+  // two row sub-tiles per wave (weights loaded once for 32 rows) on the dense tables of the submanifold layers: from
+  // 128 reduction channels, and from 64 when the launch is stream-K (the longer units no longer unbalance the launch:
+  // 64-channel layer 105 -> 99 us forward, 104 -> 96 us dgrad; without stream-K R = 2 loses there, 107 -> 121 us)
+  int r = (nt >= 4 && kvol >= 8 && m_in == m_out && (cin >= 128 || (streamk_mode() && cin >= 64))) ? 2 : 1;
   if (r_env > 0) r = r_env >= 2 ? 2 : 1;
   int ks = (kvol >= 8) ? 4 : 1;
   if (ks_env > 0) ks = ks_env >= 4 ? 4 : (ks_env >= 2 ? 2 : 1);
@@ -835,7 +844,7 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   // Stream-K (see the kernel): on by default where it was measured to win -- the 64-channel-wide split-K shape on
   // submanifold tables (every level: -3 % at 64 channels, -5 % at 128, -9 % at 256) and on the strided tables with
   // at least 128 channels on both sides (-11 %); the other strided tables lose with it (short units, many of them).
-  static const int sk_env = getenv("EFG_TILE_STREAMK") ? atoi(getenv("EFG_TILE_STREAMK")) : 1;
+  const int sk_env = streamk_mode();
   static const int sk_polls_env = getenv("EFG_TILE_SK_POLLS") ? atoi(getenv("EFG_TILE_SK_POLLS")) : 20000;
   a.sk_prefix = nullptr;
   a.sk_scratch = nullptr;
