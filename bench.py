@@ -348,6 +348,13 @@ def main():
                                              "standalone_frac_of_8TBps": round(nbytes / us / 1e3 / 8000.0, 4)})
             except Exception as exc:  # accounting only
                 line["voxelize_hbm"]["standalone_error"] = str(exc)
+            # counter traffic of the call's five kernels (profiles/pmc_latest.json, same PMC passes as roofline.traffic)
+            vk = ("vox_insert_kernel", "vox_count_kernel", "vox_assign_kernel", "vox_cascade_kernel", "vox_gather_kernel")
+            tr_b = [_pmc_traffic(k)[0] for k in vk]
+            if all(t is not None for t in tr_b):
+                alg = sum(v["bytes"] for v in vox.values()) / max(sum(v["launches"] for v in vox.values()), 1)
+                line["voxelize_hbm"].update({"traffic_bytes_per_call": round(sum(tr_b)), "alg_bytes_per_call": round(alg),
+                                             "traffic_ratio": round(sum(tr_b) / max(alg, 1.0), 2)})
         try:
             line["geometry"] = _geometry_report(trainer, pool[0])
         except Exception as exc:  # accounting only
