@@ -18,6 +18,8 @@ c_void_p, c_int, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ct
 _SIGS = {
     "efg_last_error": (ctypes.c_char_p, []),
     "efg_version": (ctypes.c_char_p, []),
+    "efg_capture_stream_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "efg_capture_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "efg_dynamic_voxelize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_hard_voxelize_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "efg_hard_voxelize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,

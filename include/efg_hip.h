@@ -33,6 +33,16 @@ const char* efg_last_error(void);
 /* "efg_hip <version> gfx950" */
 const char* efg_version(void);
 
+/*
+ * A non-blocking stream of the caller's own, on the calling thread's current device, for hipGraph captures.  On ROCm 7
+ * a capture that is invalidated (an illegal call while capturing) leaves its stream invalidated for good --
+ * hipStreamEndCapture reports the error without ending the capture -- so a capture must not run on a stream that will be
+ * handed to anything else later (PyTorch's pool streams are).  Create one, capture on it, keep it for the next capture;
+ * destroy it if its capture failed.  (No counterpart in the reference: CUDA ends an invalidated capture.)
+ */
+int efg_capture_stream_create(void** stream_out);
+int efg_capture_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Voxelization.  Replaces efg::dynamic_voxelize / efg::hard_voxelize
  * (efg/operators/src/voxelize/voxelization.h:51-83; CPU semantics voxelization_cpu.cpp:7-99).

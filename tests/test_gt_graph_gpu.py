@@ -85,6 +85,7 @@ def test_failed_capture_restores_the_stream_and_raises_capture_failed():
     r = _run_child("""
 import torch
 from efg_amd.hipgraph import capture, CaptureFailed
+torch.cuda.manual_seed(77); torch.rand(5, device="cuda")
 x = torch.zeros(1024, device="cuda")
 cur = torch.cuda.current_stream()
 calls = []
@@ -100,10 +101,37 @@ except CaptureFailed as exc:
     assert exc.__cause__ is not None
 assert torch.cuda.current_stream() == cur          # not left on the capture stream
 assert not torch.cuda.is_current_stream_capturing()
+r = torch.rand(8, device="cuda")                   # the default generator is not left in its "capturing" state ...
+torch.cuda.manual_seed(77); torch.rand(5, device="cuda"); want = torch.rand(8, device="cuda")
+assert torch.equal(r, want), (r, want)             # ... and goes on where it was (seeded 77 + 5 draws by the prelude)
 y = (x + 3).sum().item()                           # the device is usable, eagerly ...
-g, z = capture(lambda: x + 2, "cuda:0")            # ... and for the next capture
+g, z = capture(lambda: x + 2 + 0 * torch.rand(1024, device="cuda"), "cuda:0")   # ... and for the next capture
 g.replay(); torch.cuda.synchronize()
 assert y == 3 * 1024 and float(z.sum()) == 2 * 1024
+# ROCm leaves an invalidated capture stream invalidated for good: it must not be one of PyTorch's pool streams, which
+# come round again every 32 requests
+for _ in range(70):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        w = x + 1
+    s.synchronize()
+# a region that fails in Python (nothing illegal for HIP) ends its capture normally; same contract for the caller
+def bad():
+    if len(calls) >= 3:
+        calls.append(1)
+        if len(calls) == 7:
+            raise ValueError("shape mismatch, say")
+    return x + 1
+calls[:] = [1, 1, 1, 1]
+try:
+    capture(bad, "cuda:0")
+    raise SystemExit("capture of a raising region did not fail")
+except CaptureFailed as exc:
+    assert isinstance(exc.__cause__, ValueError)
+assert torch.cuda.current_stream() == cur and torch.rand(2, device="cuda").numel() == 2
+g2, z2 = capture(lambda: x + 5, "cuda:0")
+g2.replay(); torch.cuda.synchronize()
+assert float(z2.sum()) == 5 * 1024
 print("CHILD_OK")
 """)
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
