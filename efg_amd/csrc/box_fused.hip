@@ -56,8 +56,13 @@ __device__ __forceinline__ BoxGeo make_box_v(const float rf[5], const float of[5
   g.w = g.w_on ? w : 0.0f;
   g.h = g.h_on ? h : 0.0f;
   const float ang = (v == 5) ? __fmul_rn(__fmul_rn(__fadd_rn(rf[4], __fdiv_rn(of[4], 16.0f)), 2.0f), 3.14159274f) : rf[4];
-  g.cs = cosf(ang);
-  g.sn = sinf(ang);
+  if (ang == 0.0f) {   // axis-aligned anchors (the encoder): cosf(0) = 1 and sinf(0) = 0 exactly
+    g.cs = 1.0f;
+    g.sn = 0.0f;
+  } else {
+    g.cs = cosf(ang);
+    g.sn = sinf(ang);
+  }
   return g;
 }
 
@@ -429,6 +434,29 @@ __device__ __forceinline__ float quad_bcast(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
 }
 
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// lane k of the quad, k a compile-time constant after unrolling
+__device__ __forceinline__ int quad_bcast_i(int v, int k) {
+  switch (k) {
+    case 0: return quad_perm_i<0x00>(v);
+    case 1: return quad_perm_i<0x55>(v);
+    case 2: return quad_perm_i<0xAA>(v);
+    default: return quad_perm_i<0xFF>(v);
+  }
+}
+__device__ __forceinline__ float quad_bcast_f(float v, int k) {
+  return __builtin_bit_cast(float, quad_bcast_i(__builtin_bit_cast(int, v), k));
+}
+// sum over the 4 lanes of a quad: lane ^ 1 (quad_perm [1,0,3,2]) then lane ^ 2 ([2,3,0,1])
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, quad_perm_i<0xB1>(__builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, quad_perm_i<0x4E>(__builtin_bit_cast(int, v)));
+  return v;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int TQY>
@@ -564,54 +592,82 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     // ---- S2 (pass A): this lane = (query, corner, half of the lattice).  Gradients wrt the attention weights
     // and the sampling locations come from 4 scalars of G per point; the (cell, weight) of the lane's corner is
     // kept in registers for pass B.
+    // The kernel is bound by its VALU instruction count (static count of this pass in the first version: 2400 of the
+    // 5300 per tile and wave), and there all 4 corner lanes of a point redid the point's geometry and its gradient
+    // arithmetic.  Now the quad works on 4 points at a time: each lane does the geometry of ITS point of the group,
+    // then for each of the 4 points the quad takes cell / fractions / weight from the owner lane by DPP, every lane reads
+    // G at its corner (the LDS access pattern that the quad mapping keeps conflict-free) and the owner collects the 4
+    // corner values; the gradient arithmetic runs once per point, on the owner.
     float dcx = 0.f, dcy = 0.f, dw = 0.f, dh = 0.f, dth = 0.f, dot = 0.f;
     int e_cell[EPT];    // window cell (>= 0), -1: nothing to add, -2: outside the window (global path)
     float e_w[EPT];
+    const int cyo = corner >> 1, cxo = corner & 1;
+    const float sy = cyo ? 1.f : -1.f, ay = cyo ? 0.f : 1.f, sx = cxo ? 1.f : -1.f, ax = cxo ? 0.f : 1.f;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int pi = half + 2 * k;
-      e_cell[k] = -1;
-      e_w[k] = 0.f;
-      if (qok && pi < np) {
-        const float kxn = k_s[pi * 2], kyn = k_s[pi * 2 + 1];
-        const BoxPx px = box_point(g, kxn, kyn, Hm, Wm);
-        const float gx = px.gx, gy = px.gy;
-        const float wgt = as[pi] * inv;
-        const float h_im = px.h_im, w_im = px.w_im;
-        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
-        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
-        const float hh = 1.f - lh, hw = 1.f - lwf;
-        const int cy = h_low + (corner >> 1), cx = w_low + (corner & 1);
-        const bool ok = inside && cy >= 0 && cy <= Hm - 1 && cx >= 0 && cx <= Wm - 1;
+    for (int j = 0; j < EPT / 4; ++j) {
+      const int op = half + 2 * (4 * j + corner);   // the point this lane owns in group j
+      const bool own = qok && op < np;
+      const float kxn = own ? k_s[op * 2] : 0.f, kyn = own ? k_s[op * 2 + 1] : 0.f;
+      const BoxPx px = box_point(g, kxn, kyn, Hm, Wm);
+      const float wgt = own ? as[op] * inv : 0.f;
+      const float h_im = px.h_im, w_im = px.w_im;
+      const bool inside = own && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+      const int h_pub = inside ? h_low : -(1 << 20);   // no corner of a point that samples nothing is "ok"
+      float gq[4] = {0.f, 0.f, 0.f, 0.f};              // G at the 4 corners of the OWN point
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * j + c;
+        const int hb = quad_bcast_i(h_pub, c), wb = quad_bcast_i(w_low, c);
+        const float lhb = quad_bcast_f(lh, c), lwb = quad_bcast_f(lwf, c), wgb = quad_bcast_f(wgt, c);
+        const int cy = hb + cyo, cx = wb + cxo;
+        const bool ok = (unsigned)cy < (unsigned)Hm && (unsigned)cx < (unsigned)Wm;
         const int ly = cy - wy0, lx = cx - wx0;
         const bool in_win = (unsigned)ly < (unsigned)WINY && (unsigned)lx < (unsigned)WINX;
+        e_cell[k] = -1;
+        e_w[k] = 0.f;
         float gval = 0.f;
         if (ok) {
-          e_w[k] = wgt * (((corner >> 1) ? lh : hh) * ((corner & 1) ? lwf : hw));
+          // ((corner >> 1) ? lh : 1 - lh) * ((corner & 1) ? lw : 1 - lw): one rounding each, as the select form
+          e_w[k] = wgb * (fmaf(sy, lhb, ay) * fmaf(sx, lwb, ax));
           if (in_win) {
             e_cell[k] = ly * WINX + lx;
             gval = GW[slot * GS + e_cell[k]];
           } else {  // the box has grown out of the window: dot product against the global value row
             e_cell[k] = -2;
             const float* vr = value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D;
-            for (int c = 0; c < D; ++c) gval = fmaf(GOs[slot * VS + c], vr[c], gval);
+#pragma unroll 4
+            for (int cc = 0; cc < D; ++cc) gval = fmaf(GOs[slot * VS + cc], vr[cc], gval);   // rare: keep it small
           }
         }
-        const float g0 = quad_bcast<0>(gval), g1 = quad_bcast<1>(gval), g2 = quad_bcast<2>(gval), g3 = quad_bcast<3>(gval);
-        const float ga = fmaf(lh * lwf, g3, fmaf(lh * hw, g2, fmaf(hh * lwf, g1, hh * hw * g0)));
-        const float gwl = (float)Wm * wgt * fmaf(hh, g1 - g0, lh * (g3 - g2));
-        const float ghl = (float)Hm * wgt * fmaf(hw, g2 - g0, lwf * (g3 - g1));
-        dcx += gwl;
-        dcy += ghl;
-        dw += kxn * (gwl * g.cs + ghl * g.sn);
-        dh += kyn * (ghl * g.cs - gwl * g.sn);
-        dth += gwl * (-(gx * g.sn) - gy * g.cs) + ghl * (gx * g.cs - gy * g.sn);
-        dot = fmaf(wgt, ga, dot);
-        if (corner == 0) ga_s[slot * PMAX + pi] = ga;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float t4 = quad_bcast_f(gval, cc);
+          gq[cc] = (corner == c) ? t4 : gq[cc];
+        }
       }
+      const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
+      const float hh = 1.f - lh, hw = 1.f - lwf;
+      const float gx = px.gx, gy = px.gy;
+      const float ga = fmaf(lh * lwf, g3, fmaf(lh * hw, g2, fmaf(hh * lwf, g1, hh * hw * g0)));
+      const float gwl = (float)Wm * wgt * fmaf(hh, g1 - g0, lh * (g3 - g2));
+      const float ghl = (float)Hm * wgt * fmaf(hw, g2 - g0, lwf * (g3 - g1));
+      dcx += gwl;
+      dcy += ghl;
+      dw += kxn * (gwl * g.cs + ghl * g.sn);
+      dh += kyn * (ghl * g.cs - gwl * g.sn);
+      dth += gwl * (-(gx * g.sn) - gy * g.cs) + ghl * (gx * g.cs - gy * g.sn);
+      dot = fmaf(wgt, ga, dot);
+      if (own) ga_s[slot * PMAX + op] = ga;
     }
-    // the two halves (even / odd points) of a pair sit 4 lanes apart
+    // every lane holds the sums over its own points: 4 corner lanes of a half, then the two halves 4 lanes apart
+    dcx = quad_sum(dcx);
+    dcy = quad_sum(dcy);
+    dw = quad_sum(dw);
+    dh = quad_sum(dh);
+    dth = quad_sum(dth);
+    dot = quad_sum(dot);
     dcx += __shfl_xor(dcx, 4, 64);
     dcy += __shfl_xor(dcy, 4, 64);
     dw += __shfl_xor(dw, 4, 64);
@@ -635,7 +691,8 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     __syncthreads();
     // Column `slot` of W belongs to the 8 lanes of the query.  At one step the 4 corner lanes of a half hit 4
     // distinct cells, so a plain read-modify-write is safe; the two halves take turns (their points may share
-    // a cell), and the LDS pipe keeps consecutive steps of a wave in order.
+    // a cell), and the LDS pipe keeps consecutive steps of a wave in order.  (LDS float atomics instead of the 32
+    // dependent round trips: 490 -> 726 us per launch, ds_add_f32 is far slower than the read + write it replaces.)
 #pragma unroll
     for (int hsel = 0; hsel < 2; ++hsel) {
 #pragma unroll
@@ -659,6 +716,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
           bin_push(cursor, bin_end, overflow, entries, bin, (int)t, e_w[k]);
         } else {
           float* gv = grad_value + bin * D;
+#pragma unroll 1
           for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
         }
       }
@@ -956,6 +1014,10 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     static const int tqy_env = getenv("EFG_BOX_TQY") ? atoi(getenv("EFG_BOX_TQY")) : 4;
     const int tqy = tqy_env == 8 ? 8 : 4;
     const unsigned tiles_sq = (unsigned)(((side + tqy - 1) / tqy) * ((side + 7) / 8));
+    // workgroups along x of the tile kernel: it strides over the tiles and fetches one tile ahead (64 x h x b workgroups,
+    // two rounds of the 512 resident ones: 507 -> 490 us against one workgroup per tile)
+    static const int gx_env = getenv("EFG_BOX_GRIDX") ? atoi(getenv("EFG_BOX_GRIDX")) : 0;
+    const unsigned tile_gx = std::min<unsigned>((unsigned)(gx_env > 0 ? gx_env : 64), tiles_sq);
     if (l * p <= bt::PMAX) {
       // corners that leave the tile's window are binned per (cell, head) row when a workspace is given (see the kernel)
       const BinPlan pl = bin_plan(b, s, h, l, lq, p);
@@ -971,12 +1033,12 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       }
       if (tqy == 8) {
         EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
-        hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(tiles_sq, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
+        hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(tile_gx, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
                            (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
                            grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
       } else {
         EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<4>, bt::lds_bytes<4>());
-        hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(tiles_sq, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,
+        hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(tile_gx, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,
                            (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
                            grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
       }
