@@ -108,6 +108,30 @@ __device__ __forceinline__ void bin_push(int* __restrict__ cursor, const int* __
     atomicAdd(overflow, 1);
 }
 
+// ---- DPP helpers: the 4 lanes of a quad ------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// lane k of the quad, k a compile-time constant after unrolling
+__device__ __forceinline__ int quad_bcast_i(int v, int k) {
+  switch (k) {
+    case 0: return quad_perm_i<0x00>(v);
+    case 1: return quad_perm_i<0x55>(v);
+    case 2: return quad_perm_i<0xAA>(v);
+    default: return quad_perm_i<0xFF>(v);
+  }
+}
+__device__ __forceinline__ float quad_bcast_f(float v, int k) {
+  return __builtin_bit_cast(float, quad_bcast_i(__builtin_bit_cast(int, v), k));
+}
+// sum over the 4 lanes of a quad: lane ^ 1 (quad_perm [1,0,3,2]) then lane ^ 2 ([2,3,0,1])
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, quad_perm_i<0xB1>(__builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, quad_perm_i<0x4E>(__builtin_bit_cast(int, v)));
+  return v;
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ shapes,
@@ -152,6 +176,47 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
     const float* v = value + (((long long)bi * dm.s + starts[li]) * dm.h + m) * dm.d + c0;
     const BoxGeo g = make_box(ref + bq * 7, off + (tt * dm.l + li) * dm.v, dm.v);
+    if (dm.lp >= 4 && (long long)dm.s * row_stride < (1ll << 31)) {   // (32-bit row offsets)
+      // The lanes of a pair differ only in their channels, and the first version had every one of them work out
+      // every point's geometry (110 VALU instructions per point, 50 of them geometry, in a kernel whose 100 gathers
+      // per lane leave the vector-memory pipe half idle).  Now each lane of a QUAD does the geometry of one point in
+      // four and hands the 4 row offsets, the 4 corner weights and the attention weight to the quad by DPP; the
+      // arithmetic on the values is unchanged, bit for bit.
+      const int qc = lane & 3;
+      for (int p0 = 0; p0 < dm.p; p0 += 4) {
+        const int op = p0 + qc;
+        const bool own = op < dm.p;
+        const BoxPx px = box_point(g, own ? kidx[op * 2] : 0.f, own ? kidx[op * 2 + 1] : 0.f, H, W);
+        const float wgt_o = own ? as[li * dm.p + op] * inv : 0.f;
+        const float h_im = px.h_im, w_im = px.w_im;
+        const int ins_o = own && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+        const float hh = 1.f - lh, hw = 1.f - lwf;
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        const int y0 = min(max(h_low, 0), H - 1), y1 = max(min(h_low + 1, H - 1), 0);
+        const int x0 = min(max(w_low, 0), W - 1), x1 = max(min(w_low + 1, W - 1), 0);
+        const int o1 = (y0 * W + x0) * row_stride, o2 = (y0 * W + x1) * row_stride;
+        const int o3 = (y1 * W + x0) * row_stride, o4 = (y1 * W + x1) * row_stride;
+        const float w1_o = (t_ok && l_ok) ? hh * hw : 0.f, w2_o = (t_ok && r_ok) ? hh * lwf : 0.f;
+        const float w3_o = (b_ok && l_ok) ? lh * hw : 0.f, w4_o = (b_ok && r_ok) ? lh * lwf : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ins = quad_bcast_i(ins_o, c);
+          const int a1 = quad_bcast_i(o1, c), a2 = quad_bcast_i(o2, c), a3 = quad_bcast_i(o3, c), a4 = quad_bcast_i(o4, c);
+          const float w1 = quad_bcast_f(w1_o, c), w2 = quad_bcast_f(w2_o, c), w3 = quad_bcast_f(w3_o, c),
+                      w4 = quad_bcast_f(w4_o, c), wgt = quad_bcast_f(wgt_o, c);
+          if (ins && active) {
+            const float4 v1 = ld4(v + a1), v2 = ld4(v + a2), v3 = ld4(v + a3), v4 = ld4(v + a4);
+            acc.x = fmaf(bil(w1, w2, w3, w4, v1.x, v2.x, v3.x, v4.x), wgt, acc.x);
+            acc.y = fmaf(bil(w1, w2, w3, w4, v1.y, v2.y, v3.y, v4.y), wgt, acc.y);
+            acc.z = fmaf(bil(w1, w2, w3, w4, v1.z, v2.z, v3.z, v4.z), wgt, acc.z);
+            acc.w = fmaf(bil(w1, w2, w3, w4, v1.w, v2.w, v3.w, v4.w), wgt, acc.w);
+          }
+        }
+      }
+      continue;
+    }
     for (int pi = 0; pi < dm.p; ++pi) {
       const BoxPx px = box_point(g, kidx[pi * 2], kidx[pi * 2 + 1], H, W);
       const float wgt = as[li * dm.p + pi] * inv;
@@ -432,29 +497,6 @@ template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
-}
-
-template <int CTRL>
-__device__ __forceinline__ int quad_perm_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-// lane k of the quad, k a compile-time constant after unrolling
-__device__ __forceinline__ int quad_bcast_i(int v, int k) {
-  switch (k) {
-    case 0: return quad_perm_i<0x00>(v);
-    case 1: return quad_perm_i<0x55>(v);
-    case 2: return quad_perm_i<0xAA>(v);
-    default: return quad_perm_i<0xFF>(v);
-  }
-}
-__device__ __forceinline__ float quad_bcast_f(float v, int k) {
-  return __builtin_bit_cast(float, quad_bcast_i(__builtin_bit_cast(int, v), k));
-}
-// sum over the 4 lanes of a quad: lane ^ 1 (quad_perm [1,0,3,2]) then lane ^ 2 ([2,3,0,1])
-__device__ __forceinline__ float quad_sum(float v) {
-  v += __builtin_bit_cast(float, quad_perm_i<0xB1>(__builtin_bit_cast(int, v)));
-  v += __builtin_bit_cast(float, quad_perm_i<0x4E>(__builtin_bit_cast(int, v)));
-  return v;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
