@@ -297,7 +297,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # EFG_GEMM_ARM=bf16x3 is the A/B arm (split-precision products in the long Linear layers, csrc/gemm_bf16x3.hip): it
+        # reports under its own label and is never the default
+        "dtype": "f32 + bf16x3 (split bf16 products, fp32 accumulate, in the encoder-sized Linear forward / data-gradient)"
+                 if os.environ.get("EFG_GEMM_ARM", "") == "bf16x3" else "f32",
         "data": "synthetic",
         "config": {
             "workload": "%s res18 p3, %d-sweep Waymo-shaped scenes%s, %d pts/scene, 0.1 m voxels, %d scenes/GPU, %d queries, "

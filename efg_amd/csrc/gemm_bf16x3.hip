@@ -1,0 +1,221 @@
+// Split-precision GEMM for the A/B arm of the bench (NOT the headline path, which stays exact fp32):
+//   C[M,N] (fp32) = A[M,K] (fp32 activations) . B[K,N] (fp32 weights)  (+ bias, + ReLU)
+// with every operand split into two bf16 terms, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 of the 24
+// significand bits), and three bf16 MFMA products accumulated in fp32:  hi.hi + hi.lo + lo.hi  (lo.lo, 2^-16 of the
+// result, is dropped).  fp32-input MFMA peaks at 157 TFLOP/s on gfx950 and bf16 at 2.5 PFLOP/s: three bf16 products cost
+// 3/16 of the fp32 product, which turns the encoder's [70 688 x 256] x [256 x {256, 1024}] products from MFMA-bound
+// (83 / 300 us in hipBLASLt fp32, 71-80 % of that peak) into HBM-bound ones.
+// Why a kernel and not three library bf16 GEMMs: splitting the ACTIVATION in a pass of its own reads 72 MB and writes
+// 72-108 MB -- as long as the fp32 product it replaces (K is only 256).  Here the activation tile is split in registers
+// on its way from HBM to LDS; only the weights (256 KB) are split ahead of time, by efg_gemm_bf16x3_pack_f32, straight
+// into the order in which the MFMA lanes read them.
+//
+// Tiling: workgroup 128 x 128 of C, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16;
+// K in steps of 32 through ONE 32 KB LDS stage (the next step's global loads are in flight in registers during the
+// MFMAs): 3 workgroups per CU.  LDS holds fragment IMAGES: for every (k-step of 16, 32-row tile, hi | lo) the 64 lanes' 16
+// bytes in lane order, so operand reads are conflict-free ds_read_b128 with no address arithmetic.
+#include "common.h"
+
+namespace efg {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 32;
+constexpr int kStage = 16384;   // bytes of one operand's LDS image per K step: [kstep 2][tile 4][hi|lo 2][lane 64][16 B]
+
+__device__ __forceinline__ int frag_off(int kstep, int tile, int part) { return ((kstep * 4 + tile) * 2 + part) * 1024; }
+
+// Packed weights: [col block of 128][K step of 32] -> one 16 KB stage image (above).  Element (k, n) of B sits in
+// lane (n % 32) + 32 * ((k % 16) / 8), element k % 8 of the fragment (k-step (k % 32) / 16, tile (n % 128) / 32).
+__global__ void __launch_bounds__(256) gemm_bf16x3_pack_kernel(const float* __restrict__ w, long long sk, long long sn, int k,
+                                                               int n, int kp, int np, __bf16* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)kp * np) return;
+  const int nn = (int)(i % np), kk = (int)(i / np);
+  const float x = (kk < k && nn < n) ? w[kk * sk + nn * sn] : 0.0f;
+  const __bf16 hi = (__bf16)x;
+  const __bf16 lo = (__bf16)(x - (float)hi);
+  const int cb = nn / kBN, nt = (nn % kBN) / 32, ln = nn % 32;
+  const int ks = kk / kBK, kstep = (kk % kBK) / 16, kb = (kk % 16) / 8, j = kk % 8;
+  const long long stage = ((long long)cb * (kp / kBK) + ks) * (kStage / 2);   // in bf16 elements
+  const long long e = stage + frag_off(kstep, nt, 0) / 2 + (ln + 32 * kb) * 8 + j;
+  out[e] = hi;
+  out[e + 512] = lo;
+}
+
+struct GemmArgs {
+  const float* a;
+  long long m, lda;
+  int k, kp;
+  const char* bp;
+  int n, nb;
+  const float* bias;
+  int relu;
+  float* c;
+  long long ldc;
+};
+
+__global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kStage];   // A image, B image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long bid = blockIdx.x;
+  const int cb = (int)(bid % g.nb);          // the column blocks of a row block are neighbours: its A tile is read once
+  const long long row0 = (bid / g.nb) * kBM;  // from HBM and then from cache
+  // A loader: per 32-row group one row per 8 threads, 16 bytes each: full 128-byte lines
+  const int lr = tid >> 3, lc = tid & 7;
+  const float* ap[4];
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long row = row0 + 32 * i + lr;
+    rok[i] = row < g.m;
+    ap[i] = g.a + (rok[i] ? row : 0) * g.lda + lc * 4;
+  }
+  const int nks = g.kp / kBK;
+  const char* bsrc = g.bp + (long long)cb * nks * kStage + tid * 16;
+  f32x4v pa[4];
+  f32x4v pb[4];   // (an ext-vector, not HIP's uint4 struct: that one ended up in scratch memory, loads waited for on issue)
+  auto fetch = [&](int ks) {
+    const bool kok = ks * kBK + lc * 4 < g.k;   // K is a multiple of 4 (checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      pa[i] = (rok[i] && kok) ? *reinterpret_cast<const f32x4v*>(ap[i] + ks * kBK) : f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pb[u] = *reinterpret_cast<const f32x4v*>(bsrc + (long long)ks * kStage + u * 4096);
+  };
+  // the thread's 4 floats of row (32 i + lr): k = 4 lc .. 4 lc + 3 of the step
+  // (lane slots of the A images are permuted, slot = lane ^ 8 for lanes >= 32: the writers of lanes l and l + 32 -- the two
+  // k-halves of one row -- would otherwise hit the same banks; any permutation reads conflict-free)
+  const int a_kb = (lc & 3) >> 1;
+  const int a_slot = frag_off(lc >> 2, 0, 0) + ((lr + 32 * a_kb) ^ (a_kb << 3)) * 16 + (lc & 1) * 8;
+  const int a_lane = (lane ^ ((lane >> 5) << 3)) * 16;
+  auto stash = [&](int stage) {
+    char* As = lds + stage * 2 * kStage;
+    char* Bs = As + kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (__bf16)pa[i][e];
+        lo[e] = (__bf16)(pa[i][e] - (float)hi[e]);
+      }
+      *reinterpret_cast<bf16x4*>(As + a_slot + i * 2048) = hi;
+      *reinterpret_cast<bf16x4*>(As + a_slot + i * 2048 + 1024) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4v*>(Bs + u * 4096 + tid * 16) = pb[u];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // One LDS stage, two barriers per K step; step ks + 1 is in flight in registers during the MFMAs of step ks.  (Two
+  // stages with one barrier per step: 64 KB, two workgroups per CU instead of three -- 56 -> 67 us; what the kernel
+  // needs is waves to overlap its phases, not fewer barriers.)
+  fetch(0);
+  for (int ks = 0; ks < nks; ++ks) {
+    stash(0);
+    __syncthreads();
+    if (ks + 1 < nks) fetch(ks + 1);
+    const char* Ac = lds;
+    const char* Bc = Ac + kStage;
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(Ac + frag_off(kstep, 2 * wm + t, 0) + a_lane);
+        al[t] = *reinterpret_cast<const bf16x8*>(Ac + frag_off(kstep, 2 * wm + t, 1) + a_lane);
+        bh[t] = *reinterpret_cast<const bf16x8*>(Bc + frag_off(kstep, 2 * wn + t, 0) + lane * 16);
+        bl[t] = *reinterpret_cast<const bf16x8*>(Bc + frag_off(kstep, 2 * wn + t, 1) + lane * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // the two small products first, the large one last
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // C / D layout of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = cb * kBN + 64 * wn + 32 * j + (lane & 31);
+      if (col >= g.n) continue;
+      const float b = g.bias ? g.bias[col] : 0.0f;
+      const long long rbase = row0 + 64 * wm + 32 * i + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < g.m) {
+          float v = acc[i][j][r] + b;
+          if (g.relu) v = fmaxf(v, 0.0f);
+          g.c[row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" size_t efg_gemm_bf16x3_pack_bytes(int k, int n) {
+  if (k < 1 || n < 1) return 0;
+  return (size_t)round_up(k, kBK) * (size_t)round_up(n, kBN) * 4;   // hi + lo, 2 bytes each
+}
+
+extern "C" int efg_gemm_bf16x3_pack_f32(const float* w, int64_t stride_k, int64_t stride_n, int k, int n, void* packed,
+                                        void* stream) {
+  EFG_CHECK_ARG(w && packed && k >= 1 && n >= 1, "gemm_bf16x3 pack: bad arguments (k %d, n %d)", k, n);
+  const int kp = round_up(k, kBK), np = round_up(n, kBN);
+  const long long total = (long long)kp * np;
+  hipLaunchKernelGGL(gemm_bf16x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (long long)stride_k, (long long)stride_n, k, n, kp, np, (__bf16*)packed);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda, const void* packed_b, int n,
+                                   const float* bias, int relu, float* c, int64_t ldc, void* stream) {
+  EFG_CHECK_ARG(a && packed_b && c && m >= 0 && k >= 1 && n >= 1, "gemm_bf16x3: bad arguments");
+  EFG_CHECK_ARG(k % 4 == 0 && lda % 4 == 0 && lda >= k && ldc >= n && ((uintptr_t)a & 15) == 0,
+                "gemm_bf16x3: A rows must be 16-byte aligned with K a multiple of 4 (k %d, lda %lld)", k, (long long)lda);
+  if (m == 0) return EFG_OK;
+  GemmArgs g;
+  g.a = a;
+  g.m = m;
+  g.lda = lda;
+  g.k = k;
+  g.kp = round_up(k, kBK);
+  g.bp = (const char*)packed_b;
+  g.n = n;
+  g.nb = round_up(n, kBN) / kBN;
+  g.bias = bias;
+  g.relu = relu;
+  g.c = c;
+  g.ldc = ldc;
+  const long long blocks = ((m + kBM - 1) / kBM) * g.nb;
+  EFG_CHECK_ARG(blocks < (1ll << 31), "gemm_bf16x3: too many tiles");
+  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}

@@ -1,0 +1,34 @@
+"""Split-precision (bf16 x 3) products for the A/B arm of the bench -- csrc/gemm_bf16x3.hip through the C ABI.
+
+Never the default: `EFG_GEMM_ARM=bf16x3` swaps it in for the forward and the data-gradient product of the encoder-sized
+`nn.Linear` layers (operators/linear.py); the weight gradient and everything else stay exact fp32."""
+import torch
+
+from .. import _lib
+
+
+def pack(w, k, n, stride_k, stride_n):
+    """Split B(kk, nn) = w.flatten()[kk * stride_k + nn * stride_n] into the MFMA lane order (device buffer)."""
+    lib = _lib.lib()
+    out = torch.empty(lib.efg_gemm_bf16x3_pack_bytes(k, n), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.efg_gemm_bf16x3_pack_f32(_lib.ptr(w), stride_k, stride_n, k, n, _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def pack_linear(weight, transposed):
+    """weight [out, in] of an nn.Linear.  transposed=False: B = W^T [in, out] (y = x W^T); True: B = W [out, in]
+    (dx = dy W)."""
+    w = weight.contiguous()
+    o, i = w.shape
+    return pack(w, i, o, 1, i) if not transposed else pack(w, o, i, i, 1)
+
+
+def gemm(a, packed, n, bias=None, relu=False):
+    """a [m, k] fp32 (rows contiguous) x packed B [k, n] -> [m, n] fp32."""
+    assert a.dim() == 2 and a.dtype == torch.float32 and a.stride(1) == 1
+    m, k = a.shape
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().efg_gemm_bf16x3_f32(a.data_ptr(), m, k, a.stride(0), _lib.ptr(packed), n,
+                                              _lib.ptr(bias) if bias is not None else None, 1 if relu else 0,
+                                              _lib.ptr(c), n, _lib.stream()))
+    return c

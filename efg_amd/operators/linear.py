@@ -64,11 +64,38 @@ def weight_grad(x2, g2):
     return x2.t().mm(g2).t()  # the call autograd makes for F.linear (tuned solutions apply)
 
 
+# The A/B arm of the bench (EFG_GEMM_ARM=bf16x3, never the default): forward and data-gradient products of the long
+# matrices as three bf16 MFMA products of split operands (csrc/gemm_bf16x3.hip).  The weight gradient, the bias gradient
+# and every short matrix stay exact fp32.
+_ARM_BF16X3 = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
+_packed = {}   # (weight storage, transposed) -> (weight version, packed operand)
+
+
+def _packed_weight(weight, transposed):
+    from . import gemm_bf16x3 as G
+
+    key = (weight.data_ptr(), tuple(weight.shape), transposed)
+    hit = _packed.get(key)
+    if hit is None or hit[0] != weight._version:
+        hit = (weight._version, G.pack_linear(weight.detach(), transposed))
+        _packed[key] = hit
+    return hit[1]
+
+
+def _arm_ok(a2):
+    return (_ARM_BF16X3 and a2.dim() == 2 and a2.stride(1) == 1 and a2.shape[1] % 4 == 0 and a2.stride(0) % 4 == 0
+            and a2.data_ptr() % 16 == 0 and a2.shape[0] > 0)
+
+
 class LinearFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
         x2 = x.reshape(-1, x.shape[-1])
-        if relu and bias is not None:
+        if _arm_ok(x2):
+            from . import gemm_bf16x3 as G
+
+            y = G.gemm(x2, _packed_weight(weight, False), weight.shape[0], bias=bias, relu=relu)
+        elif relu and bias is not None:
             # bias + ReLU in the GEMM epilogue (hipBLASLt): bit-identical to relu(addmm(...)), and the 290 MB
             # activation of the encoder FFN is written once instead of written, read and written again
             # (scripts/ubench/addmm_relu.py: 294 us against 304 + 103 us)
@@ -94,7 +121,12 @@ class LinearFunction(Function):
                 g2, gb = relu_backward_column_sum(g2, y)   # threshold_backward + bias gradient in one pass
             else:
                 g2 = torch.ops.aten.threshold_backward(g2, y, 0)  # what autograd runs for relu
-        gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0] and _arm_ok(g2):
+            from . import gemm_bf16x3 as G
+
+            gx = G.gemm(g2, _packed_weight(weight, True), weight.shape[1]).view(ctx.x_shape)
+        else:
+            gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = weight_grad(x2, g2) if ctx.needs_input_grad[1] else None
         if gb is None and ctx.needs_input_grad[2]:  # bias=None -> needs_input_grad[2] is False
             gb = column_sum(g2)

@@ -465,6 +465,21 @@ int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t row_stride, f
 int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t rows, int cols, float* g_out, float* out, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* ---- split-precision (bf16 x 3) GEMM: the A/B arm of the bench, never the default path ---------------------
+ * C[m, n] = A[m, k] . B[k, n] (+ bias[n]) (ReLU if relu != 0), fp32 in and out, every operand split into two bf16 terms
+ * (x = hi + lo) and hi.hi + hi.lo + lo.hi accumulated in fp32 on the bf16 MFMA: ~2^-16 relative per product instead of
+ * fp32's 2^-24, at 3/16 of the fp32 MFMA time (gemm_bf16x3.hip).  Stands where the encoder's nn.Linear products
+ * ($CQ/transformer.py:215-243, $CQ/modules/box_attention.py:31-40) call hipBLASLt in fp32 when EFG_GEMM_ARM=bf16x3.
+ *   pack: B(kk, nn) = w[kk * stride_k + nn * stride_n] (so a Linear weight [out, in] packs as B = W^T with
+ *         stride_k = 1, stride_n = in, and as B = W with stride_k = in, stride_n = 1), split and laid out in the
+ *         order the MFMA lanes read it; `packed` holds efg_gemm_bf16x3_pack_bytes(k, n) bytes.
+ *   gemm: A rows 16-byte aligned, lda >= k, k % 4 == 0, lda % 4 == 0; C rows ldc floats apart. */
+size_t efg_gemm_bf16x3_pack_bytes(int k, int n);
+int efg_gemm_bf16x3_pack_f32(const float* w, int64_t stride_k, int64_t stride_n, int k, int n, void* packed,
+                             void* stream);
+int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda, const void* packed_b, int n, const float* bias,
+                        int relu, float* c, int64_t ldc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

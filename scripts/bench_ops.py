@@ -86,6 +86,28 @@ def bench_box():
             name, tf, alg / tf / 1e3, tb))
 
 
+def bench_gemm3():
+    """Split-precision (bf16 x 3) GEMM against the fp32 library product at the encoder's Linear shapes."""
+    from efg_amd.operators import gemm_bf16x3 as G
+
+    g = torch.Generator().manual_seed(0)
+    for m, k, n in [(70688, 256, 256), (70688, 256, 1024), (70688, 1024, 256), (70688, 256, 200), (70688, 200, 256),
+                    (70688, 256, 32), (70688, 32, 256)]:
+        a = torch.randn(m, k, generator=g).to(dev)
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+        b = torch.randn(n, generator=g).to(dev)
+        pk = G.pack_linear(w, False)
+        t3 = timeit(lambda: G.gemm(a, pk, n, bias=b))
+        tp = timeit(lambda: G.pack_linear(w, False))
+        t32 = timeit(lambda: torch.addmm(b, a, w.t()))
+        ref = a[:4096].double() @ w.double().t() + b.double()
+        e3 = float((G.gemm(a[:4096], pk, n, bias=b).double() - ref).abs().max() / ref.abs().max())
+        e32 = float((torch.addmm(b, a[:4096], w.t()).double() - ref).abs().max() / ref.abs().max())
+        hbm = 4 * (m * k + m * n)
+        print("gemm %6d x %4d x %4d  bf16x3 %7.1f us (%5.2f TB/s of A + C, %6.1f TFLOP/s fp32-equivalent; pack %5.1f us)   fp32 %7.1f us"
+              "   max err / max |c|: %.1e vs %.1e" % (m, k, n, t3, hbm / t3 / 1e6, 2.0 * m * k * n / t3 / 1e6, tp, t32, e3, e32))
+
+
 def bench_spconv():
     import efg_amd.spconv as spconv
     from efg_amd import _prof
