@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra, untimed steps with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-arm", action="store_true", help="skip the third timing (bf16x3 split-precision A/B arm)")
     ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")
     ap.add_argument("--full-graph", action="store_true", help="make the full reference graph the headline run")
     return ap.parse_args()
@@ -113,6 +114,8 @@ def cpu_baseline(args):
         dt = time.perf_counter() - t0
     cpu_losses = {k: float(v.detach()) for k, v in cpu_losses.items()}
     cpu_losses["__grad_norm__"] = _grad_norm(tr.model)
+    _LAST_CPU_LOSSES.clear()
+    _LAST_CPU_LOSSES.update(cpu_losses)
     tr.close()
     cpu = "?"
     try:
@@ -126,6 +129,9 @@ def cpu_baseline(args):
                       "full ConQueR model (%d queries), oracle C ops (OpenMP) + PyTorch CPU dense layers, %.1f s"
                       % (args.points, args.queries, dt),
             "stages": stages}
+
+
+_LAST_CPU_LOSSES = {}   # the oracle-backed CPU step of cpu_baseline(), kept for the arm's parity check
 
 
 def _grad_norm(model):
@@ -363,9 +369,30 @@ def main():
         except Exception as exc:  # accounting only
             line["geometry"] = {"error": str(exc)}
     trainer.close()
+    # ---- A/B arm: the same step with split-precision (bf16 x 3) products in the encoder-sized Linear layers -----------
+    arm_on = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
+    if not args.no_arm and not arm_on and world == 1 and args.model in ("conquer", "voxeldetr"):
+        import efg_amd.operators.linear as _lin
+
+        del trainer
+        trainer = None
+        torch.cuda.empty_cache()
+        _lin._ARM_BF16X3 = True
+        try:
+            arm = Trainer(config=config, device=dev, overrides=dict(overrides), seed=0)
+            e3 = timed_run(arm, args.steps, args.warmup)
+            arm.close()
+            del arm
+            line["arm_bf16x3"] = {
+                "ms_per_step": 1000.0 * e3 / args.steps, "value": args.scenes * args.steps / e3, "unit": "scenes/s",
+                "steps": args.steps, "warmup": args.warmup,
+                "dtype": "f32 + bf16x3: forward and data-gradient products of the >= 16384-row Linear layers as hi.hi + hi.lo + "
+                         "lo.hi of bf16-split operands, fp32 accumulate (csrc/gemm_bf16x3.hip); everything else exact fp32",
+                "note": "A/B arm, not the headline: `value` above is the exact-fp32 step"}
+        finally:
+            _lin._ARM_BF16X3 = False
     # ---- the same step with the reference's dead branches evaluated ----------------------------------
     if not args.no_full_graph and not args.full_graph and world == 1:
-        del trainer
         torch.cuda.empty_cache()
         ov = dict(overrides)
         ov["model.eval_unused_levels"] = True
@@ -381,6 +408,14 @@ def main():
             base = cpu_baseline(args)
             line["parity_full_size"] = base.pop("parity_full_size")
             line["cpu_baseline"] = base
+            if "arm_bf16x3" in line:   # the arm's own gate: the same full-size step against the same oracle-backed CPU step
+                import efg_amd.operators.linear as _lin
+
+                _lin._ARM_BF16X3 = True
+                try:
+                    line["arm_bf16x3"]["parity_full_size"] = _parity_full_size(args, _LAST_CPU_LOSSES)
+                finally:
+                    _lin._ARM_BF16X3 = False
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -114,6 +114,9 @@ _SIGS = {
     "efg_gemm_bf16x3_pack_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "efg_gemm_bf16x3_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64,
                                     c_void_p]),
+    "efg_gemm_bf16x3_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "efg_gemm_bf16x3_wgrad_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                          c_size_t, c_void_p]),
     "efg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "efg_colsum_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

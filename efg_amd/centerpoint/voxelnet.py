@@ -52,7 +52,9 @@ class VoxelNet(nn.Module):
         if self.device.type != "cuda":
             return None
         if self._geo_stream is None:
-            self._geo_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            from ..streams import side_stream
+
+            self._geo_stream = side_stream(self.device, "geometry", priority=-1)   # one per process and device
         return self._geo_stream
 
     def _inputs(self, samples):

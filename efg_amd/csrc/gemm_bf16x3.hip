@@ -16,6 +16,8 @@
 // bytes in lane order, so operand reads are conflict-free ds_read_b128 with no address arithmetic.
 #include "common.h"
 
+#include <algorithm>
+
 namespace efg {
 namespace {
 
@@ -171,7 +173,132 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmArgs g) {
     }
 }
 
+// ---- weight gradient: dW[n, k] = sum_m G[m, n] . X[m, k]  (both operands row-major activations, the reduction runs
+// over the ROWS) ------------------------------------------------------------------------------------------------------
+// Both MFMA operands want 8 consecutive m per lane, which in a row-major matrix are a row stride apart: each loader
+// thread takes an 8-row x 4-column block (8 coalesced 16-byte loads), so that after the split it holds, per column, the 8
+// consecutive-m elements of one lane -- the transpose costs nothing.  Same LDS images and wave tiling as above; the M range
+// is cut into chunks (one workgroup per chunk and 128 x 128 output tile) whose partial tiles a second kernel sums in
+// chunk order: deterministic, no atomics.
+struct WgradArgs {
+  const float *g, *x;
+  long long m, ldg, ldx;
+  int n, k, tiles_k, rows_per_chunk;
+  float* part;   // [chunks][n][k]
+};
+
+__global__ void __launch_bounds__(256) gemm_bf16x3_tn_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x, chunk = blockIdx.y;
+  const int n0 = (tile / a.tiles_k) * kBN, k0 = (tile % a.tiles_k) * kBN;
+  const long long m_begin = (long long)chunk * a.rows_per_chunk;
+  const long long m_end = min(m_begin + a.rows_per_chunk, a.m);
+  // loader: threads 0..127 the G tile (A operand), 128..255 the X tile (B operand); 32 rows x 128 columns per stage
+  const int which = tid >> 7, lt = tid & 127;
+  const int mblk = lt >> 5, c4 = (lt & 31) * 4;
+  const float* src = which ? a.x : a.g;
+  const long long ld = which ? a.ldx : a.ldg;
+  const int col0 = (which ? k0 : n0) + c4;
+  const bool col_ok = col0 < (which ? a.k : a.n);   // n, k multiples of 4
+  f32x4v pre[8];
+  auto fetch = [&](long long mrow) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const long long row = mrow + 8 * mblk + r;
+      pre[r] = (col_ok && row < m_end) ? *reinterpret_cast<const f32x4v*>(src + row * ld + col0) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  char* img = lds + which * kStage + frag_off(mblk >> 1, (lt & 31) >> 3, 0) + (((lt & 7) * 4) + 32 * (mblk & 1)) * 16;
+  auto stash = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        hi[r] = (__bf16)pre[r][c];
+        lo[r] = (__bf16)(pre[r][c] - (float)hi[r]);
+      }
+      *reinterpret_cast<bf16x8*>(img + c * 16) = hi;
+      *reinterpret_cast<bf16x8*>(img + c * 16 + 1024) = lo;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const char* Ac = lds;
+  const char* Bc = lds + kStage;
+  if (m_begin < m_end) fetch(m_begin);
+  for (long long mrow = m_begin; mrow < m_end; mrow += kBK) {
+    stash();
+    __syncthreads();
+    if (mrow + kBK < m_end) fetch(mrow + kBK);
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(Ac + frag_off(kstep, 2 * wm + t, 0) + lane * 16);
+        al[t] = *reinterpret_cast<const bf16x8*>(Ac + frag_off(kstep, 2 * wm + t, 1) + lane * 16);
+        bh[t] = *reinterpret_cast<const bf16x8*>(Bc + frag_off(kstep, 2 * wn + t, 0) + lane * 16);
+        bl[t] = *reinterpret_cast<const bf16x8*>(Bc + frag_off(kstep, 2 * wn + t, 1) + lane * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  float* out = a.part + (long long)chunk * a.n * a.k;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + 64 * wn + 32 * j + (lane & 31);
+      if (kc >= a.k) continue;
+      const int nbase = n0 + 64 * wm + 32 * i + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = nbase + (r & 3) + 8 * (r >> 2);
+        if (nn < a.n) out[(long long)nn * a.k + kc] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_bf16x3_tn_reduce_kernel(const float* __restrict__ part, int chunks, long long elems,
+                                                                    float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  float s = 0.0f;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {   // four loads in flight, summed in chunk order
+    const float v0 = part[(long long)c * elems + i], v1 = part[(long long)(c + 1) * elems + i],
+                v2 = part[(long long)(c + 2) * elems + i], v3 = part[(long long)(c + 3) * elems + i];
+    s = ((s + v0) + v1) + v2 + v3;
+  }
+  for (; c < chunks; ++c) s += part[(long long)c * elems + i];
+  out[i] = s;
+}
+
 inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+// rows of a chunk: about 512 workgroups in all, whole stages of 32 rows
+inline int tn_rows_per_chunk(long long m, int n, int k) {
+  const int tiles = (round_up(n, kBN) / kBN) * (round_up(k, kBN) / kBN);
+  const long long chunks = std::max<long long>(1, 512 / tiles);
+  const long long rows = (m + chunks - 1) / chunks;
+  return (int)std::max<long long>(kBK, (rows + kBK - 1) / kBK * kBK);
+}
 
 }  // namespace
 }  // namespace efg
@@ -216,6 +343,44 @@ extern "C" int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda
   const long long blocks = ((m + kBM - 1) / kBM) * g.nb;
   EFG_CHECK_ARG(blocks < (1ll << 31), "gemm_bf16x3: too many tiles");
   hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" size_t efg_gemm_bf16x3_wgrad_workspace_bytes(int64_t m, int n, int k) {
+  if (m < 1 || n < 1 || k < 1) return 0;
+  const int rows = tn_rows_per_chunk(m, n, k);
+  const long long chunks = (m + rows - 1) / rows;
+  return (size_t)chunks * (size_t)n * (size_t)k * sizeof(float);
+}
+
+extern "C" int efg_gemm_bf16x3_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t m, int n, int k,
+                                         float* dw, void* ws, size_t ws_bytes, void* stream) {
+  EFG_CHECK_ARG(g && x && dw && m >= 1 && n >= 1 && k >= 1, "gemm_bf16x3 wgrad: bad arguments");
+  EFG_CHECK_ARG(n % 4 == 0 && k % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && ldg >= n && ldx >= k &&
+                    ((uintptr_t)g & 15) == 0 && ((uintptr_t)x & 15) == 0,
+                "gemm_bf16x3 wgrad: rows must be 16-byte aligned, n and k multiples of 4 (n %d, k %d)", n, k);
+  const size_t need = efg_gemm_bf16x3_wgrad_workspace_bytes(m, n, k);
+  EFG_CHECK_ARG(ws && ws_bytes >= need, "gemm_bf16x3 wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  WgradArgs a;
+  a.g = g;
+  a.x = x;
+  a.m = m;
+  a.ldg = ldg;
+  a.ldx = ldx;
+  a.n = n;
+  a.k = k;
+  a.tiles_k = round_up(k, kBN) / kBN;
+  a.rows_per_chunk = tn_rows_per_chunk(m, n, k);
+  a.part = (float*)ws;
+  const int tiles = (round_up(n, kBN) / kBN) * a.tiles_k;
+  const long long chunks = (m + a.rows_per_chunk - 1) / a.rows_per_chunk;
+  EFG_CHECK_ARG(chunks <= 65535, "gemm_bf16x3 wgrad: too many chunks");
+  hipLaunchKernelGGL(gemm_bf16x3_tn_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a);
+  EFG_LAUNCH_CHECK();
+  const long long elems = (long long)n * k;
+  hipLaunchKernelGGL(gemm_bf16x3_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, (int)chunks, elems, dw);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

@@ -181,7 +181,9 @@ class VoxelDETR(nn.Module):
         if self.device.type != "cuda" or os.environ.get("EFG_GEOMETRY_STREAM", "1") == "0":
             return None
         if self._geo_stream is None:
-            self._geo_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            from ..streams import side_stream
+
+            self._geo_stream = side_stream(self.device, "geometry", priority=-1)   # one per process and device
         return self._geo_stream
 
     def forward(self, batched_inputs):

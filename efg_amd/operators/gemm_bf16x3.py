@@ -32,3 +32,17 @@ def gemm(a, packed, n, bias=None, relu=False):
                                               _lib.ptr(bias) if bias is not None else None, 1 if relu else 0,
                                               _lib.ptr(c), n, _lib.stream()))
     return c
+
+
+def wgrad(g, x):
+    """g [m, n] (grad_output), x [m, k] (input), fp32 rows contiguous -> g^T x [n, k] (an nn.Linear's weight gradient)."""
+    assert g.dim() == 2 and x.dim() == 2 and g.shape[0] == x.shape[0] and g.stride(1) == 1 and x.stride(1) == 1
+    m, n = g.shape
+    k = x.shape[1]
+    lib = _lib.lib()
+    out = torch.empty((n, k), dtype=torch.float32, device=g.device)
+    ws_bytes = lib.efg_gemm_bf16x3_wgrad_workspace_bytes(m, n, k)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    _lib.check(lib.efg_gemm_bf16x3_wgrad_f32(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), m, n, k, _lib.ptr(out),
+                                             _lib.ptr(ws), ws_bytes, _lib.stream()))
+    return out

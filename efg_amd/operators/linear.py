@@ -50,23 +50,9 @@ _FUSED_MIN_ROWS = int(os.environ.get("EFG_LINEAR_MIN_ROWS", "16384"))  # linear(
 _SPLITS = 16
 
 
-def weight_grad(x2, g2):
-    """grad_outputᵀ @ x -> [out, in].  With tens of thousands of rows and a 256-wide output the product is one
-    long reduction over few output tiles; the library's own split runs [256, 70688] x [70688, 256] in 136 us
-    (68 TFLOP/s).  Sixteen explicit row chunks as one batched product plus a fixed-order sum of the 16 partial
-    matrices take 85 us (scripts/ubench/wgrad_split.py: 333 -> 262 us for the 1024-wide FFN layers, 138 -> 76 us
-    for the 200-wide attention logits).  Deterministic, same fp32 products."""
-    k = x2.shape[0]
-    if k >= _SPLIT_MIN_ROWS and k % _SPLITS == 0 and x2.is_contiguous() and g2.is_contiguous():
-        gs = g2.view(_SPLITS, k // _SPLITS, g2.shape[1])
-        xs = x2.view(_SPLITS, k // _SPLITS, x2.shape[1])
-        return torch.bmm(gs.transpose(1, 2), xs).sum(0)
-    return x2.t().mm(g2).t()  # the call autograd makes for F.linear (tuned solutions apply)
-
-
 # The A/B arm of the bench (EFG_GEMM_ARM=bf16x3, never the default): forward and data-gradient products of the long
-# matrices as three bf16 MFMA products of split operands (csrc/gemm_bf16x3.hip).  The weight gradient, the bias gradient
-# and every short matrix stay exact fp32.
+# matrices, and their weight gradients, as three bf16 MFMA products of split operands (csrc/gemm_bf16x3.hip).  The bias
+# gradient and every short matrix stay exact fp32.
 _ARM_BF16X3 = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
 _packed = {}   # (weight storage, transposed) -> (weight version, packed operand)
 
@@ -82,9 +68,29 @@ def _packed_weight(weight, transposed):
     return hit[1]
 
 
-def _arm_ok(a2):
+def _arm_ok(a2, min_cols=64):
+    """a2: the [rows, K] operand of a product.  Below K = 64 the split product loses to fp32 (op bench: 32 -> 256 29.6 vs
+    26.2 us; the 32-row weight gradient 44.5 vs 28.5 us)."""
     return (_ARM_BF16X3 and a2.dim() == 2 and a2.stride(1) == 1 and a2.shape[1] % 4 == 0 and a2.stride(0) % 4 == 0
-            and a2.data_ptr() % 16 == 0 and a2.shape[0] > 0)
+            and a2.data_ptr() % 16 == 0 and a2.shape[0] > 0 and a2.shape[1] >= min_cols)
+
+
+def weight_grad(x2, g2):
+    """grad_outputᵀ @ x -> [out, in].  With tens of thousands of rows and a 256-wide output the product is one
+    long reduction over few output tiles; the library's own split runs [256, 70688] x [70688, 256] in 136 us
+    (68 TFLOP/s).  Sixteen explicit row chunks as one batched product plus a fixed-order sum of the 16 partial
+    matrices take 85 us (scripts/ubench/wgrad_split.py: 333 -> 262 us for the 1024-wide FFN layers, 138 -> 76 us
+    for the 200-wide attention logits).  Deterministic, same fp32 products."""
+    if _arm_ok(x2) and _arm_ok(g2):
+        from . import gemm_bf16x3 as G
+
+        return G.wgrad(g2, x2)
+    k = x2.shape[0]
+    if k >= _SPLIT_MIN_ROWS and k % _SPLITS == 0 and x2.is_contiguous() and g2.is_contiguous():
+        gs = g2.view(_SPLITS, k // _SPLITS, g2.shape[1])
+        xs = x2.view(_SPLITS, k // _SPLITS, x2.shape[1])
+        return torch.bmm(gs.transpose(1, 2), xs).sum(0)
+    return x2.t().mm(g2).t()  # the call autograd makes for F.linear (tuned solutions apply)
 
 
 class LinearFunction(Function):

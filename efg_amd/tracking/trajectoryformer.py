@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..operators.iou3d_nms import boxes_iou3d_gpu, nms_gpu, nms_gpu_batched
+from ..streams import side_stream
 from .geometry import (crop_current_frame_points, encode_boxes_res_torch, get_corner_points_of_roi, reorder_rois,
                        rotate_points_along_z, spherical_coordinate, transform_trajs_to_global_coords,
                        transform_trajs_to_local_coords)
@@ -223,7 +224,7 @@ class TrajectoryFormer(OnlineTrackingMixin, nn.Module):
         if self.device.type != "cuda" or os.environ.get("EFG_TF_PREP_STREAM", "1") == "0":
             return fn(batched_inputs)
         if getattr(self, "_prep_stream", None) is None:
-            self._prep_stream = torch.cuda.Stream(self.device)
+            self._prep_stream = side_stream(self.device, "tf-prepare")
         main, side = torch.cuda.current_stream(self.device), self._prep_stream
         events = [s[0].get("ready_event") if isinstance(s, (list, tuple)) else s.get("ready_event")
                   for s, _ in batched_inputs]

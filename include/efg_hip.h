@@ -479,6 +479,12 @@ int efg_gemm_bf16x3_pack_f32(const float* w, int64_t stride_k, int64_t stride_n,
                              void* stream);
 int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda, const void* packed_b, int n, const float* bias,
                         int relu, float* c, int64_t ldc, void* stream);
+/* The weight gradient of the same arm: dw[n, k] = sum over the m rows of g[m, n] * x[m, k] (g = grad_output, x = the
+ * layer's input, both row-major fp32 with 16-byte aligned rows, n and k multiples of 4), split products as above, the row
+ * range summed in a fixed chunk order (deterministic).  ws: efg_gemm_bf16x3_wgrad_workspace_bytes(m, n, k). */
+size_t efg_gemm_bf16x3_wgrad_workspace_bytes(int64_t m, int n, int k);
+int efg_gemm_bf16x3_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t m, int n, int k, float* dw,
+                              void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

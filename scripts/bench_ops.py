@@ -108,6 +108,24 @@ def bench_gemm3():
               "   max err / max |c|: %.1e vs %.1e" % (m, k, n, t3, hbm / t3 / 1e6, 2.0 * m * k * n / t3 / 1e6, tp, t32, e3, e32))
 
 
+def bench_wgrad3():
+    """Split-precision weight gradient g^T x against the fp32 products (library, and operators/linear.py's 16-chunk bmm)."""
+    from efg_amd.operators import gemm_bf16x3 as G
+    from efg_amd.operators.linear import weight_grad
+
+    g = torch.Generator().manual_seed(0)
+    for m, n, k in [(70688, 256, 256), (70688, 1024, 256), (70688, 256, 1024), (70688, 200, 256), (70688, 32, 256)]:
+        go = torch.randn(m, n, generator=g).to(dev)
+        x = torch.randn(m, k, generator=g).to(dev)
+        t3 = timeit(lambda: G.wgrad(go, x))
+        t32 = timeit(lambda: weight_grad(x, go))
+        ref = go.double().t() @ x.double()
+        e3 = float((G.wgrad(go, x).double() - ref).abs().max() / ref.abs().max())
+        e32 = float((weight_grad(x, go).double() - ref).abs().max() / ref.abs().max())
+        print("wgrad %6d rows -> %4d x %4d  bf16x3 %7.1f us (%5.2f TB/s of g + x)   fp32 (16-chunk bmm) %7.1f us   max err / max |dw|: %.1e vs %.1e"
+              % (m, n, k, t3, 4.0 * m * (n + k) / t3 / 1e6, t32, e3, e32))
+
+
 def bench_spconv():
     import efg_amd.spconv as spconv
     from efg_amd import _prof

@@ -43,6 +43,22 @@ def test_data_gradient_product_and_strided_rows():
     assert _rel(G.gemm(view, G.pack_linear(w2, transposed=False), 64), view.double() @ w2.double().t()) < 2e-5
 
 
+@pytest.mark.parametrize("m,n,k", [(70688, 256, 256), (9000, 1024, 256), (9000, 256, 1024), (4097, 200, 256), (4097, 32, 256),
+                                   (31, 256, 256), (33, 8, 4)])
+def test_weight_gradient_matches_fp64(m, n, k):
+    from efg_amd.operators import gemm_bf16x3 as G
+
+    gen = torch.Generator().manual_seed(m + n + k)
+    g = torch.randn(m, n, generator=gen).cuda()
+    x = torch.randn(m, k, generator=gen).cuda()
+    ref = g.double().t() @ x.double()
+    out = G.wgrad(g, x)
+    assert out.shape == (n, k)
+    e3, e32 = _rel(out, ref), _rel(g.t() @ x, ref)
+    assert e3 < 2e-5, (e3, e32)
+    assert torch.equal(out, G.wgrad(g, x))      # fixed summation order: run-to-run identical
+
+
 def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
     """The gate the arm has to pass before its number may be quoted: one full-size ConQueR training step
     with the split-precision products against the same step in exact fp32 -- encoder logits within 1e-4, every loss term
@@ -54,9 +70,10 @@ def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
     from efg_amd.operators import linear as lin
 
     dev = torch.device("cuda:0")
-    calls = []
-    real = G.gemm
+    calls, wcalls = [], []
+    real, real_w = G.gemm, G.wgrad
     monkeypatch.setattr(G, "gemm", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    monkeypatch.setattr(G, "wgrad", lambda *a, **k: (wcalls.append(a[0].shape), real_w(*a, **k))[1])
 
     def step(arm, forced):
         monkeypatch.setattr(lin, "_ARM_BF16X3", arm)
@@ -77,6 +94,7 @@ def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
     assert not calls
     arm, arm_norm, arm_seen = step(True, ref_seen["topk"])
     assert len(calls) >= 30 and all(s[0] >= 16384 for s in calls), len(calls)   # forward + data gradient of the long layers
+    assert len(wcalls) >= 15, len(wcalls)                                        # and their weight gradients
     assert float((arm_seen["logits"] - ref_seen["logits"]).abs().max()) < 1e-4
     for k in ref:
         assert arm[k] == pytest.approx(ref[k], rel=1e-4, abs=1e-6), k
