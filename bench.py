@@ -368,31 +368,30 @@ def main():
             line["geometry"] = _geometry_report(trainer, pool[0])
         except Exception as exc:  # accounting only
             line["geometry"] = {"error": str(exc)}
-    trainer.close()
     # ---- A/B arm: the same step with split-precision (bf16 x 3) products in the encoder-sized Linear layers -----------
+    # On the SAME trainer (the switch is read at call time): same memory, streams and graphs as the fp32 timing above, so
+    # the difference is the products and nothing else (a second model in the process draws new physical memory and, before
+    # efg_amd/streams.py, new hardware queues: one model in three came out 2-3 ms slower).
     arm_on = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
     if not args.no_arm and not arm_on and world == 1 and args.model in ("conquer", "voxeldetr"):
         import efg_amd.operators.linear as _lin
 
-        del trainer
-        trainer = None
-        torch.cuda.empty_cache()
         _lin._ARM_BF16X3 = True
         try:
-            arm = Trainer(config=config, device=dev, overrides=dict(overrides), seed=0)
-            e3 = timed_run(arm, args.steps, args.warmup)
-            arm.close()
-            del arm
+            e3 = timed_run(trainer, args.steps, args.warmup)
             line["arm_bf16x3"] = {
                 "ms_per_step": 1000.0 * e3 / args.steps, "value": args.scenes * args.steps / e3, "unit": "scenes/s",
                 "steps": args.steps, "warmup": args.warmup,
-                "dtype": "f32 + bf16x3: forward and data-gradient products of the >= 16384-row Linear layers as hi.hi + hi.lo + "
-                         "lo.hi of bf16-split operands, fp32 accumulate (csrc/gemm_bf16x3.hip); everything else exact fp32",
+                "dtype": "f32 + bf16x3: forward, data-gradient and weight-gradient products of the >= 16384-row Linear layers as "
+                         "hi.hi + hi.lo + lo.hi of bf16-split operands, fp32 accumulate (csrc/gemm_bf16x3.hip); everything else "
+                         "exact fp32",
                 "note": "A/B arm, not the headline: `value` above is the exact-fp32 step"}
         finally:
             _lin._ARM_BF16X3 = False
+    trainer.close()
     # ---- the same step with the reference's dead branches evaluated ----------------------------------
     if not args.no_full_graph and not args.full_graph and world == 1:
+        del trainer
         torch.cuda.empty_cache()
         ov = dict(overrides)
         ov["model.eval_unused_levels"] = True

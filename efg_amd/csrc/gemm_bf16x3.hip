@@ -31,8 +31,13 @@ constexpr int kStage = 16384;   // bytes of one operand's LDS image per K step: 
 
 __device__ __forceinline__ int frag_off(int kstep, int tile, int part) { return ((kstep * 4 + tile) * 2 + part) * 1024; }
 
-// Packed weights: [col block of 128][K step of 32] -> one 16 KB stage image (above).  Element (k, n) of B sits in
-// lane (n % 32) + 32 * ((k % 16) / 8), element k % 8 of the fragment (k-step (k % 32) / 16, tile (n % 128) / 32).
+// Packed weights: [col block of 128][K step of 32] -> one 16 KB stage image (above).  The reduction does not care which k
+// goes to which (k-step, lane group, element) as long as A and B agree: within a step of 32, lane group g = (k % 32) / 16
+// (lanes 32 g ..), k-step (k % 16) / 8, element k % 8 -- a lane group's 16 floats of a row are contiguous.  Element (k, n)
+// of B sits in lane (n % 32) + 32 g of tile (n % 128) / 32.
+// (Tried on top of this layout and removed: a persistent kernel with the B slice resident in LDS (K <= 256) and A read
+// straight into MFMA fragments, no LDS for A and no barrier -- 105 us against this kernel's 56 us at 70 688 x 256 x 256:
+// 8 waves per CU and a 4-chunk register ring do not cover the memory latency that 12 waves and the LDS stage do.)
 __global__ void __launch_bounds__(256) gemm_bf16x3_pack_kernel(const float* __restrict__ w, long long sk, long long sn, int k,
                                                                int n, int kp, int np, __bf16* __restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -42,7 +47,7 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_pack_kernel(const float* __re
   const __bf16 hi = (__bf16)x;
   const __bf16 lo = (__bf16)(x - (float)hi);
   const int cb = nn / kBN, nt = (nn % kBN) / 32, ln = nn % 32;
-  const int ks = kk / kBK, kstep = (kk % kBK) / 16, kb = (kk % 16) / 8, j = kk % 8;
+  const int ks = kk / kBK, kb = (kk % kBK) / 16, kstep = (kk % 16) / 8, j = kk % 8;
   const long long stage = ((long long)cb * (kp / kBK) + ks) * (kStage / 2);   // in bf16 elements
   const long long e = stage + frag_off(kstep, nt, 0) / 2 + (ln + 32 * kb) * 8 + j;
   out[e] = hi;
@@ -93,8 +98,8 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_kernel(GemmArgs g) {
   // the thread's 4 floats of row (32 i + lr): k = 4 lc .. 4 lc + 3 of the step
   // (lane slots of the A images are permuted, slot = lane ^ 8 for lanes >= 32: the writers of lanes l and l + 32 -- the two
   // k-halves of one row -- would otherwise hit the same banks; any permutation reads conflict-free)
-  const int a_kb = (lc & 3) >> 1;
-  const int a_slot = frag_off(lc >> 2, 0, 0) + ((lr + 32 * a_kb) ^ (a_kb << 3)) * 16 + (lc & 1) * 8;
+  const int a_kb = lc >> 2;   // floats 4 lc .. 4 lc + 3 of the step: lane group (4 lc) / 16, k-step ((4 lc) % 16) / 8
+  const int a_slot = frag_off((lc >> 1) & 1, 0, 0) + ((lr + 32 * a_kb) ^ (a_kb << 3)) * 16 + (lc & 1) * 8;
   const int a_lane = (lane ^ ((lane >> 5) << 3)) * 16;
   auto stash = [&](int stage) {
     char* As = lds + stage * 2 * kStage;

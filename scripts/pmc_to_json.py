@@ -32,7 +32,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             v["launches_" + ctr] = tot + n
 out = {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "source": "%s/{FETCH_SIZE,WRITE_SIZE}.summary.csv: rocprofv3 --kernel-trace --pmc <ctr> -- python bench.py --steps 2 "
-                 "--warmup 1 --no-cpu-baseline --no-full-graph (scripts/round_profile.sh)" % src.rstrip("/").split("/")[-1],
+                 "--warmup 1 --no-cpu-baseline --no-full-graph --no-arm (scripts/round_profile.sh)" % src.rstrip("/").split("/")[-1],
        "kernels": {}}
 for name, v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
