@@ -112,6 +112,7 @@ _SIGS = {
                             [c_size_t, c_void_p]),
     "efg_gemm_bf16x3_pack_bytes": (c_size_t, [c_int, c_int]),
     "efg_gemm_bf16x3_pack_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "efg_gemm_bf16x3_pack_linear_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_gemm_bf16x3_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64,
                                     c_void_p]),
     "efg_gemm_bf16x3_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),

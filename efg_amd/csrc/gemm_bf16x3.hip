@@ -54,6 +54,36 @@ __global__ void __launch_bounds__(256) gemm_bf16x3_pack_kernel(const float* __re
   out[e + 512] = lo;
 }
 
+// Both layouts an nn.Linear weight w[out, in] is needed in, in one launch: B = w^T (k = in, n = out) for y = x w^T and
+// B = w (k = out, n = in) for dx = dy w.
+__device__ __forceinline__ long long packed_index(int kk, int nn, int kp) {
+  const int cb = nn / kBN, nt = (nn % kBN) / 32, ln = nn % 32;
+  const int ks = kk / kBK, kb = (kk % kBK) / 16, kstep = (kk % 16) / 8, j = kk % 8;
+  return ((long long)cb * (kp / kBK) + ks) * (kStage / 2) + frag_off(kstep, nt, 0) / 2 + (ln + 32 * kb) * 8 + j;
+}
+
+__global__ void __launch_bounds__(256) gemm_bf16x3_pack_linear_kernel(const float* __restrict__ w, int n_out, int n_in,
+                                                                      __bf16* __restrict__ fwd, __bf16* __restrict__ dgrad) {
+  const int ip = (n_in + 127) / 128 * 128, op = (n_out + 127) / 128 * 128;   // both dims padded to the larger granule
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)ip * op) return;
+  const int ci = (int)(i % ip), ro = (int)(i / ip);
+  const float x = (ro < n_out && ci < n_in) ? w[(long long)ro * n_in + ci] : 0.0f;
+  const __bf16 hi = (__bf16)x;
+  const __bf16 lo = (__bf16)(x - (float)hi);
+  const int in_kp = (n_in + kBK - 1) / kBK * kBK, out_kp = (n_out + kBK - 1) / kBK * kBK;
+  if (ci < in_kp && ro < op) {     // forward: k = ci, n = ro
+    const long long e = packed_index(ci, ro, in_kp);
+    fwd[e] = hi;
+    fwd[e + 512] = lo;
+  }
+  if (ro < out_kp && ci < ip) {    // data gradient: k = ro, n = ci
+    const long long e = packed_index(ro, ci, out_kp);
+    dgrad[e] = hi;
+    dgrad[e + 512] = lo;
+  }
+}
+
 struct GemmArgs {
   const float* a;
   long long m, lda;
@@ -386,6 +416,16 @@ extern "C" int efg_gemm_bf16x3_wgrad_f32(const float* g, int64_t ldg, const floa
   const long long elems = (long long)n * k;
   hipLaunchKernelGGL(gemm_bf16x3_tn_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)ws, (int)chunks, elems, dw);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_gemm_bf16x3_pack_linear_f32(const float* w, int n_out, int n_in, void* packed_fwd, void* packed_dgrad,
+                                               void* stream) {
+  EFG_CHECK_ARG(w && packed_fwd && packed_dgrad && n_out >= 1 && n_in >= 1, "gemm_bf16x3 pack_linear: bad arguments");
+  const long long total = (long long)round_up(n_in, 128) * round_up(n_out, 128);
+  hipLaunchKernelGGL(gemm_bf16x3_pack_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     n_out, n_in, (__bf16*)packed_fwd, (__bf16*)packed_dgrad);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

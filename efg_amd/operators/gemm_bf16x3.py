@@ -23,6 +23,17 @@ def pack_linear(weight, transposed):
     return pack(w, i, o, 1, i) if not transposed else pack(w, o, i, i, 1)
 
 
+def pack_linear_both(weight):
+    """(B = W^T for y = x W^T, B = W for dx = dy W) of an nn.Linear weight [out, in], one launch."""
+    w = weight.contiguous()
+    o, i = w.shape
+    lib = _lib.lib()
+    fwd = torch.empty(lib.efg_gemm_bf16x3_pack_bytes(i, o), dtype=torch.uint8, device=w.device)
+    dgr = torch.empty(lib.efg_gemm_bf16x3_pack_bytes(o, i), dtype=torch.uint8, device=w.device)
+    _lib.check(lib.efg_gemm_bf16x3_pack_linear_f32(_lib.ptr(w), o, i, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream()))
+    return fwd, dgr
+
+
 def gemm(a, packed, n, bias=None, relu=False):
     """a [m, k] fp32 (rows contiguous) x packed B [k, n] -> [m, n] fp32."""
     assert a.dim() == 2 and a.dtype == torch.float32 and a.stride(1) == 1

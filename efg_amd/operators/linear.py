@@ -54,18 +54,9 @@ _SPLITS = 16
 # matrices, and their weight gradients, as three bf16 MFMA products of split operands (csrc/gemm_bf16x3.hip).  The bias
 # gradient and every short matrix stay exact fp32.
 _ARM_BF16X3 = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
-_packed = {}   # (weight storage, transposed) -> (weight version, packed operand)
-
-
-def _packed_weight(weight, transposed):
-    from . import gemm_bf16x3 as G
-
-    key = (weight.data_ptr(), tuple(weight.shape), transposed)
-    hit = _packed.get(key)
-    if hit is None or hit[0] != weight._version:
-        hit = (weight._version, G.pack_linear(weight.detach(), transposed))
-        _packed[key] = hit
-    return hit[1]
+# (No cache of the split weights across calls: one keyed on the parameter's `_version` went stale -- the fused AdamW step
+# updates parameters without moving it; tests/test_gemm_bf16x3_gpu.py::test_split_weights_follow_the_optimizer.  The
+# forward packs both layouts in one launch and hands the data-gradient one to the backward.)
 
 
 def _arm_ok(a2, min_cols=64):
@@ -97,10 +88,12 @@ class LinearFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.packed_dgrad = None
         if _arm_ok(x2):
             from . import gemm_bf16x3 as G
 
-            y = G.gemm(x2, _packed_weight(weight, False), weight.shape[0], bias=bias, relu=relu)
+            packed_fwd, ctx.packed_dgrad = G.pack_linear_both(weight.detach())
+            y = G.gemm(x2, packed_fwd, weight.shape[0], bias=bias, relu=relu)
         elif relu and bias is not None:
             # bias + ReLU in the GEMM epilogue (hipBLASLt): bit-identical to relu(addmm(...)), and the 290 MB
             # activation of the encoder FFN is written once instead of written, read and written again
@@ -130,7 +123,8 @@ class LinearFunction(Function):
         if ctx.needs_input_grad[0] and _arm_ok(g2):
             from . import gemm_bf16x3 as G
 
-            gx = G.gemm(g2, _packed_weight(weight, True), weight.shape[1]).view(ctx.x_shape)
+            packed = ctx.packed_dgrad if ctx.packed_dgrad is not None else G.pack_linear(weight.detach(), True)
+            gx = G.gemm(g2, packed, weight.shape[1]).view(ctx.x_shape)
         else:
             gx = g2.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         gw = weight_grad(x2, g2) if ctx.needs_input_grad[1] else None

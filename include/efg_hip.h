@@ -477,6 +477,9 @@ int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t rows, int co
 size_t efg_gemm_bf16x3_pack_bytes(int k, int n);
 int efg_gemm_bf16x3_pack_f32(const float* w, int64_t stride_k, int64_t stride_n, int k, int n, void* packed,
                              void* stream);
+/* Both layouts of an nn.Linear weight w[n_out, n_in] in one launch: packed_fwd = pack(B = w^T; efg_gemm_bf16x3_pack_bytes(n_in,
+ * n_out) bytes) for y = x w^T, packed_dgrad = pack(B = w; ..._pack_bytes(n_out, n_in) bytes) for dx = dy w. */
+int efg_gemm_bf16x3_pack_linear_f32(const float* w, int n_out, int n_in, void* packed_fwd, void* packed_dgrad, void* stream);
 int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda, const void* packed_b, int n, const float* bias,
                         int relu, float* c, int64_t ldc, void* stream);
 /* The weight gradient of the same arm: dw[n, k] = sum over the m rows of g[m, n] * x[m, k] (g = grad_output, x = the

@@ -99,3 +99,24 @@ def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
     for k in ref:
         assert arm[k] == pytest.approx(ref[k], rel=1e-4, abs=1e-6), k
     assert arm_norm == pytest.approx(ref_norm, rel=5e-4)
+
+
+def test_split_weights_follow_the_optimizer(monkeypatch):
+    """The arm caches the split weight per parameter version: after an (in-place, fused) optimizer step the next product must
+    use the NEW weight."""
+    from efg_amd.operators import linear as lin
+
+    monkeypatch.setattr(lin, "_ARM_BF16X3", True)
+    g = torch.Generator().manual_seed(11)
+    layer = lin.Linear(256, 256).cuda()
+    opt = torch.optim.AdamW(layer.parameters(), lr=0.05, fused=True)
+    x = torch.randn(20000, 256, generator=g).cuda()
+    for _ in range(3):
+        y = layer(x)
+        ref = x.double() @ layer.weight.detach().double().t() + layer.bias.detach().double()
+        assert _rel(y.detach(), ref) < 2e-5
+        y.square().mean().backward()
+        gw = (2.0 / y.numel()) * (y.detach().double().t() @ x.double())
+        assert _rel(layer.weight.grad, gw) < 5e-5
+        opt.step()
+        opt.zero_grad(set_to_none=True)
