@@ -40,9 +40,30 @@ __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 // for_dgrad bit 1 ("natural order", the 16-byte-gather tile kernel): red = r16*16 + 4*kk + j instead.
 __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin,
                                                            int for_dgrad, float* __restrict__ packed) {
-  const int natural = for_dgrad & 2;
+  const int natural = for_dgrad & 2, bf3 = for_dgrad & 4;
   for_dgrad &= 1;
   const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
+  if (bf3) {
+    // split-precision arm of the tile kernel (spconv_tiles.hip, MODE & 4; red % 32 == 0, nn % 64 == 0): per (offset,
+    // 32-channel step, n-tile of 16) 2 KB = the 64 lanes' 8 bf16 of W_hi, then of W_lo, lane = n % 16 + 16 * ((red % 32) / 8)
+    typedef __bf16 bf16_t;
+    bf16_t* out = reinterpret_cast<bf16_t*>(packed);
+    const int c32n = red / 32, nt16 = nn / 16;
+    const long long total = (long long)kvol * red * nn;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+      const int n = (int)(e % nn);
+      long long q = e / nn;
+      const int r = (int)(q % red), k = (int)(q / red);
+      const int co = for_dgrad ? r : n, ci = for_dgrad ? n : r;
+      const float v = w[((long long)co * kvol + k) * cin + ci];
+      const bf16_t hi = (bf16_t)v;
+      const bf16_t lo = (bf16_t)(v - (float)hi);
+      const long long idx = ((((long long)k * c32n + r / 32) * nt16 + n / 16) * 1024) + ((n % 16) + 16 * ((r % 32) / 8)) * 8 + (r % 8);
+      out[idx] = hi;
+      out[idx + 512] = lo;
+    }
+    return;
+  }
   const int r16n = round16(red) / 16, np = round16(nn);
   const long long total = (long long)kvol * r16n * np * 16;
   // (+ the slack row kernels with NT > tiles read past the last n-tile: written as zeros here, no separate memset)
@@ -698,6 +719,11 @@ extern "C" int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvo
                                           float* packed, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EFG_CHECK_ARG(cout >= 1 && cin >= 1 && kvol >= 1, "spconv: bad weight shape");
+  if (for_dgrad & 4) {   // split-precision layout of the tile kernel's A/B arm: whole 32-channel steps, whole n-tile groups
+    const int red = (for_dgrad & 1) ? cout : cin, nn = (for_dgrad & 1) ? cin : cout;
+    EFG_CHECK_ARG(!(for_dgrad & 2) && red % 32 == 0 && nn % 64 == 0,
+                  "spconv: the bf16x3 weight layout needs red %% 32 == 0 and n %% 64 == 0 (got %d, %d)", red, nn);
+  }
   const size_t bytes = efg_spconv_packed_weight_bytes(cout, kvol, cin, for_dgrad);
   const long long total = (long long)(bytes / sizeof(float));
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256),

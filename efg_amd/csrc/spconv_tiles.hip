@@ -30,6 +30,7 @@ namespace efg {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kChunkRows = 1024;  // rows sorted together (one workgroup of the plan kernel)
 constexpr int kCKt = 64;          // channels per staged chunk
@@ -195,6 +196,7 @@ struct TileArgs {
   int sk_polls;          // polls of a share's flag before the unit is recomputed instead (EFG_TILE_SK_POLLS, default 20000)
   unsigned ux, uy;       // the unit grid (what gridDim is otherwise)
   long long zero_off;    // byte offset from `in` of 16 zero bytes (absent rows / channel pieces past cin gather those)
+  int bf3;               // 1: split-precision arm (MODE & 4), weights packed by efg_spconv_pack_weight_f32 with flag 4
   int v4;                // 1: 16-byte gathers, natural-order packed weights (cin % 4 == 0)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
                          // the transposed table of a symmetric window is the table with the offsets reversed)
@@ -212,7 +214,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE 
 conv_tile_kernel(TileArgs a) {
   constexpr int SK = (MODE >> 1) & 1;  // stream-K: the (unit, offset) items are cut into equal shares, one per workgroup
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
-  constexpr int kAStr = V4 ? kCKt : kCKt + 2;        // LDS row stride of the A tile (V4: swizzled pieces, no padding)
+  constexpr int BF3 = (MODE >> 2) & 1;  // A/B arm: three bf16 MFMA products of split operands instead of the fp32 MFMA
+  // LDS row stride of the A tile (V4: swizzled pieces, no padding; BF3: 16-byte aligned rows for the 32-byte fragment reads)
+  constexpr int kAStr = V4 ? kCKt : (BF3 ? kCKt + 4 : kCKt + 2);
   __shared__ __attribute__((aligned(16))) float a_tile[4][R * 16 * kAStr];  // wave-private A staging
   __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
   __shared__ int s_redo_flag;                        // stream-K: a share did not arrive in time, recompute the unit
@@ -371,6 +375,45 @@ conv_tile_kernel(TileArgs a) {
       b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
   };
   auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
+    if (BF3) {
+      // Split-precision arm: per 32-channel step the lane's 8 consecutive channels of its row (two 16-byte LDS reads) are
+      // split into bf16 hi / lo in registers; the weights arrive split and in lane order (2 KB per n-tile: hi | lo);
+      // hi.lo + lo.hi + hi.hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate (same C layout as the fp32 form).
+      const int m = lane & 15, kk = lane >> 4;
+      const int k = a.flip ? (a.kvol - 1 - col) : col;
+      const int c32n = a.c16n >> 1, c32_lo = ch * (kCKt / 32);
+      const int nc2 = min(kCKt / 32, c32n - c32_lo);
+      for (int i2 = 0; i2 < nc2; ++i2) {
+        const char* bp = reinterpret_cast<const char*>(a.wp) +
+                         (((size_t)k * c32n + c32_lo + i2) * (a.np >> 4) + n_tile0) * 2048u + lane * 16;
+        bf16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          bh[t] = *reinterpret_cast<const bf16x8*>(bp + t * 2048);
+          bl[t] = *reinterpret_cast<const bf16x8*>(bp + t * 2048 + 1024);
+        }
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+          if ((s == 0 ? m0 : m1) == 0) continue;
+          const float* ap = at + (s * 16 + m) * kAStr + i2 * 32 + kk * 8;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(ap), x1 = *reinterpret_cast<const f32x4*>(ap + 4);
+          bf16x8 ah, al;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? x0[e & 3] : x1[e & 3];
+            ah[e] = (__bf16)x;
+            al[e] = (__bf16)(x - (float)ah[e]);
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[t], acc[s][t], 0, 0, 0);
+            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[t], acc[s][t], 0, 0, 0);
+            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[t], acc[s][t], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     const int c16_lo = ch * (kCKt / 16);
     const int m = lane & 15, kk = lane >> 4;
     const unsigned boff0 = b_offset(col, ch);
@@ -718,6 +761,11 @@ template <int NT, int R, int V4>
 void launch_tiles_v(const TileArgs& a, int ny, int ks, hipStream_t stream) {
   // stream-K exists for the 64-channel-wide wave tiles with 4-byte gathers and the split-K shape only (the default shapes)
   constexpr bool kModes = (NT == 4 && V4 == 0);
+  if (kModes && a.bf3 && ks == 4) {   // the split-precision arm exists for this shape only (run_tiles checked)
+    if (a.sk_scratch) launch_tiles_k<NT, R, 4, V4, kModes ? 6 : 0>(a, (unsigned)((a.n_tiles + R - 1) / R), ny, stream);
+    else launch_tiles_k<NT, R, 4, V4, kModes ? 4 : 0>(a, (unsigned)((a.n_tiles + R - 1) / R), ny, stream);
+    return;
+  }
   if (kModes && a.sk_scratch && ks == 4) launch_tiles_x<NT, R, V4, kModes ? 2 : 0>(a, ny, ks, stream);
   else launch_tiles_x<NT, R, V4, 0>(a, ny, ks, stream);
 }
@@ -785,9 +833,20 @@ int streamk_for_stream(hipStream_t stream, StreamKState** out) {
   return EFG_OK;
 }
 
+// The split-precision arm covers the 64-channel-wide split-K shape (NT = 4, KS = 4) with whole 32-channel reduction steps
+// and whole groups of 4 n-tiles; ONE rule for the launcher, the packer's caller and efg_spconv_tile_bf16x3_ok.
+bool bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {
+  int nt, r, ks, pipe;
+  tile_shape(cin, cout, kvol, m_in, m_out, &nt, &r, &ks, &pipe);
+  return nt == 4 && ks == 4 && kvol <= 31 && cin >= 64 && cin % 32 == 0 && cout % 64 == 0;
+}
+
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
-              const void* plan, int64_t m_out, float* out, int flip, int natural_order, hipStream_t stream) {
+              const void* plan, int64_t m_out, float* out, int flip, int natural_order, int bf3, hipStream_t stream) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
+  EFG_CHECK_ARG(!bf3 || (!natural_order && bf16x3_ok(cin, cout, kvol, m_in, m_out)),
+                "spconv tiled: the bf16x3 arm does not cover %d -> %d channels, kvol %d (ask efg_spconv_tile_bf16x3_ok)", cin,
+                cout, kvol);
   EFG_CHECK_ARG(kvol >= 1 && kvol <= 31, "spconv tiled: kernel volume must be in [1,31], got %d", kvol);
   if (m_out == 0) return EFG_OK;
   EFG_CHECK_ARG(m_in >= 0 && (unsigned long long)m_in * (unsigned long long)cin * 4ull < (1ull << 32),
@@ -809,6 +868,7 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.np = (cout + 15) / 16 * 16;
   a.flip = flip;
   a.v4 = natural_order ? 1 : 0;
+  a.bf3 = bf3 ? 1 : 0;
   a.zero_off = 0;
   if (a.v4) {
     static const char* zero_piece[64] = {};  // per device: address of g_zero_piece
@@ -912,5 +972,9 @@ extern "C" int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, 
                                             const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                             int flip_offsets, float* out_feat, void* stream) {
   return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets & 1, (flip_offsets >> 1) & 1,
-                   (hipStream_t)stream);
+                   (flip_offsets >> 2) & 1, (hipStream_t)stream);
+}
+
+extern "C" int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {
+  return (cin >= 1 && cout >= 1 && kvol >= 1 && bf16x3_ok(cin, cout, kvol, m_in, m_out)) ? 1 : 0;
 }

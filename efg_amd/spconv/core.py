@@ -116,12 +116,30 @@ def _natural_order(reduce_channels):
     return 2 if reduce_channels % 4 == 0 and os.environ.get("EFG_TILE_V4", "0") == "1" else 0
 
 
+_ARM_OK = {}
+
+
+def _arm_bf16x3(cin, cout, kvol, m_in, m_out):
+    """4 (the flag of the pack / tiled-conv entry points) when the split-precision A/B arm is on (operators/linear.py's switch,
+    EFG_GEMM_ARM=bf16x3) and the library's tile kernel covers this convolution, else 0."""
+    from ..operators import linear as _lin
+
+    if not _lin._ARM_BF16X3 or os.environ.get("EFG_CONV_ARM", "1") == "0":   # (EFG_CONV_ARM=0: the arm without its convolutions)
+        return 0
+    key = (cin, cout, kvol, m_in == m_out)
+    if key not in _ARM_OK:
+        _ARM_OK[key] = 4 if L.lib().efg_spconv_tile_bf16x3_ok(cin, cout, kvol, m_in, m_out) else 0
+    return _ARM_OK[key]
+
+
 def _conv_forward(features, w, bias, rb):
     """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
     lib = L.lib()
     cout, kvol, cin = w.shape
     tiled = _tiled() and kvol <= 31 and rb.m_out > 0
     nat = _natural_order(cin) if tiled else 0
+    if tiled and not nat:
+        nat = _arm_bf16x3(cin, cout, kvol, rb.m_in, rb.m_out)   # (bit 2 of the same flag word)
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
                          device=features.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0 | nat, L.ptr(packed), L.stream()))
@@ -143,6 +161,8 @@ def _conv_dgrad(grad_out, w, rb):
     cout, kvol, cin = w.shape
     tiled = _tiled() and kvol <= 31 and rb.m_in > 0
     nat = _natural_order(cout) if tiled else 0
+    if tiled and not nat:
+        nat = _arm_bf16x3(cout, cin, kvol, rb.m_out, rb.m_in)
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8,
                          device=grad_out.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1 | nat, L.ptr(packed), L.stream()))

@@ -145,7 +145,10 @@ int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m
  * v_mfma_f32_16x16x4_f32):  for_dgrad = 0: packed[k][cin/16][cout_pad][16]  (reduce over cin)
  *                           for_dgrad = 1: packed[k][cout/16][cin_pad][16]  (reduce over cout).
  * Within a 16-channel group the lane kk's fragment holds channels {kk, kk+4, kk+8, kk+12}; for_dgrad | 2 ("natural
- * order", what efg_spconv_forward_tiled_f32 takes with flip_offsets | 2) holds {4kk .. 4kk+3} instead. */
+ * order", what efg_spconv_forward_tiled_f32 takes with flip_offsets | 2) holds {4kk .. 4kk+3} instead.
+ * for_dgrad | 4: the split-precision (bf16 x 3) layout of the tile kernel's A/B arm (flip_offsets | 4 there; reduction
+ * width a multiple of 32, output width a multiple of 64; same size): per (offset, 32-channel step, n-tile of 16) the 64
+ * lanes' 8 bf16 of W_hi, then of W_lo.  efg_spconv_tile_bf16x3_ok says whether a layer is covered. */
 size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad);
 int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad, float* packed,
                                void* stream);
@@ -188,6 +191,8 @@ int efg_spconv_tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_o
 int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);
+/* 1 when the split-precision arm of the tile kernel covers a (cin -> cout, kvol) convolution of these table sizes. */
+int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out);
 
 /* order[m]: the rows of `indices` (int32 [m][4] = b, z, y, x) grouped by the parity of (z, y, x) -- the rows of a
  * stride-2 layer's dgrad that share their set of reachable kernel offsets.  ws: 64 bytes. */

@@ -72,3 +72,23 @@ def test_streamk_matches_plain_launch_and_is_reproducible(tmp_path):
         np.testing.assert_allclose(on[k], off[k], rtol=2e-5, atol=2e-5 * scale, err_msg=k)
         assert np.array_equal(on[k], again[k]), "%s differs between two stream-K runs" % k
         np.testing.assert_allclose(redo[k], off[k], rtol=2e-5, atol=2e-5 * scale, err_msg=k + " (recompute path)")
+
+
+def test_split_precision_arm_of_the_tile_kernel(tmp_path):
+    """EFG_GEMM_ARM=bf16x3 (the bench's A/B arm): forward and data gradient of the 64-channel-wide split-K shapes as three bf16
+    MFMA products of split operands (MODE & 4 of conv_tile_kernel), plain and stream-K launch, against the exact fp32 kernel."""
+    off = _run(tmp_path, "fp32", {"EFG_TILE_STREAMK": "0"})
+    arm = _run(tmp_path, "arm", {"EFG_TILE_STREAMK": "0", "EFG_GEMM_ARM": "bf16x3"})
+    arm_sk = _run(tmp_path, "arm_sk", {"EFG_TILE_STREAMK": "2", "EFG_GEMM_ARM": "bf16x3"})
+    again = _run(tmp_path, "arm_sk2", {"EFG_TILE_STREAMK": "2", "EFG_GEMM_ARM": "bf16x3"})
+    changed = 0
+    for k in off:
+        if k.startswith("rows_"):
+            continue
+        scale = float(np.abs(off[k]).max())
+        for name, got in (("arm", arm), ("arm + stream-K", arm_sk)):
+            err = float(np.abs(got[k] - off[k]).max()) / scale
+            assert err < 3e-5, (k, name, err)       # 16 significand bits per operand; a wrong lane order would be O(1)
+            changed += err > 0
+        assert np.array_equal(arm_sk[k], again[k]), "%s differs between two runs" % k
+    assert changed >= 8                              # the arm really ran (fp32 against itself would be exactly 0)
