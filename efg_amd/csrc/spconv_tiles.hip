@@ -19,6 +19,7 @@
 // MFMAs; the offsets of a tile are split over the KS waves of its workgroup and summed through LDS (small levels).
 // The prologue is three coalesced loads (rows, neighbour block, masks) -- no ballots, no index arithmetic.
 #include "common.h"
+#include "tile_plan.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -32,43 +33,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kChunkRows = 1024;  // rows sorted together (one workgroup of the plan kernel)
 constexpr int kCKt = 64;          // channels per staged chunk
 constexpr int kStreamKMaxGrid = 4096;  // workgroups of a stream-K launch (256 CUs x at most 16)
-
-// ---- plan -------------------------------------------------------------------------------------------------
-// layout of the plan buffer for (m rows, kvol offsets), n_tiles = round_up(m, 1024) / 16:
-//   rows i32 [n_tiles][16] | nb i32 [n_tiles][kvol][16] | vm u32 [n_tiles][32]   (vm[.][31] = active offsets)
-//   | pfx1 i32 [n_tiles + 1] | pfx2 i32 [n_tiles / 2 + 1]
-// pfxR: exclusive prefix sums of the item counts of the units of R consecutive tiles (stream-K, conv_tile_kernel): a
-// unit's items are its active offsets (the union over its tiles); a unit with rows but no offset counts one item, so
-// that its rows are still written.
-struct PlanView {
-  int* rows;
-  int* nb;
-  unsigned* vm;
-  int* pfx1;
-  int* pfx2;
-  long long n_tiles;
-};
-
-__host__ __device__ inline long long plan_tiles(long long m) { return (m + kChunkRows - 1) / kChunkRows * (kChunkRows / 16); }
-
-inline size_t plan_bytes(long long m, int kvol) {
-  const long long t = plan_tiles(m);
-  return (size_t)t * 16 * 4 + (size_t)t * kvol * 16 * 4 + (size_t)t * 32 * 4 + (size_t)(t + 1) * 4 + (size_t)(t / 2 + 1) * 4;
-}
-
-inline PlanView plan_view(void* p, long long m, int kvol) {
-  PlanView v;
-  v.n_tiles = plan_tiles(m);
-  v.rows = static_cast<int*>(p);
-  v.nb = v.rows + v.n_tiles * 16;
-  v.vm = reinterpret_cast<unsigned*>(v.nb + v.n_tiles * kvol * 16);
-  v.pfx1 = reinterpret_cast<int*>(v.vm + v.n_tiles * 32);
-  v.pfx2 = v.pfx1 + v.n_tiles + 1;
-  return v;
-}
 
 // pfx[u] = items of the units before u, for units of R tiles (n_tiles is a multiple of 64).  Two workgroups, one launch:
 // blockIdx.x = 0 -> R = 1 (pfx1), 1 -> R = 2 (pfx2).

@@ -1,0 +1,314 @@
+// Weight gradient of a sparse convolution over a TILE PLAN (spconv_tiles.hip), for gfx950.
+//
+//   dW[co][k][ci] = sum_o G[o][co] * X[nbr[k][o]][ci]
+// (reference: spconv's indice-conv backward -- the pair-gathered GEMM  dW_k = G_pairs^T . X_pairs  per kernel offset,
+// called from efg/modeling/backbones/sparse_net.py through spconv.SparseConv3d / SubMConv3d).
+//
+// The first-generation kernel (spconv_conv.hip: conv_wgrad_kernel) walks the neighbour table, compacts the valid
+// (out row, in row) pairs of 256 rows through an LDS queue with ballots and workgroup barriers, stages 32-pair tiles
+// of both operands in LDS and reads MFMA fragments back: three barriers per 1024 MFMA cycles, 0.31 of the fp32 MFMA
+// peak in the training step.  Here the reduction dimension of the product IS the row dimension, so a 16-row tile of
+// the plan is four K-steps of v_mfma_f32_16x16x4_f32 whose operands can come straight from HBM / L2 in fragment layout:
+// lane (m = lane & 15, kk = lane >> 4) of K-step q supplies A[m][kk] = G[row(4 kk + q)][channel of m] and
+// B[kk][m] = X[nbr(4 kk + q)][channel of m] -- and since WHICH channel an M / N index stands for is free, a lane takes 4
+// consecutive channels of its row for the 4 tiles of the block: one 16-byte load per operand and K-step, the 16 lanes of
+// a row reading its 256 bytes contiguously.  No LDS, no transposition, no barrier.
+// The plan has already sorted the rows by neighbour mask, so a (tile, offset) unit is either absent (skipped: one mask
+// word per tile) or nearly full (x1.10-1.15 the exact pair count); a lane's four row numbers of a unit are ONE 16-byte
+// load (rows 4 kk .. 4 kk + 3 of the tile's row list / neighbour column).
+//
+// Launch: one workgroup = (range of tiles, 64 x 16*NCI block of dW, ONE kernel offset); its four waves deal the active
+// tiles of the range round-robin, each accumulating the whole block privately over a register pipeline two units deep
+// (row numbers of unit u + 2 and operands of unit u + 1 in flight during the 16 * NCI MFMAs of unit u); the four partial blocks
+// are summed through LDS in wave order and the workgroup's block goes to the workspace, which wgt_reduce_kernel
+// folds over the tile ranges in a fixed order (bit-reproducible run to run, as before).
+#include "common.h"
+#include "tile_plan.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+namespace efg {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct WgtArgs {
+  const float* in;     // [m_in][cin]
+  const float* go;     // [m_out][cout]
+  const int* rows;     // plan
+  const int* nb;
+  const unsigned* vm;
+  float* partial;      // [splits][kvol][cout][cin]
+  long long n_tiles;   // multiple of 64
+  int cin, cout, kvol;
+  int tiles_per_split;  // multiple of 64
+  int nci_blk;          // blocks along cin
+};
+
+template <int NCO, int NCI>
+__global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
+  constexpr int kAcc = NCO * NCI * 4;          // accumulator registers per lane
+  static_assert(NCO == 4 && (NCI == 4 || NCI == 2), "block: 64 output channels x 64 or 32 reduction channels");
+  typedef float VA __attribute__((ext_vector_type(NCO)));
+  typedef float VB __attribute__((ext_vector_type(NCI)));
+  constexpr int kGroup = 256;                  // tiles per pass over the range (<= 64 units per wave and pass)
+  __shared__ float red[3][kAcc * 64];          // the partial blocks of waves 1..3
+  __shared__ int lst[4][kGroup / 4];           // per wave: its active tiles of the current group
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // XCD-aware order (as conv_wgrad_kernel): the kvol x blocks workgroups of one tile range re-read the same grad_out /
+  // input rows; the hardware deals linear workgroup ids round-robin to the 8 XCDs, so give every XCD whole ranges
+  int split = blockIdx.x, k = blockIdx.z, yb = blockIdx.y;
+  if ((gridDim.x & 7) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned per = gridDim.y * gridDim.z, idx = lin >> 3, rest = idx % per;
+    split = (int)((lin & 7) + 8 * (idx / per));
+    yb = (int)(rest % gridDim.y);
+    k = (int)(rest / gridDim.y);
+  }
+  const int co0 = (yb / a.nci_blk) * (NCO * 16), ci0 = (yb % a.nci_blk) * (NCI * 16);
+  const int m = lane & 15, kk = lane >> 4;
+  const int t_lo = split * a.tiles_per_split;
+  const int t_hi = (int)min((long long)t_lo + a.tiles_per_split, a.n_tiles);
+
+  f32x4 acc[NCO][NCI];
+#pragma unroll
+  for (int ct = 0; ct < NCO; ++ct)
+#pragma unroll
+    for (int it = 0; it < NCI; ++it) acc[ct][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_idx = [&](int t, i32x4& ro, i32x4& rn) {
+    ro = *reinterpret_cast<const i32x4*>(a.rows + (long long)t * 16 + kk * 4);
+    rn = *reinterpret_cast<const i32x4*>(a.nb + ((long long)t * a.kvol + k) * 16 + kk * 4);
+  };
+  // operands of one unit, in fragment order; returns the validity of the lane's four pairs (an absent neighbour -- and
+  // with it every padding row of the tile -- reads row 0 and is multiplied by zero).  The M / N index of the MFMA is a
+  // free bijection onto the block's channels: tile t of the block holds channels {NC * m + t}, so that a lane's NC
+  // operands of a K-step are NC CONSECUTIVE channels of its row -- one 16-byte (8-byte for 32 channels) load, and the 16
+  // lanes of a row read its 256 bytes contiguously: 4 + 4 load instructions per unit instead of 16 + 16 four-byte gathers.
+  auto load_data = [&](const i32x4& ro, const i32x4& rn, VA (&A)[4], VB (&B)[4]) -> unsigned {
+    unsigned ok = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // 32-bit byte offsets (saddr + voffset loads; the host checks both tensors are below 4 GB)
+      const unsigned ao = ((unsigned)max(ro[q], 0) * (unsigned)a.cout + (unsigned)(co0 + NCO * m)) * 4u;
+      const unsigned bo = ((unsigned)max(rn[q], 0) * (unsigned)a.cin + (unsigned)(ci0 + NCI * m)) * 4u;
+      A[q] = *reinterpret_cast<const VA*>(reinterpret_cast<const char*>(a.go) + ao);
+      B[q] = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(a.in) + bo);
+      ok |= (rn[q] >= 0 ? 1u : 0u) << q;
+    }
+    return ok;
+  };
+  auto mfmas = [&](const VA (&A)[4], const VB (&B)[4], unsigned ok) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float b[NCI];
+#pragma unroll
+      for (int t = 0; t < NCI; ++t) b[t] = ((ok >> q) & 1u) ? B[q][t] : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCO; ++ct)
+#pragma unroll
+        for (int it = 0; it < NCI; ++it) acc[ct][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q][ct], b[it], acc[ct][it], 0, 0, 0);
+    }
+  };
+
+  // The range is walked in groups of kGroup tiles.  Phase 1: the wave's list of active tiles of the group at this offset
+  // (lane l looks at the validity words of tiles l, l + 64, ..; ballot + popcount give each active tile its rank in the
+  // workgroup's order, the four waves take every fourth) goes to a wave-private LDS list.  Phase 2: a register pipeline
+  // two units deep over that list -- row numbers of unit u + 2 and operands of unit u + 1 in flight during the MFMAs of
+  // unit u.  Every memory instruction of phase 2 is issued UNCONDITIONALLY (past the end of the list it repeats the
+  // last unit's loads; only the MFMAs are skipped): with a load inside a branch the compiler can no longer count the
+  // loads in flight at the join and waits for all of them (s_waitcnt vmcnt(0)) in front of every MFMA block -- measured:
+  // the pipeline then does not overlap anything.
+  VA A[2][4];
+  VB B[2][4];
+  i32x4 RO[2], RN[2];
+  unsigned OK[2];
+  int* my_list = lst[wv];
+  for (int g0 = t_lo; g0 < t_hi; g0 += kGroup) {
+    unsigned v[kGroup / 64];
+#pragma unroll
+    for (int j = 0; j < kGroup / 64; ++j) {
+      const int t = g0 + j * 64 + lane;
+      v[j] = a.vm[(long long)min(t, t_hi - 1) * 32 + k];
+      if (t >= t_hi) v[j] = 0u;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kGroup / 64; ++j) {
+      const unsigned long long mask = __ballot(v[j] != 0u);
+      const int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (v[j] != 0u && (rank & 3) == wv) my_list[rank >> 2] = g0 + j * 64 + lane;
+      cnt += __popcll(mask);
+    }
+    const int n = (cnt + 3 - wv) >> 2;   // this wave's units of the group (wave-uniform)
+    __builtin_amdgcn_wave_barrier();
+    if (n == 0) continue;
+    auto unit = [&](int u) { return my_list[min(u, n - 1)]; };
+    load_idx(unit(0), RO[0], RN[0]);
+    load_idx(unit(1), RO[1], RN[1]);
+    OK[0] = load_data(RO[0], RN[0], A[0], B[0]);
+    for (int u = 0; u < n; u += 2) {
+      OK[1] = load_data(RO[1], RN[1], A[1], B[1]);   // unit u + 1
+      load_idx(unit(u + 2), RO[0], RN[0]);           // unit u + 2
+      mfmas(A[0], B[0], OK[0]);
+      OK[0] = load_data(RO[0], RN[0], A[0], B[0]);   // unit u + 2
+      load_idx(unit(u + 3), RO[1], RN[1]);           // unit u + 3
+      if (u + 1 < n) mfmas(A[1], B[1], OK[1]);
+    }
+    __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next group
+  }
+
+  // the four waves' blocks, summed in wave order
+  if (wv > 0) {
+#pragma unroll
+    for (int ct = 0; ct < NCO; ++ct)
+#pragma unroll
+      for (int it = 0; it < NCI; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv - 1][((ct * NCI + it) * 4 + r) * 64 + lane] = acc[ct][it][r];
+  }
+  __syncthreads();
+  if (wv > 0) return;
+  float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
+  // C/D layout of 16x16x4: M = (lane >> 4) * 4 + reg, N = lane & 15; with the channel bijection of load_data
+  // co = co0 + NCO * M + ct and ci = ci0 + NCI * N + it: a lane's NCI values of (ct, reg) are consecutive in memory
+#pragma unroll
+  for (int ct = 0; ct < NCO; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      VB v;
+#pragma unroll
+      for (int it = 0; it < NCI; ++it) {
+        const int e = ((ct * NCI + it) * 4 + r) * 64 + lane;
+        v[it] = ((acc[ct][it][r] + red[0][e]) + red[1][e]) + red[2][e];
+      }
+      const int co = co0 + NCO * (kk * 4 + r) + ct;
+      *reinterpret_cast<VB*>(p + (long long)co * a.cin + ci0 + NCI * m) = v;
+    }
+}
+
+// gw[co][k][ci] = sum over the tile ranges of partial[s][k][co][ci], in a fixed order
+__global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict__ partial, int splits, int kvol, int cout,
+                                                          int cin, float* __restrict__ gw) {
+  __shared__ float sm[4][64];
+  const long long per = (long long)kvol * cout * cin;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < per) {
+    int sp = wv;
+    for (; sp + 12 < splits; sp += 16) {   // four loads in flight
+      s0 += partial[(long long)sp * per + e];
+      s1 += partial[(long long)(sp + 4) * per + e];
+      s2 += partial[(long long)(sp + 8) * per + e];
+      s3 += partial[(long long)(sp + 12) * per + e];
+    }
+    for (; sp < splits; sp += 4) s0 += partial[(long long)sp * per + e];
+  }
+  sm[wv][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wv == 0 && e < per) {
+    const float s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    const int ci = (int)(e % cin);
+    const long long q = e / cin;
+    const int co = (int)(q % cout);
+    const int k = (int)(q / cout);
+    gw[((long long)co * kvol + k) * cin + ci] = s;
+  }
+}
+
+// Covered: output width a multiple of 64, reduction width 32 or a multiple of 64 (every convolution of the res18 / res34
+// backbones from the first 32 -> 64 layer on; the 5 / 16-channel stem keeps conv_wgrad_small_kernel).
+bool wgt_ok(int cin, int cout, int kvol) {
+  return kvol >= 1 && kvol <= 31 && cout >= 64 && cout % 64 == 0 && (cin == 32 || (cin >= 64 && cin % 64 == 0));
+}
+
+struct WgtLayout {
+  int splits, tiles_per_split, nco_blk, nci_blk;
+  size_t bytes;
+};
+
+WgtLayout wgt_layout(int64_t m_out, int cin, int cout, int kvol) {
+  WgtLayout L;
+  L.nco_blk = cout / 64;
+  L.nci_blk = cin == 32 ? 1 : cin / 64;
+  const size_t per = (size_t)kvol * cout * cin * 4;
+  const int64_t batches = std::max<int64_t>(1, plan_tiles(m_out) / 64);
+  // ~2048 workgroups when the level has that many (tile range, block, offset) combinations; a range is whole batches
+  // of 64 tiles (what a wave turns into one ballot); <= 128 MB of partial blocks
+  static const int64_t fill_env = getenv("EFG_WGT_FILL") ? atoll(getenv("EFG_WGT_FILL")) : 2048;
+  const int64_t by_fill = std::max<int64_t>(1, fill_env / ((int64_t)L.nco_blk * L.nci_blk * kvol));
+  const int64_t by_mem = std::max<int64_t>(1, (int64_t)((128ull << 20) / std::max<size_t>(per, 1)));
+  int64_t s = std::min(std::min(by_fill, batches), by_mem);
+  const int64_t bper = ceil_div(batches, s);
+  s = ceil_div(batches, bper);
+  if (s >= 8) s = ceil_div(s, 8) * 8;   // whole ranges per XCD (the surplus ranges are empty: they write zeros)
+  L.splits = (int)s;
+  L.tiles_per_split = (int)(bper * 64);
+  L.bytes = (size_t)L.splits * per;
+  return L;
+}
+
+}  // namespace
+}  // namespace efg
+
+using namespace efg;
+
+extern "C" int efg_spconv_wgrad_tiled_ok(int cin, int cout, int kvol) { return wgt_ok(cin, cout, kvol) ? 1 : 0; }
+
+extern "C" size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin, int cout, int kvol) {
+  if (m_out < 0 || !wgt_ok(cin, cout, kvol)) return 0;
+  return wgt_layout(m_out, cin, cout, kvol).bytes + 256;
+}
+
+extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
+                                          int cout, int kvol, const void* plan, float* grad_w, void* ws, size_t ws_bytes,
+                                          void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(wgt_ok(cin, cout, kvol), "spconv wgrad tiled: %d -> %d channels, kvol %d not covered (ask efg_spconv_wgrad_tiled_ok)",
+                cin, cout, kvol);
+  EFG_CHECK_ARG(m_in >= 0 && m_out >= 0 && (unsigned long long)m_in * cin * 4ull < (1ull << 32) &&
+                    (unsigned long long)m_out * cout * 4ull < (1ull << 32),
+                "spconv wgrad tiled: feature tensors must be smaller than 4 GB");
+  const size_t gw_bytes = (size_t)cout * kvol * cin * 4;
+  if (m_out == 0 || m_in == 0) {
+    EFG_HIP_TRY(hipMemsetAsync(grad_w, 0, gw_bytes, stream));
+    return EFG_OK;
+  }
+  EFG_CHECK_ARG(plan && in_feat && grad_out && grad_w, "spconv wgrad tiled: null pointer");
+  EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(in_feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(plan) & 15) == 0,
+                "spconv wgrad tiled: feature tensors, plan and workspace must be 16-byte aligned");
+  const WgtLayout L = wgt_layout(m_out, cin, cout, kvol);
+  if (!ws || ws_bytes < L.bytes) {
+    set_error("spconv wgrad tiled workspace too small: need %zu bytes, got %zu", L.bytes + 256, ws_bytes);
+    return EFG_E_WORKSPACE;
+  }
+  const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
+  WgtArgs a;
+  a.in = in_feat;
+  a.go = grad_out;
+  a.rows = pv.rows;
+  a.nb = pv.nb;
+  a.vm = pv.vm;
+  a.partial = static_cast<float*>(ws);
+  a.n_tiles = pv.n_tiles;
+  a.cin = cin;
+  a.cout = cout;
+  a.kvol = kvol;
+  a.tiles_per_split = L.tiles_per_split;
+  a.nci_blk = L.nci_blk;
+  const dim3 grid(L.splits, L.nco_blk * L.nci_blk, kvol);
+  if (cin == 32) hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 2>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+  EFG_LAUNCH_CHECK();
+  const long long per = (long long)kvol * cout * cin;
+  hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 64)), dim3(256), 0, stream, a.partial, L.splits, kvol, cout,
+                     cin, grad_w);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}

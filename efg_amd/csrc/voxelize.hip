@@ -72,7 +72,8 @@ __device__ __forceinline__ unsigned hash_cell(unsigned key, int shift) { return 
 // K1: slot_of_point[i] = hash slot of the point's cell (or -1); table[slot] = {cell, min point}.
 __global__ void __launch_bounds__(256)
 vox_insert_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom g, unsigned vol,
-                  unsigned long long* __restrict__ table, unsigned tmask, int tshift, int* __restrict__ slot_of_point) {
+                  unsigned long long* __restrict__ table, unsigned tmask, int tshift, int* __restrict__ slot_of_point,
+                  int precheck) {
   const int scene = blockIdx.y;
   const long long beg = so.off[scene], end = so.off[scene + 1];
   for (long long i = beg + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < end;
@@ -92,7 +93,10 @@ vox_insert_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom
         if (cur == kEmpty) break;  // claimed
       }
       if ((unsigned)(cur >> 32) == key) {
-        atomicMin(&table[h], mine);
+        // a slot's key never changes and its point index only decreases: an index already below mine (however stale
+        // the read) means the atomic would be a no-op.  Points arrive roughly in index order, so this is the common
+        // case for every later point of a voxel -- and a device-scope atomic costs a trip to the memory side.
+        if (!precheck || (unsigned)cur > (unsigned)i) atomicMin(&table[h], mine);
         break;
       }
       h = (h + 1) & tmask;
@@ -206,7 +210,7 @@ vox_assign_kernel(SceneOffsets so, const unsigned long long* __restrict__ table,
 // K4: later points of kept voxels; sorted-list insertion by atomicMin chain.
 __global__ void __launch_bounds__(256)
 vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const int* __restrict__ vid_of_slot,
-                   const unsigned* __restrict__ i_break, int max_points, unsigned* __restrict__ lists) {
+                   const unsigned* __restrict__ i_break, int max_points, unsigned* __restrict__ lists, int precheck) {
   const int scene = blockIdx.y;
   const long long beg = so.off[scene];
   const long long end = min(so.off[scene + 1], (long long)i_break[scene]);
@@ -219,6 +223,9 @@ vox_cascade_kernel(SceneOffsets so, const int* __restrict__ slot_of_point, const
     unsigned* lst = lists + (long long)vid * max_points;
     unsigned carry = (unsigned)i;
     for (int r = 1; r < max_points; ++r) {
+      // entries only decrease: one that already reads below the carry keeps its value whatever happens later (the
+      // atomicMin would return it and change nothing) -- skip the atomic, the carry moves on unchanged
+      if (precheck && lst[r] < carry) continue;
       const unsigned old = atomicMin(&lst[r], carry);
       if (old == kInf) break;          // landed in an empty entry
       carry = max(old, carry);         // the larger index moves on
@@ -369,10 +376,11 @@ extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, i
   EFG_HIP_TRY(hipMemsetAsync(table, 0xff, reinterpret_cast<char*>(cleared_small + 2 * kMaxBatch) - reinterpret_cast<char*>(table),
                              stream));
   const dim3 blk(256);
+  static const int precheck = getenv("EFG_VOX_PRECHECK") ? atoi(getenv("EFG_VOX_PRECHECK")) : 1;  // 0: every point issues its atomics (A/B)
   if (n_total > 0) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
     hipLaunchKernelGGL(vox_insert_kernel, dim3(gx, batch), blk, 0, stream, points, so, f, g, (unsigned)vol, table,
-                       L.tsize - 1, L.tshift, slot_of_point);
+                       L.tsize - 1, L.tshift, slot_of_point, precheck);
     EFG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(vox_count_kernel, dim3(L.tiles_per_scene, batch), blk, 0, stream, so, table, slot_of_point,
@@ -385,7 +393,7 @@ extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, i
   if (n_total > 0 && max_points > 1) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
     hipLaunchKernelGGL(vox_cascade_kernel, dim3(gx, batch), blk, 0, stream, so, slot_of_point, vid_of_slot, i_break,
-                       max_points, lists);
+                       max_points, lists, precheck);
     EFG_LAUNCH_CHECK();
   }
   // upper bound on rows: min(points, capacity); threads beyond the real count exit early

@@ -184,6 +184,17 @@ def _conv_dgrad(grad_out, w, rb):
 def _conv_wgrad(features, grad_out, rb):
     lib = L.lib()
     cin, cout, kvol = features.shape[1], grad_out.shape[1], rb.kvol
+    if (kvol <= 31 and rb.m_out > 0 and lib.efg_spconv_wgrad_tiled_ok(cin, cout, kvol)
+            and os.environ.get("EFG_WGRAD_TILED", "1") != "0"):
+        # over the layer's forward tile plan: MFMA operands straight from the feature rows (csrc/spconv_wgt.hip)
+        plan = rb.plan_fwd()
+        ws_bytes = lib.efg_spconv_wgrad_tiled_workspace_bytes(rb.m_out, cin, cout, kvol)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
+        grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
+        with _prof.timed("conv_wgrad_tile_kernel+wgt_reduce_kernel", _Cost(rb, cin, cout, "wgrad")):
+            L.check(lib.efg_spconv_wgrad_tiled_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
+                                                   L.ptr(plan), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
+        return grad_w
     ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)

@@ -203,6 +203,18 @@ size_t efg_spconv_wgrad_workspace_bytes(int64_t m_out, int cin, int cout, int kv
 int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
                          int cout, int kvol, const int32_t* nbr, float* grad_w, void* ws, size_t ws_bytes,
                          void* stream);
+/* The same weight gradient over the tile plan of `nbr` (efg_spconv_tile_plan; the plan the forward pass of the layer
+ * uses): a (16-row tile, offset) unit of the plan is four K-steps of the fp32 MFMA whose operands are loaded straight
+ * from the feature rows in fragment layout -- no pair compaction, no LDS staging, no workgroup barrier (csrc/spconv_wgt.hip).
+ * Covered (efg_spconv_wgrad_tiled_ok): cout a multiple of 64, cin 32 or a multiple of 64, kvol <= 31.  Deterministic
+ * two-pass like efg_spconv_wgrad_f32; the grouping of a weight's partial sums follows the plan's tiles, so the two
+ * entry points agree to fp32 rounding, not bit for bit.  Replaces the same spconv call (indice-conv backward, weight
+ * part) as efg_spconv_wgrad_f32: efg/modeling/backbones/sparse_net.py:85-95 via spconv.SparseConv3d / SubMConv3d. */
+int efg_spconv_wgrad_tiled_ok(int cin, int cout, int kvol);
+size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
+int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
+                               int cout, int kvol, const void* plan, float* grad_w, void* ws, size_t ws_bytes,
+                               void* stream);
 
 /* SparseConvTensor.dense(): dense f32 [batch, c, D, H, W], fully written (zeros where inactive).
  * feat rows must be in canonical order (perm == NULL) or mapped through perm. */
