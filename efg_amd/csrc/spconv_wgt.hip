@@ -17,11 +17,12 @@
 // word per tile) or nearly full (x1.10-1.15 the exact pair count); a lane's four row numbers of a unit are ONE 16-byte
 // load (rows 4 kk .. 4 kk + 3 of the tile's row list / neighbour column).
 //
-// Launch: one workgroup = (range of tiles, 64 x 16*NCI block of dW, ONE kernel offset); its four waves deal the active
-// tiles of the range round-robin, each accumulating the whole block privately over a register pipeline two units deep
-// (row numbers of unit u + 2 and operands of unit u + 1 in flight during the 16 * NCI MFMAs of unit u); the four partial blocks
-// are summed through LDS in wave order and the workgroup's block goes to the workspace, which wgt_reduce_kernel
-// folds over the tile ranges in a fixed order (bit-reproducible run to run, as before).
+// Launch: one workgroup = (slot of the schedule below: ONE kernel offset and a range of tiles holding ~48 active ones,
+// 64 x 16*NCI block of dW); its four waves deal the active tiles of the range round-robin, each accumulating the whole
+// block privately over a register pipeline (row numbers of unit u + 2 and operands of unit u + 1 in flight during the
+// 16 * NCI MFMAs of unit u); the four partial blocks are summed through LDS in wave order and the workgroup's block goes to
+// the workspace, which wgt_reduce_kernel folds over the slots of each offset in a fixed order (bit-reproducible run to
+// run, as before).
 #include "common.h"
 #include "tile_plan.h"
 
@@ -41,12 +42,115 @@ struct WgtArgs {
   const int* rows;     // plan
   const int* nb;
   const unsigned* vm;
-  float* partial;      // [splits][kvol][cout][cin]
+  const int4* entry;   // schedule: (offset, first tile, end tile, -) per slot; offset < 0: unused slot
+  float* partial;      // [slots][cout][cin]
   long long n_tiles;   // multiple of 64
   int cin, cout, kvol;
-  int tiles_per_split;  // multiple of 64
   int nci_blk;          // blocks along cin
 };
+
+// ---- schedule ---------------------------------------------------------------------------------------------------
+// A unit of work is an ACTIVE (tile, offset) pair, and the offsets differ a lot: the centre of a 3 x 3 x 3 window has
+// every tile active, a corner a fifth of them.  With one workgroup per (equal tile range, offset) the launch is 2.5
+// rounds of workgroups whose lengths differ 5x: PMC on the 64-channel level -- wave slots occupied 60 % of the kernel's
+// cycles, the matrix pipe 84 % busy while two waves share a SIMD, 50 % overall.  The schedule is the fix: per plan,
+// computed on the device (no host round trip) and a pure function of the plan (reproducible): offset k gets
+// S_k = round(T * U_k / sum U) slots (U_k = its active tiles; T ~ one slot per 48 units) and its tiles are cut where the
+// running count of ACTIVE tiles crosses j * U_k / S_k -- every slot of the launch has the same number of units.
+// Slots of one offset are contiguous and in tile order (the reduction walks them in order).  Dealing an offset's ranges
+// to the XCDs by tile position (slot 8 q + x = q-th range of the x-th eighth of the rows, so that the workgroups of XCD x
+// share its L2 at every offset) was measured and lost: 86.7 vs 78.1 us on the 64-channel level, equal elsewhere.
+// buffer: int4 entry[w_max] | int kfirst[33]
+constexpr int kUnitsPerSlot = 48;
+constexpr int kMaxT8 = 120;
+
+inline int sched_t8_max(long long n_tiles) { return (int)std::min<long long>(kMaxT8, std::max<long long>(1, n_tiles * 16 / kUnitsPerSlot / 8)); }
+inline int sched_w_max(long long n_tiles, int kvol) { return 8 * (sched_t8_max(n_tiles) + kvol); }
+inline size_t sched_bytes(long long n_tiles, int kvol) { return (size_t)sched_w_max(n_tiles, kvol) * 16 + 33 * 4; }
+
+__global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __restrict__ vm, long long n_tiles, int kvol, int t8_max,
+                                                            int w_max, int units_per_slot, int4* __restrict__ entry,
+                                                            int* __restrict__ kfirst) {
+  __shared__ int U[32], S[32], KF[33];
+  __shared__ int sm[17];
+  __shared__ int lo[8 * kMaxT8 + 40];
+  constexpr int kStage = 8192;
+  __shared__ unsigned wl[kStage];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  if (tid < 32) U[tid] = 0;
+  __syncthreads();
+  // The tiles' active-offset words (vm[t][31]) are staged in LDS, 8 loads in flight per thread (one dependent 128-byte
+  // strided load per loop trip had made this kernel 50 us); both passes read them there.  Pass 1: active tiles per offset
+  // (every workgroup counts all offsets: it needs the total).
+  auto stage = [&](long long c0, int cn) {
+    for (int i0 = tid; i0 < cn; i0 += 256 * 8) {
+      unsigned w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = vm[(c0 + min(i0 + u * 256, cn - 1)) * 32 + 31];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < cn) wl[i0 + u * 256] = w[u];
+    }
+    __syncthreads();
+  };
+  for (long long c0 = 0; c0 < n_tiles; c0 += kStage) {
+    const int cn = (int)min((long long)kStage, n_tiles - c0);
+    if (c0 > 0) __syncthreads();
+    stage(c0, cn);
+    for (int i = tid; i < cn; i += 256) {
+      unsigned w = wl[i];
+      while (w) {
+        atomicAdd(&U[__ffs((int)w) - 1], 1);
+        w &= w - 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long total = 0;
+    for (int q = 0; q < kvol; ++q) total += U[q];
+    const long long T = 8 * std::min<long long>(t8_max, std::max<long long>(1, total / (units_per_slot * 8)));
+    int acc = 0;
+    for (int q = 0; q < kvol; ++q) {
+      const long long r = total > 0 ? (T * U[q] + total / 2) / total : 1;
+      S[q] = (int)std::max<long long>(1, r);
+      KF[q] = acc;
+      acc += S[q];
+    }
+    KF[kvol] = acc;   // <= T + kvol <= w_max
+  }
+  __syncthreads();
+  const int sk = S[k], uk = U[k];
+  for (int j = tid; j <= sk; j += 256) lo[j] = (int)n_tiles;
+  __syncthreads();
+  int carry = 0;
+  for (long long c0 = 0; c0 < n_tiles; c0 += kStage) {
+    const int cn = (int)min((long long)kStage, n_tiles - c0);
+    if (n_tiles > kStage) {   // (a single chunk is still staged from pass 1)
+      __syncthreads();
+      stage(c0, cn);
+    }
+    for (int base = 0; base < cn; base += 256) {
+      const int i = base + tid;
+      const int flag = (i < cn) ? (int)((wl[i] >> k) & 1u) : 0;
+      int tot;
+      const int r = carry + block_exclusive_scan(flag, sm, &tot);
+      if (flag) {   // rank r of the offset's active tiles starts range j when j(r) != j(r - 1)   (j(r) = r S / U)
+        const int j = (int)(((long long)r * sk) / uk);
+        const int jp = r > 0 ? (int)(((long long)(r - 1) * sk) / uk) : -1;
+        for (int jj = jp + 1; jj <= j; ++jj) lo[jj] = (int)(c0 + i);
+      }
+      carry += tot;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < sk; j += 256) entry[KF[k] + j] = make_int4(k, lo[j], lo[j + 1], 0);
+  if (k == 0) {
+    for (int q = tid; q <= kvol; q += 256) kfirst[q] = KF[q];
+    for (int e = KF[kvol] + tid; e < w_max; e += 256) entry[e] = make_int4(-1, 0, 0, 0);
+  }
+}
+
 
 template <int NCO, int NCI>
 __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
@@ -59,20 +163,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   __shared__ int lst[4][kGroup / 4];           // per wave: its active tiles of the current group
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // XCD-aware order (as conv_wgrad_kernel): the kvol x blocks workgroups of one tile range re-read the same grad_out /
-  // input rows; the hardware deals linear workgroup ids round-robin to the 8 XCDs, so give every XCD whole ranges
-  int split = blockIdx.x, k = blockIdx.z, yb = blockIdx.y;
-  if ((gridDim.x & 7) == 0) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned per = gridDim.y * gridDim.z, idx = lin >> 3, rest = idx % per;
-    split = (int)((lin & 7) + 8 * (idx / per));
-    yb = (int)(rest % gridDim.y);
-    k = (int)(rest / gridDim.y);
-  }
+  const int4 ent = a.entry[blockIdx.x];   // (the schedule: which offset, which tiles; slot = blockIdx.x)
+  if (ent.x < 0) return;
+  const int k = ent.x, yb = blockIdx.y;
   const int co0 = (yb / a.nci_blk) * (NCO * 16), ci0 = (yb % a.nci_blk) * (NCI * 16);
   const int m = lane & 15, kk = lane >> 4;
-  const int t_lo = split * a.tiles_per_split;
-  const int t_hi = (int)min((long long)t_lo + a.tiles_per_split, a.n_tiles);
+  const int t_lo = ent.y, t_hi = ent.z;
 
   f32x4 acc[NCO][NCI];
 #pragma unroll
@@ -152,12 +248,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
     load_idx(unit(1), RO[1], RN[1]);
     OK[0] = load_data(RO[0], RN[0], A[0], B[0]);
     for (int u = 0; u < n; u += 2) {
+      // (the scheduling barriers keep the loads IN FRONT of the MFMA block: left alone, the scheduler sinks them to the end
+      // of the block to shorten live ranges, and every second unit then waits out a full memory latency)
       OK[1] = load_data(RO[1], RN[1], A[1], B[1]);   // unit u + 1
       load_idx(unit(u + 2), RO[0], RN[0]);           // unit u + 2
+      __builtin_amdgcn_sched_barrier(0);
       mfmas(A[0], B[0], OK[0]);
+      __builtin_amdgcn_sched_barrier(0);
       OK[0] = load_data(RO[0], RN[0], A[0], B[0]);   // unit u + 2
       load_idx(unit(u + 3), RO[1], RN[1]);           // unit u + 3
+      __builtin_amdgcn_sched_barrier(0);
       if (u + 1 < n) mfmas(A[1], B[1], OK[1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next group
   }
@@ -173,7 +275,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   }
   __syncthreads();
   if (wv > 0) return;
-  float* p = a.partial + ((long long)split * a.kvol + k) * a.cout * a.cin;
+  float* p = a.partial + (long long)blockIdx.x * a.cout * a.cin;
   // C/D layout of 16x16x4: M = (lane >> 4) * 4 + reg, N = lane & 15; with the channel bijection of load_data
   // co = co0 + NCO * M + ct and ci = ci0 + NCI * N + it: a lane's NCI values of (ct, reg) are consecutive in memory
 #pragma unroll
@@ -191,33 +293,35 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
     }
 }
 
-// gw[co][k][ci] = sum over the tile ranges of partial[s][k][co][ci], in a fixed order
-__global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict__ partial, int splits, int kvol, int cout,
-                                                          int cin, float* __restrict__ gw) {
-  __shared__ float sm[4][64];
-  const long long per = (long long)kvol * cout * cin;
+// gw[co][k][ci] = sum over the slots of offset k of partial[slot][co][ci], in slot order; 4 consecutive ci per thread
+__global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict__ partial,
+                                                          const int* __restrict__ kfirst, int kvol, int cout, int cin,
+                                                          float* __restrict__ gw) {
+  __shared__ f32x4 sm[4][64];
+  const long long blk = (long long)cout * cin, per = (long long)kvol * blk;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long e = (long long)blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long long e = ((long long)blockIdx.x * 64 + lane) * 4;   // (k, co, ci); blk is a multiple of 256: k is block-uniform
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int k = 0;
+  long long rem = 0;
   if (e < per) {
-    int sp = wv;
-    for (; sp + 12 < splits; sp += 16) {   // four loads in flight
-      s0 += partial[(long long)sp * per + e];
-      s1 += partial[(long long)(sp + 4) * per + e];
-      s2 += partial[(long long)(sp + 8) * per + e];
-      s3 += partial[(long long)(sp + 12) * per + e];
+    k = (int)(e / blk);
+    rem = e - (long long)k * blk;
+    const int s_end = kfirst[k + 1];
+    int sp = kfirst[k] + wv;
+    auto term = [&](int slot) { return *reinterpret_cast<const f32x4*>(partial + (long long)slot * blk + rem); };
+    for (; sp + 4 < s_end; sp += 8) {   // two loads in flight
+      s0 += term(sp);
+      s1 += term(sp + 4);
     }
-    for (; sp < splits; sp += 4) s0 += partial[(long long)sp * per + e];
+    for (; sp < s_end; sp += 4) s0 += term(sp);
   }
-  sm[wv][lane] = (s0 + s1) + (s2 + s3);
+  sm[wv][lane] = s0 + s1;
   __syncthreads();
   if (wv == 0 && e < per) {
-    const float s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-    const int ci = (int)(e % cin);
-    const long long q = e / cin;
-    const int co = (int)(q % cout);
-    const int k = (int)(q / cout);
-    gw[((long long)co * kvol + k) * cin + ci] = s;
+    const f32x4 s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    const int co = (int)(rem / cin), ci = (int)(rem - (long long)co * cin);
+    *reinterpret_cast<f32x4*>(gw + ((long long)co * kvol + k) * cin + ci) = s;
   }
 }
 
@@ -228,7 +332,7 @@ bool wgt_ok(int cin, int cout, int kvol) {
 }
 
 struct WgtLayout {
-  int splits, tiles_per_split, nco_blk, nci_blk;
+  int slots, nco_blk, nci_blk;
   size_t bytes;
 };
 
@@ -236,20 +340,8 @@ WgtLayout wgt_layout(int64_t m_out, int cin, int cout, int kvol) {
   WgtLayout L;
   L.nco_blk = cout / 64;
   L.nci_blk = cin == 32 ? 1 : cin / 64;
-  const size_t per = (size_t)kvol * cout * cin * 4;
-  const int64_t batches = std::max<int64_t>(1, plan_tiles(m_out) / 64);
-  // ~2048 workgroups when the level has that many (tile range, block, offset) combinations; a range is whole batches
-  // of 64 tiles (what a wave turns into one ballot); <= 128 MB of partial blocks
-  static const int64_t fill_env = getenv("EFG_WGT_FILL") ? atoll(getenv("EFG_WGT_FILL")) : 2048;
-  const int64_t by_fill = std::max<int64_t>(1, fill_env / ((int64_t)L.nco_blk * L.nci_blk * kvol));
-  const int64_t by_mem = std::max<int64_t>(1, (int64_t)((128ull << 20) / std::max<size_t>(per, 1)));
-  int64_t s = std::min(std::min(by_fill, batches), by_mem);
-  const int64_t bper = ceil_div(batches, s);
-  s = ceil_div(batches, bper);
-  if (s >= 8) s = ceil_div(s, 8) * 8;   // whole ranges per XCD (the surplus ranges are empty: they write zeros)
-  L.splits = (int)s;
-  L.tiles_per_split = (int)(bper * 64);
-  L.bytes = (size_t)L.splits * per;
+  L.slots = sched_w_max(plan_tiles(m_out), kvol);
+  L.bytes = (size_t)L.slots * cout * cin * 4;
   return L;
 }
 
@@ -265,9 +357,34 @@ extern "C" size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin,
   return wgt_layout(m_out, cin, cout, kvol).bytes + 256;
 }
 
+extern "C" size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int kvol) {
+  if (m_out < 0 || kvol < 1 || kvol > 31) return 0;
+  return sched_bytes(plan_tiles(m_out), kvol) + 256;
+}
+
+extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int kvol, void* sched, size_t sched_bytes_given,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EFG_CHECK_ARG(m_out >= 0 && m_out < (1ll << 31) && kvol >= 1 && kvol <= 31, "wgrad_sched: bad sizes (m=%lld, kvol=%d)", (long long)m_out, kvol);
+  if (m_out == 0) return EFG_OK;
+  const long long n_tiles = plan_tiles(m_out);
+  EFG_CHECK_ARG(plan && sched && sched_bytes_given >= sched_bytes(n_tiles, kvol), "wgrad_sched: null pointer / buffer too small");
+  EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(sched) & 15) == 0, "wgrad_sched: buffer must be 16-byte aligned");
+  const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
+  const int w_max = sched_w_max(n_tiles, kvol);
+  int4* entry = static_cast<int4*>(sched);
+  int* kfirst = reinterpret_cast<int*>(entry + w_max);
+  // EFG_WGT_UNITS: units per slot (>= 48: the slot table is sized for that)
+  static const int units_env = getenv("EFG_WGT_UNITS") ? std::max(atoi(getenv("EFG_WGT_UNITS")), kUnitsPerSlot) : kUnitsPerSlot;
+  hipLaunchKernelGGL(wgt_schedule_kernel, dim3(kvol), dim3(256), 0, stream, pv.vm, n_tiles, kvol, sched_t8_max(n_tiles), w_max, units_env,
+                     entry, kfirst);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
 extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
-                                          int cout, int kvol, const void* plan, float* grad_w, void* ws, size_t ws_bytes,
-                                          void* stream_) {
+                                          int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,
+                                          size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EFG_CHECK_ARG(wgt_ok(cin, cout, kvol), "spconv wgrad tiled: %d -> %d channels, kvol %d not covered (ask efg_spconv_wgrad_tiled_ok)",
                 cin, cout, kvol);
@@ -279,10 +396,11 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
     EFG_HIP_TRY(hipMemsetAsync(grad_w, 0, gw_bytes, stream));
     return EFG_OK;
   }
-  EFG_CHECK_ARG(plan && in_feat && grad_out && grad_w, "spconv wgrad tiled: null pointer");
+  EFG_CHECK_ARG(plan && sched && in_feat && grad_out && grad_w, "spconv wgrad tiled: null pointer");
   EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(in_feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(plan) & 15) == 0,
-                "spconv wgrad tiled: feature tensors, plan and workspace must be 16-byte aligned");
+                    (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(sched) & 15) == 0,
+                "spconv wgrad tiled: feature tensors, plan, schedule and workspace must be 16-byte aligned");
   const WgtLayout L = wgt_layout(m_out, cin, cout, kvol);
   if (!ws || ws_bytes < L.bytes) {
     set_error("spconv wgrad tiled workspace too small: need %zu bytes, got %zu", L.bytes + 256, ws_bytes);
@@ -295,19 +413,20 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   a.rows = pv.rows;
   a.nb = pv.nb;
   a.vm = pv.vm;
+  a.entry = static_cast<const int4*>(sched);
   a.partial = static_cast<float*>(ws);
   a.n_tiles = pv.n_tiles;
   a.cin = cin;
   a.cout = cout;
   a.kvol = kvol;
-  a.tiles_per_split = L.tiles_per_split;
   a.nci_blk = L.nci_blk;
-  const dim3 grid(L.splits, L.nco_blk * L.nci_blk, kvol);
+  const dim3 grid(L.slots, L.nco_blk * L.nci_blk);
   if (cin == 32) hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 2>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 4>), grid, dim3(256), 0, stream, a);
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * cin;
-  hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 64)), dim3(256), 0, stream, a.partial, L.splits, kvol, cout,
+  const int* kfirst = reinterpret_cast<const int*>(a.entry + L.slots);
+  hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 256)), dim3(256), 0, stream, a.partial, kfirst, kvol, cout,
                      cin, grad_w);
   EFG_LAUNCH_CHECK();
   return EFG_OK;

@@ -107,6 +107,15 @@ def _build_plan(table, m, kvol):
     return plan
 
 
+def _build_wgrad_sched(plan, m, kvol):
+    """Launch schedule (uint8 buffer) of the plan-walking weight gradient over `plan`."""
+    lib = L.lib()
+    nbytes = lib.efg_spconv_wgrad_sched_bytes(m, kvol)
+    sched = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
+    L.check(lib.efg_spconv_wgrad_sched(L.ptr(plan), m, kvol, L.ptr(sched), nbytes, L.stream()))
+    return sched
+
+
 def _natural_order(reduce_channels):
     """2 when the tile kernel should take its 16-byte-gather path for this reduction width (weights packed in natural
     channel order), else 0.  OFF by default: measured 3-13 % SLOWER than the 4-byte path on every res18 layer
@@ -187,13 +196,13 @@ def _conv_wgrad(features, grad_out, rb):
     if (kvol <= 31 and rb.m_out > 0 and lib.efg_spconv_wgrad_tiled_ok(cin, cout, kvol)
             and os.environ.get("EFG_WGRAD_TILED", "1") != "0"):
         # over the layer's forward tile plan: MFMA operands straight from the feature rows (csrc/spconv_wgt.hip)
-        plan = rb.plan_fwd()
+        plan, sched = rb.plan_fwd(), rb.wgrad_sched()
         ws_bytes = lib.efg_spconv_wgrad_tiled_workspace_bytes(rb.m_out, cin, cout, kvol)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
         grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
         with _prof.timed("conv_wgrad_tile_kernel+wgt_reduce_kernel", _Cost(rb, cin, cout, "wgrad")):
             L.check(lib.efg_spconv_wgrad_tiled_f32(L.ptr(features), rb.m_in, cin, L.ptr(grad_out), rb.m_out, cout, kvol,
-                                                   L.ptr(plan), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
+                                                   L.ptr(plan), L.ptr(sched), L.ptr(grad_w), L.ptr(ws), ws_bytes, L.stream()))
         return grad_w
     ws_bytes = lib.efg_spconv_wgrad_workspace_bytes(rb.m_out, cin, cout, kvol)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
@@ -340,14 +349,30 @@ class Rulebook:
         self._order = None
         self._plan_fwd = None
         self._plan_dgrad = None
+        self._wgrad_sched = None
 
     def plan_fwd(self):
-        """Tile plan of `nbr` (csrc/spconv_tiles.hip), built on first use on the geometry stream when one is active."""
+        """Tile plan of `nbr` (csrc/spconv_tiles.hip), built on first use on the geometry stream when one is active --
+        in training together with the launch schedule of the plan-walking weight gradient (wgrad_sched), so that the
+        backward pass finds it ready."""
         if self._plan_fwd is None:
             with _on_geometry_stream() as main:
                 self._plan_fwd = _build_plan(self.nbr, self.m_out, self.kvol)
                 _hand_over(main, self._plan_fwd)
+                if torch.is_grad_enabled() and self._plan_fwd is not None and os.environ.get("EFG_WGRAD_TILED", "1") != "0":
+                    self._wgrad_sched = _build_wgrad_sched(self._plan_fwd, self.m_out, self.kvol)
+                    _hand_over(main, self._wgrad_sched)
         return self._plan_fwd
+
+    def wgrad_sched(self):
+        """Equal-work launch schedule of efg_spconv_wgrad_tiled_f32 over plan_fwd() (csrc/spconv_wgt.hip)."""
+        if self._wgrad_sched is None:
+            plan = self.plan_fwd()
+            if self._wgrad_sched is None:
+                with _on_geometry_stream() as main:
+                    self._wgrad_sched = _build_wgrad_sched(plan, self.m_out, self.kvol)
+                    _hand_over(main, self._wgrad_sched)
+        return self._wgrad_sched
 
     def plan_dgrad(self):
         """(plan, flip): submanifold -> the forward plan walked with reversed offsets (the transposed table of a

@@ -211,10 +211,15 @@ int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const floa
  * entry points agree to fp32 rounding, not bit for bit.  Replaces the same spconv call (indice-conv backward, weight
  * part) as efg_spconv_wgrad_f32: efg/modeling/backbones/sparse_net.py:85-95 via spconv.SparseConv3d / SubMConv3d. */
 int efg_spconv_wgrad_tiled_ok(int cin, int cout, int kvol);
+/* The launch schedule of the plan-walking weight gradient: a device-side table that cuts the plan's (tile, offset)
+ * units into slots of EQUAL unit counts (the offsets of a window differ 5x in active tiles), computed from the plan on
+ * the device, once per plan; shared by every layer that uses the plan. */
+size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int kvol);
+int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int kvol, void* sched, size_t sched_bytes, void* stream);
 size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
 int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
-                               int cout, int kvol, const void* plan, float* grad_w, void* ws, size_t ws_bytes,
-                               void* stream);
+                               int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* SparseConvTensor.dense(): dense f32 [batch, c, D, H, W], fully written (zeros where inactive).
  * feat rows must be in canonical order (perm == NULL) or mapped through perm. */
