@@ -59,8 +59,8 @@ _SIGS = {
                                      c_void_p, c_size_t, c_void_p]),
     "efg_spconv_wgrad_tiled_ok": (c_int, [c_int, c_int, c_int]),
     "efg_spconv_wgrad_tiled_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
-    "efg_spconv_wgrad_sched_bytes": (c_size_t, [c_int64, c_int]),
-    "efg_spconv_wgrad_sched": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_wgrad_sched_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "efg_spconv_wgrad_sched": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_wgrad_tiled_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_sparse_to_dense_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

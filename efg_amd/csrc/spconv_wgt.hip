@@ -17,8 +17,8 @@
 // word per tile) or nearly full (x1.10-1.15 the exact pair count); a lane's four row numbers of a unit are ONE 16-byte
 // load (rows 4 kk .. 4 kk + 3 of the tile's row list / neighbour column).
 //
-// Launch: one workgroup = (slot of the schedule below: ONE kernel offset and a range of tiles holding ~48 active ones,
-// 64 x 16*NCI block of dW); its four waves deal the active tiles of the range round-robin, each accumulating the whole
+// Launch: one workgroup = (slot of the schedule below: ONE kernel offset and a range of tiles holding ~80 active ones,
+// 16*NCO x 16*NCI block of dW: 64 x 64 from 64 channels up); its four waves deal the active tiles of the range round-robin, each accumulating the whole
 // block privately over a register pipeline (row numbers of unit u + 2 and operands of unit u + 1 in flight during the
 // 16 * NCI MFMAs of unit u); the four partial blocks are summed through LDS in wave order and the workgroup's block goes to
 // the workspace, which wgt_reduce_kernel folds over the slots of each offset in a fixed order (bit-reproducible run to
@@ -55,33 +55,43 @@ struct WgtArgs {
 // rounds of workgroups whose lengths differ 5x: PMC on the 64-channel level -- wave slots occupied 60 % of the kernel's
 // cycles, the matrix pipe 84 % busy while two waves share a SIMD, 50 % overall.  The schedule is the fix: per plan,
 // computed on the device (no host round trip) and a pure function of the plan (reproducible): offset k gets
-// S_k = round(T * U_k / sum U) slots (U_k = its active tiles; T ~ one slot per 48 units) and its tiles are cut where the
+// S_k ~ T * U_k / sum U slots (U_k = its active tiles; T ~ one slot per 80 units) and its tiles are cut where the
 // running count of ACTIVE tiles crosses j * U_k / S_k -- every slot of the launch has the same number of units.
 // Slots of one offset are contiguous and in tile order (the reduction walks them in order).  Dealing an offset's ranges
 // to the XCDs by tile position (slot 8 q + x = q-th range of the x-th eighth of the rows, so that the workgroups of XCD x
 // share its L2 at every offset) was measured and lost: 86.7 vs 78.1 us on the 64-channel level, equal elsewhere.
-// buffer: int4 entry[w_max] | int kfirst[33]
-constexpr int kUnitsPerSlot = 48;
-constexpr int kMaxT8 = 120;
+// The number of slots is fixed by the HOST from what it knows (tiles, window, the layer's block count, how many
+// workgroups of the kernel the device holds at once): slots x blocks is a whole number of device fills -- with equal
+// slots, a launch of 2 fills + 6 workgroups costs 3 (PMC: wave slots occupied 68 % of the 64-channel level's launch) --
+// and the device deals exactly that many slots to the offsets by their unit counts (largest remainders).
+// buffer: int4 entry[slots] | int kfirst[33]
+constexpr int kUnitsPerSlot = 80;
+constexpr int kMaxSlots = 2048;
 
-inline int sched_t8_max(long long n_tiles) { return (int)std::min<long long>(kMaxT8, std::max<long long>(1, n_tiles * 16 / kUnitsPerSlot / 8)); }
-inline int sched_w_max(long long n_tiles, int kvol) { return 8 * (sched_t8_max(n_tiles) + kvol); }
-inline size_t sched_bytes(long long n_tiles, int kvol) { return (size_t)sched_w_max(n_tiles, kvol) * 16 + 33 * 4; }
+inline int sched_slots(long long n_tiles, int kvol, int nblk, int resident) {
+  // ~0.55 of the (tile, offset) pairs of a submanifold window are active, fewer on strided tables: an estimate is enough,
+  // it only sets the slot size
+  static const int units_env = getenv("EFG_WGT_UNITS") ? std::max(atoi(getenv("EFG_WGT_UNITS")), 8) : kUnitsPerSlot;
+  const double want = (double)n_tiles * kvol * 0.55 / units_env * nblk;          // workgroups
+  const long long fills = std::max<long long>(1, (long long)(want / resident + 0.5));
+  long long slots = fills * resident / nblk;
+  slots = std::max<long long>(slots, kvol);
+  return (int)std::min<long long>(slots, kMaxSlots);
+}
+inline size_t sched_bytes(int slots) { return (size_t)slots * 16 + 33 * 4; }
 
-__global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __restrict__ vm, long long n_tiles, int kvol, int t8_max,
-                                                            int w_max, int units_per_slot, int4* __restrict__ entry,
-                                                            int* __restrict__ kfirst) {
+__global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __restrict__ vm, long long n_tiles, int kvol, int slots,
+                                                            int4* __restrict__ entry, int* __restrict__ kfirst) {
   __shared__ int U[32], S[32], KF[33];
   __shared__ int sm[17];
-  __shared__ int lo[8 * kMaxT8 + 40];
+  __shared__ int lo[kMaxSlots + 8];
   constexpr int kStage = 8192;
   __shared__ unsigned wl[kStage];
   const int tid = threadIdx.x, k = blockIdx.x;
   if (tid < 32) U[tid] = 0;
   __syncthreads();
   // The tiles' active-offset words (vm[t][31]) are staged in LDS, 8 loads in flight per thread (one dependent 128-byte
-  // strided load per loop trip had made this kernel 50 us); both passes read them there.  Pass 1: active tiles per offset
-  // (every workgroup counts all offsets: it needs the total).
+  // strided load per loop trip had made this kernel 50 us); both passes read them there.
   auto stage = [&](long long c0, int cn) {
     for (int i0 = tid; i0 < cn; i0 += 256 * 8) {
       unsigned w[8];
@@ -93,36 +103,78 @@ __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __res
     }
     __syncthreads();
   };
+  // Pass 1: active tiles per offset (every workgroup counts all offsets: it needs the total).  Counters in registers, one
+  // wave reduction and one LDS atomic per wave and offset (an LDS atomic per set bit: 64 lanes on <= 27 addresses).
+  int cnt[31];
+#pragma unroll
+  for (int q = 0; q < 31; ++q) cnt[q] = 0;
   for (long long c0 = 0; c0 < n_tiles; c0 += kStage) {
     const int cn = (int)min((long long)kStage, n_tiles - c0);
     if (c0 > 0) __syncthreads();
     stage(c0, cn);
     for (int i = tid; i < cn; i += 256) {
-      unsigned w = wl[i];
-      while (w) {
-        atomicAdd(&U[__ffs((int)w) - 1], 1);
-        w &= w - 1;
-      }
+      const unsigned w = wl[i];
+#pragma unroll
+      for (int q = 0; q < 31; ++q) cnt[q] += (int)((w >> q) & 1u);
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 31; ++q) {
+    const int c = wave_reduce_sum(cnt[q]);
+    if ((tid & 63) == 0 && c) atomicAdd(&U[q], c);
   }
   __syncthreads();
   if (tid == 0) {
-    long long total = 0;
-    for (int q = 0; q < kvol; ++q) total += U[q];
-    const long long T = 8 * std::min<long long>(t8_max, std::max<long long>(1, total / (units_per_slot * 8)));
+    // exactly `slots` slots (>= kvol) over the offsets: floor of the proportional share, at least one per offset that has
+    // units, the rest by largest remainder (ties: lowest offset) -- integer arithmetic, the same on every workgroup
+    // (slots <= 2048 and U < 2^20: the products fit 32 bits)
+    unsigned total = 0;
+    for (int q = 0; q < kvol; ++q) total += (unsigned)U[q];
+    int rem[32];
+    int used = 0;
+    for (int q = 0; q < kvol; ++q) {
+      const unsigned share = (unsigned)slots * (unsigned)U[q];
+      S[q] = total > 0 ? (int)(share / total) : 0;
+      rem[q] = total > 0 ? (int)(share % total) : 0;
+      if (S[q] == 0 && U[q] > 0) {
+        S[q] = 1;
+        rem[q] = -1;
+      }
+      used += S[q];
+    }
+    while (used < slots && total > 0) {   // hand out what is left
+      int best = 0;
+      bool any = false;
+      for (int q = 1; q < kvol; ++q)
+        if (rem[q] > rem[best]) best = q;
+      ++S[best];
+      rem[best] = -1;
+      ++used;
+      for (int q = 0; q < kvol; ++q) any |= rem[q] >= 0;
+      if (!any)
+        for (int q = 0; q < kvol; ++q) rem[q] = U[q];   // (more than one extra per offset: again, by size)
+    }
+    while (used > slots) {   // the one-per-offset minimum overshot: take from the largest
+      int best = 0;
+      for (int q = 1; q < kvol; ++q)
+        if (S[q] > S[best]) best = q;
+      --S[best];
+      --used;
+    }
     int acc = 0;
     for (int q = 0; q < kvol; ++q) {
-      const long long r = total > 0 ? (T * U[q] + total / 2) / total : 1;
-      S[q] = (int)std::max<long long>(1, r);
       KF[q] = acc;
       acc += S[q];
     }
-    KF[kvol] = acc;   // <= T + kvol <= w_max
+    KF[kvol] = acc;   // == slots (or 0 for an empty plan)
   }
   __syncthreads();
-  const int sk = S[k], uk = U[k];
+  const int sk = S[k];
+  const unsigned uk = (unsigned)U[k];
   for (int j = tid; j <= sk; j += 256) lo[j] = (int)n_tiles;
   __syncthreads();
+  // Pass 2: this workgroup's offset.  Rank r of its active tiles starts range j when j(r) != j(r - 1), j(r) = r S / U;
+  // four consecutive tiles per thread and scan step.
   int carry = 0;
   for (long long c0 = 0; c0 < n_tiles; c0 += kStage) {
     const int cn = (int)min((long long)kStage, n_tiles - c0);
@@ -130,16 +182,24 @@ __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __res
       __syncthreads();
       stage(c0, cn);
     }
-    for (int base = 0; base < cn; base += 256) {
-      const int i = base + tid;
-      const int flag = (i < cn) ? (int)((wl[i] >> k) & 1u) : 0;
-      int tot;
-      const int r = carry + block_exclusive_scan(flag, sm, &tot);
-      if (flag) {   // rank r of the offset's active tiles starts range j when j(r) != j(r - 1)   (j(r) = r S / U)
-        const int j = (int)(((long long)r * sk) / uk);
-        const int jp = r > 0 ? (int)(((long long)(r - 1) * sk) / uk) : -1;
-        for (int jj = jp + 1; jj <= j; ++jj) lo[jj] = (int)(c0 + i);
+    for (int base = 0; base < cn; base += 1024) {
+      const int i0 = base + tid * 4;
+      int flag[4], mine = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        flag[u] = (i0 + u < cn) ? (int)((wl[i0 + u] >> k) & 1u) : 0;
+        mine += flag[u];
       }
+      int tot;
+      int r = carry + block_exclusive_scan(mine, sm, &tot);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (flag[u]) {   // (sk >= 1 whenever uk > 0)
+          const int j = (int)(((unsigned)r * (unsigned)sk) / uk);
+          const int jp = r > 0 ? (int)(((unsigned)(r - 1) * (unsigned)sk) / uk) : -1;
+          for (int jj = jp + 1; jj <= j; ++jj) lo[jj] = (int)(c0 + i0 + u);
+          ++r;
+        }
       carry += tot;
     }
   }
@@ -147,15 +207,14 @@ __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __res
   for (int j = tid; j < sk; j += 256) entry[KF[k] + j] = make_int4(k, lo[j], lo[j + 1], 0);
   if (k == 0) {
     for (int q = tid; q <= kvol; q += 256) kfirst[q] = KF[q];
-    for (int e = KF[kvol] + tid; e < w_max; e += 256) entry[e] = make_int4(-1, 0, 0, 0);
+    for (int e = KF[kvol] + tid; e < slots; e += 256) entry[e] = make_int4(-1, 0, 0, 0);
   }
 }
-
 
 template <int NCO, int NCI>
 __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   constexpr int kAcc = NCO * NCI * 4;          // accumulator registers per lane
-  static_assert(NCO == 4 && (NCI == 4 || NCI == 2), "block: 64 output channels x 64 or 32 reduction channels");
+  static_assert((NCO == 4 || NCO == 2 || NCO == 1) && (NCI == 4 || NCI == 2 || NCI == 1), "block: 16 NCO x 16 NCI channels");
   typedef float VA __attribute__((ext_vector_type(NCO)));
   typedef float VB __attribute__((ext_vector_type(NCI)));
   constexpr int kGroup = 256;                  // tiles per pass over the range (<= 64 units per wave and pass)
@@ -325,10 +384,20 @@ __global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict
   }
 }
 
-// Covered: output width a multiple of 64, reduction width 32 or a multiple of 64 (every convolution of the res18 / res34
-// backbones from the first 32 -> 64 layer on; the 5 / 16-channel stem keeps conv_wgrad_small_kernel).
-bool wgt_ok(int cin, int cout, int kvol) {
-  return kvol >= 1 && kvol <= 31 && cout >= 64 && cout % 64 == 0 && (cin == 32 || (cin >= 64 && cin % 64 == 0));
+// Covered: output and reduction widths of 16, 32 or a multiple of 64 (every convolution of the res18 / res34 and
+// CenterPoint backbones but their first one, whose 5 / 6 input channels keep conv_wgrad_small_kernel).
+bool wgt_width_ok(int c) { return c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
+bool wgt_ok(int cin, int cout, int kvol) { return kvol >= 1 && kvol <= 31 && wgt_width_ok(cin) && wgt_width_ok(cout); }
+inline int wgt_tiles(int c) { return c >= 64 ? 4 : c / 16; }   // 16-channel tiles of a block along one side
+
+// workgroups of `kernel` the device holds at once
+template <typename K>
+int resident_workgroups(K kernel) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  return per_cu * cus;
 }
 
 struct WgtLayout {
@@ -336,11 +405,27 @@ struct WgtLayout {
   size_t bytes;
 };
 
+// the (NCO, NCI) instantiation of a layer: f(kernel) for its kernel
+template <typename F>
+auto with_kernel(int cin, int cout, F f) {
+  const int nco = wgt_tiles(cout), nci = wgt_tiles(cin);
+#define EFG_WGT_CASE(A, B) \
+  if (nco == A && nci == B) return f(conv_wgrad_tile_kernel<A, B>);
+  EFG_WGT_CASE(4, 4) EFG_WGT_CASE(4, 2) EFG_WGT_CASE(4, 1) EFG_WGT_CASE(2, 4) EFG_WGT_CASE(2, 2) EFG_WGT_CASE(2, 1)
+  EFG_WGT_CASE(1, 4) EFG_WGT_CASE(1, 2)
+#undef EFG_WGT_CASE
+  return f(conv_wgrad_tile_kernel<1, 1>);
+}
+
+// ONE definition of the slot count of a (rows, window, channels) layer for the schedule, the workspace and the launch
 WgtLayout wgt_layout(int64_t m_out, int cin, int cout, int kvol) {
+  static int resident[5][5] = {};   // per (NCO, NCI): workgroups the device holds (asked once)
+  const int nco = wgt_tiles(cout), nci = wgt_tiles(cin);
+  if (!resident[nco][nci]) resident[nco][nci] = with_kernel(cin, cout, [](auto kern) { return resident_workgroups(kern); });
   WgtLayout L;
-  L.nco_blk = cout / 64;
-  L.nci_blk = cin == 32 ? 1 : cin / 64;
-  L.slots = sched_w_max(plan_tiles(m_out), kvol);
+  L.nco_blk = cout >= 64 ? cout / 64 : 1;
+  L.nci_blk = cin >= 64 ? cin / 64 : 1;
+  L.slots = sched_slots(plan_tiles(m_out), kvol, L.nco_blk * L.nci_blk, resident[nco][nci]);
   L.bytes = (size_t)L.slots * cout * cin * 4;
   return L;
 }
@@ -357,27 +442,24 @@ extern "C" size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin,
   return wgt_layout(m_out, cin, cout, kvol).bytes + 256;
 }
 
-extern "C" size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int kvol) {
-  if (m_out < 0 || kvol < 1 || kvol > 31) return 0;
-  return sched_bytes(plan_tiles(m_out), kvol) + 256;
+extern "C" size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int cin, int cout, int kvol) {
+  if (m_out < 0 || !wgt_ok(cin, cout, kvol)) return 0;
+  return sched_bytes(wgt_layout(m_out, cin, cout, kvol).slots) + 256;
 }
 
-extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int kvol, void* sched, size_t sched_bytes_given,
-                                      void* stream_) {
+extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, int cout, int kvol, void* sched,
+                                      size_t sched_bytes_given, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EFG_CHECK_ARG(m_out >= 0 && m_out < (1ll << 31) && kvol >= 1 && kvol <= 31, "wgrad_sched: bad sizes (m=%lld, kvol=%d)", (long long)m_out, kvol);
+  EFG_CHECK_ARG(m_out >= 0 && m_out < (1ll << 31) && wgt_ok(cin, cout, kvol), "wgrad_sched: bad sizes (m=%lld, %d -> %d, kvol=%d)",
+                (long long)m_out, cin, cout, kvol);
   if (m_out == 0) return EFG_OK;
-  const long long n_tiles = plan_tiles(m_out);
-  EFG_CHECK_ARG(plan && sched && sched_bytes_given >= sched_bytes(n_tiles, kvol), "wgrad_sched: null pointer / buffer too small");
+  const int slots = wgt_layout(m_out, cin, cout, kvol).slots;
+  EFG_CHECK_ARG(plan && sched && sched_bytes_given >= sched_bytes(slots), "wgrad_sched: null pointer / buffer too small");
   EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(sched) & 15) == 0, "wgrad_sched: buffer must be 16-byte aligned");
   const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
-  const int w_max = sched_w_max(n_tiles, kvol);
   int4* entry = static_cast<int4*>(sched);
-  int* kfirst = reinterpret_cast<int*>(entry + w_max);
-  // EFG_WGT_UNITS: units per slot (>= 48: the slot table is sized for that)
-  static const int units_env = getenv("EFG_WGT_UNITS") ? std::max(atoi(getenv("EFG_WGT_UNITS")), kUnitsPerSlot) : kUnitsPerSlot;
-  hipLaunchKernelGGL(wgt_schedule_kernel, dim3(kvol), dim3(256), 0, stream, pv.vm, n_tiles, kvol, sched_t8_max(n_tiles), w_max, units_env,
-                     entry, kfirst);
+  int* kfirst = reinterpret_cast<int*>(entry + slots);
+  hipLaunchKernelGGL(wgt_schedule_kernel, dim3(kvol), dim3(256), 0, stream, pv.vm, pv.n_tiles, kvol, slots, entry, kfirst);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
@@ -421,8 +503,10 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   a.kvol = kvol;
   a.nci_blk = L.nci_blk;
   const dim3 grid(L.slots, L.nco_blk * L.nci_blk);
-  if (cin == 32) hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 2>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv_wgrad_tile_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+  with_kernel(cin, cout, [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a);
+    return 0;
+  });
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * cin;
   const int* kfirst = reinterpret_cast<const int*>(a.entry + L.slots);

@@ -107,13 +107,18 @@ def _build_plan(table, m, kvol):
     return plan
 
 
-def _build_wgrad_sched(plan, m, kvol):
-    """Launch schedule (uint8 buffer) of the plan-walking weight gradient over `plan`."""
+def _build_wgrad_sched(plan, m, cin, cout, kvol):
+    """Launch schedule (uint8 buffer) of the plan-walking weight gradient of a (cin -> cout) layer over `plan`."""
     lib = L.lib()
-    nbytes = lib.efg_spconv_wgrad_sched_bytes(m, kvol)
+    nbytes = lib.efg_spconv_wgrad_sched_bytes(m, cin, cout, kvol)
     sched = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
-    L.check(lib.efg_spconv_wgrad_sched(L.ptr(plan), m, kvol, L.ptr(sched), nbytes, L.stream()))
+    L.check(lib.efg_spconv_wgrad_sched(L.ptr(plan), m, cin, cout, kvol, L.ptr(sched), nbytes, L.stream()))
     return sched
+
+
+def _wgrad_tiled(cin, cout, kvol, m_out):
+    return (kvol <= 31 and m_out > 0 and os.environ.get("EFG_WGRAD_TILED", "1") != "0"
+            and bool(L.lib().efg_spconv_wgrad_tiled_ok(cin, cout, kvol)))
 
 
 def _natural_order(reduce_channels):
@@ -193,10 +198,9 @@ def _conv_dgrad(grad_out, w, rb):
 def _conv_wgrad(features, grad_out, rb):
     lib = L.lib()
     cin, cout, kvol = features.shape[1], grad_out.shape[1], rb.kvol
-    if (kvol <= 31 and rb.m_out > 0 and lib.efg_spconv_wgrad_tiled_ok(cin, cout, kvol)
-            and os.environ.get("EFG_WGRAD_TILED", "1") != "0"):
+    if _wgrad_tiled(cin, cout, kvol, rb.m_out):
         # over the layer's forward tile plan: MFMA operands straight from the feature rows (csrc/spconv_wgt.hip)
-        plan, sched = rb.plan_fwd(), rb.wgrad_sched()
+        plan, sched = rb.plan_fwd(), rb.wgrad_sched(cin, cout)
         ws_bytes = lib.efg_spconv_wgrad_tiled_workspace_bytes(rb.m_out, cin, cout, kvol)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
         grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
@@ -312,7 +316,11 @@ class geometry_stream:
 
 
 class _on_geometry_stream:
-    """`with _on_geometry_stream() as main:` -- main is None when no scope is active."""
+    """`with _on_geometry_stream() as main:` -- main is None when no scope is active.  wait=False: the main stream does
+    NOT wait for what was queued (the caller records an event and waits where the result is used)."""
+
+    def __init__(self, wait=True):
+        self.wait = wait
 
     def __enter__(self):
         self.main = None
@@ -325,7 +333,8 @@ class _on_geometry_stream:
     def __exit__(self, *exc):
         if self.main is not None:
             self.ctx.__exit__(*exc)
-            self.main.wait_stream(_GEO)  # device-side dependency, the host does not block
+            if self.wait:
+                self.main.wait_stream(_GEO)  # device-side dependency, the host does not block
         return False
 
 
@@ -349,30 +358,40 @@ class Rulebook:
         self._order = None
         self._plan_fwd = None
         self._plan_dgrad = None
-        self._wgrad_sched = None
+        self._wgrad_sched = {}
 
     def plan_fwd(self):
-        """Tile plan of `nbr` (csrc/spconv_tiles.hip), built on first use on the geometry stream when one is active --
-        in training together with the launch schedule of the plan-walking weight gradient (wgrad_sched), so that the
-        backward pass finds it ready."""
+        """Tile plan of `nbr` (csrc/spconv_tiles.hip), built on first use on the geometry stream when one is active."""
         if self._plan_fwd is None:
             with _on_geometry_stream() as main:
                 self._plan_fwd = _build_plan(self.nbr, self.m_out, self.kvol)
                 _hand_over(main, self._plan_fwd)
-                if torch.is_grad_enabled() and self._plan_fwd is not None and os.environ.get("EFG_WGRAD_TILED", "1") != "0":
-                    self._wgrad_sched = _build_wgrad_sched(self._plan_fwd, self.m_out, self.kvol)
-                    _hand_over(main, self._wgrad_sched)
         return self._plan_fwd
 
-    def wgrad_sched(self):
-        """Equal-work launch schedule of efg_spconv_wgrad_tiled_f32 over plan_fwd() (csrc/spconv_wgt.hip)."""
-        if self._wgrad_sched is None:
-            plan = self.plan_fwd()
-            if self._wgrad_sched is None:
-                with _on_geometry_stream() as main:
-                    self._wgrad_sched = _build_wgrad_sched(plan, self.m_out, self.kvol)
-                    _hand_over(main, self._wgrad_sched)
-        return self._wgrad_sched
+    def prepare_wgrad(self, cin, cout):
+        """Queue the launch schedule of the plan-walking weight gradient of a (cin -> cout) layer over plan_fwd()
+        (csrc/spconv_wgt.hip) on the geometry stream -- the forward pass of a training step calls this and does NOT wait
+        for it: only the backward pass reads the schedule (wgrad_sched waits for the event recorded here)."""
+        key = (cin, cout)
+        if key in self._wgrad_sched or not _wgrad_tiled(cin, cout, self.kvol, self.m_out):
+            return
+        plan = self.plan_fwd()
+        with _on_geometry_stream(wait=False) as main:
+            sched = _build_wgrad_sched(plan, self.m_out, cin, cout, self.kvol)
+            _hand_over(main, sched)
+            event = None
+            if main is not None:
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream())
+        self._wgrad_sched[key] = (sched, event)
+
+    def wgrad_sched(self, cin, cout):
+        """The schedule queued by prepare_wgrad (built now if the forward pass did not), ready for the current stream."""
+        self.prepare_wgrad(cin, cout)
+        sched, event = self._wgrad_sched[(cin, cout)]
+        if event is not None:
+            torch.cuda.current_stream().wait_event(event)
+        return sched
 
     def plan_dgrad(self):
         """(plan, flip): submanifold -> the forward plan walked with reversed offsets (the transposed table of a
@@ -497,6 +516,8 @@ class _SparseConvFunction(Function):
         cout, cin = weight.shape[0], weight.shape[-1]
         w = weight.reshape(cout, rb.kvol, cin).contiguous()
         out = _conv_forward(features, w, bias, rb)
+        if ctx.needs_input_grad[1] and features.is_cuda:   # (the oracle-backed CPU path of the tests patches _conv_* only)
+            rb.prepare_wgrad(cin, cout)   # the weight gradient's launch schedule, on the geometry stream, ahead of the backward
         ctx.save_for_backward(features, w)
         ctx.rb = rb
         ctx.has_bias = bias is not None

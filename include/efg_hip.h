@@ -206,16 +206,19 @@ int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const floa
 /* The same weight gradient over the tile plan of `nbr` (efg_spconv_tile_plan; the plan the forward pass of the layer
  * uses): a (16-row tile, offset) unit of the plan is four K-steps of the fp32 MFMA whose operands are loaded straight
  * from the feature rows in fragment layout -- no pair compaction, no LDS staging, no workgroup barrier (csrc/spconv_wgt.hip).
- * Covered (efg_spconv_wgrad_tiled_ok): cout a multiple of 64, cin 32 or a multiple of 64, kvol <= 31.  Deterministic
+ * Covered (efg_spconv_wgrad_tiled_ok): cin and cout each 16, 32 or a multiple of 64, kvol <= 31.  Deterministic
  * two-pass like efg_spconv_wgrad_f32; the grouping of a weight's partial sums follows the plan's tiles, so the two
  * entry points agree to fp32 rounding, not bit for bit.  Replaces the same spconv call (indice-conv backward, weight
  * part) as efg_spconv_wgrad_f32: efg/modeling/backbones/sparse_net.py:85-95 via spconv.SparseConv3d / SubMConv3d. */
 int efg_spconv_wgrad_tiled_ok(int cin, int cout, int kvol);
-/* The launch schedule of the plan-walking weight gradient: a device-side table that cuts the plan's (tile, offset)
- * units into slots of EQUAL unit counts (the offsets of a window differ 5x in active tiles), computed from the plan on
- * the device, once per plan; shared by every layer that uses the plan. */
-size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int kvol);
-int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int kvol, void* sched, size_t sched_bytes, void* stream);
+/* The launch schedule of the plan-walking weight gradient for a (cin -> cout) layer over `plan`: a device-side table
+ * that cuts the plan's (tile, offset) units into slots of EQUAL unit counts (the offsets of a window differ 5x in active
+ * tiles); the number of slots is such that slots x blocks of the layer is a whole number of device fills.  Computed from
+ * the plan on the device (no host round trip), a pure function of the plan and the layer shape; layers of equal shape
+ * share it.  efg_spconv_wgrad_tiled_f32 must be given the schedule built for ITS (m_out, cin, cout, kvol). */
+size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int cin, int cout, int kvol);
+int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, int cout, int kvol, void* sched, size_t sched_bytes,
+                           void* stream);
 size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin, int cout, int kvol);
 int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
                                int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,

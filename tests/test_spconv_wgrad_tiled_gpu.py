@@ -1,5 +1,5 @@
 """GPU: the plan-walking weight gradient (csrc/spconv_wgt.hip) against the table-walking kernel it replaces and an
-fp64 sum, at the geometry of a real 180k-point scene (strided 32 -> 64 and submanifold 64 -> 64 / 128 -> 128), plus
+fp64 sum, at the geometry of a real 180k-point scene (the stem's 16 / 32 channels up to 128 -> 256), plus
 run-to-run bit-reproducibility.  The small-shape oracle comparisons of test_spconv_gpu.py go through it as well."""
 import pytest
 import torch
@@ -22,8 +22,9 @@ def _level(dev, n_down):
     return x
 
 
-@pytest.mark.parametrize("kind,n_down,cin,cout", [("down", 1, 32, 64), ("subm", 2, 64, 64), ("subm", 3, 128, 128),
-                                                  ("down", 3, 128, 256), ("head", 3, 128, 128)])
+@pytest.mark.parametrize("kind,n_down,cin,cout", [("subm", 1, 16, 16), ("subm", 1, 16, 32), ("down", 1, 32, 64),
+                                                  ("subm", 2, 64, 64), ("subm", 3, 128, 128), ("down", 3, 128, 256),
+                                                  ("head", 3, 128, 128), ("subm", 2, 32, 32)])
 def test_tiled_wgrad_matches_table_kernel(dev, monkeypatch, kind, n_down, cin, cout):
     import efg_amd.spconv as spconv
     from efg_amd.spconv import core
@@ -67,5 +68,5 @@ def L_ok(cin, cout, kvol):
 
 
 def test_uncovered_shapes_keep_the_table_kernel():
-    assert not L_ok(16, 32, 27) and not L_ok(5, 16, 27) and not L_ok(48, 80, 27) and not L_ok(64, 64, 32)
-    assert L_ok(32, 64, 27) and L_ok(64, 64, 27) and L_ok(256, 256, 3)
+    assert not L_ok(5, 16, 27) and not L_ok(6, 16, 27) and not L_ok(48, 80, 27) and not L_ok(64, 64, 32)
+    assert L_ok(16, 16, 27) and L_ok(16, 32, 27) and L_ok(32, 64, 27) and L_ok(64, 64, 27) and L_ok(256, 256, 3)
