@@ -116,9 +116,20 @@ def _build_wgrad_sched(plan, m, cin, cout, kvol):
     return sched
 
 
+_WGT_OK = {}
+
+
 def _wgrad_tiled(cin, cout, kvol, m_out):
-    return (kvol <= 31 and m_out > 0 and os.environ.get("EFG_WGRAD_TILED", "1") != "0"
-            and bool(L.lib().efg_spconv_wgrad_tiled_ok(cin, cout, kvol)))
+    """Does the plan-walking weight gradient take this layer?  (EFG_WGRAD_TILED=0: the table kernel everywhere.)  Cached:
+    this sits on the host path of every sparse convolution, and the training step is close to host-bound."""
+    if m_out <= 0:
+        return False
+    key = (cin, cout, kvol)
+    ok = _WGT_OK.get(key)
+    if ok is None:
+        ok = _WGT_OK[key] = (kvol <= 31 and os.environ.get("EFG_WGRAD_TILED", "1") != "0"
+                             and bool(L.lib().efg_spconv_wgrad_tiled_ok(cin, cout, kvol)))
+    return ok
 
 
 def _natural_order(reduce_channels):
@@ -200,8 +211,7 @@ def _conv_wgrad(features, grad_out, rb):
     cin, cout, kvol = features.shape[1], grad_out.shape[1], rb.kvol
     if _wgrad_tiled(cin, cout, kvol, rb.m_out):
         # over the layer's forward tile plan: MFMA operands straight from the feature rows (csrc/spconv_wgt.hip)
-        plan, sched = rb.plan_fwd(), rb.wgrad_sched(cin, cout)
-        ws_bytes = lib.efg_spconv_wgrad_tiled_workspace_bytes(rb.m_out, cin, cout, kvol)
+        plan, sched, ws_bytes = rb.plan_fwd(), *rb.wgrad_sched(cin, cout)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
         grad_w = torch.empty((cout, kvol, cin), dtype=torch.float32, device=grad_out.device)
         with _prof.timed("conv_wgrad_tile_kernel+wgt_reduce_kernel", _Cost(rb, cin, cout, "wgrad")):
@@ -383,15 +393,20 @@ class Rulebook:
             if main is not None:
                 event = torch.cuda.Event()
                 event.record(torch.cuda.current_stream())
-        self._wgrad_sched[key] = (sched, event)
+        ws_bytes = L.lib().efg_spconv_wgrad_tiled_workspace_bytes(self.m_out, cin, cout, self.kvol)
+        self._wgrad_sched[key] = [sched, ws_bytes, event]
 
     def wgrad_sched(self, cin, cout):
-        """The schedule queued by prepare_wgrad (built now if the forward pass did not), ready for the current stream."""
-        self.prepare_wgrad(cin, cout)
-        sched, event = self._wgrad_sched[(cin, cout)]
-        if event is not None:
-            torch.cuda.current_stream().wait_event(event)
-        return sched
+        """(schedule, workspace bytes) of the layer shape: the schedule queued by prepare_wgrad (built now if the forward
+        pass did not), ready for the current stream (the event is waited for once: every later use is on that stream)."""
+        key = (cin, cout)
+        if key not in self._wgrad_sched:
+            self.prepare_wgrad(cin, cout)
+        ent = self._wgrad_sched[key]
+        if ent[2] is not None:
+            torch.cuda.current_stream().wait_event(ent[2])
+            ent[2] = None
+        return ent[0], ent[1]
 
     def plan_dgrad(self):
         """(plan, flip): submanifold -> the forward plan walked with reversed offsets (the transposed table of a

@@ -44,10 +44,14 @@ def test_tiled_wgrad_matches_table_kernel(dev, monkeypatch, kind, n_down, cin, c
     go = torch.randn_like(y.features)
     assert L_ok(cin, cout, rb.kvol)
     monkeypatch.setenv("EFG_WGRAD_TILED", "1")
+    core._WGT_OK.clear()          # (the switch is read once per layer shape)
     g1 = core._conv_wgrad(feat, go, rb)
     g1b = core._conv_wgrad(feat, go, rb)
+    assert (cin, cout) in rb._wgrad_sched            # the plan-walking kernel really ran
     monkeypatch.setenv("EFG_WGRAD_TILED", "0")
+    core._WGT_OK.clear()
     g0 = core._conv_wgrad(feat, go, rb)
+    core._WGT_OK.clear()
     assert torch.equal(g1, g1b)                       # fixed summation order
     # fp64 sum over the table, offset by offset
     nbr = rb.nbr.long()
