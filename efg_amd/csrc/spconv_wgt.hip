@@ -42,7 +42,7 @@ struct WgtArgs {
   const int* rows;     // plan
   const int* nb;
   const unsigned* vm;
-  const int4* entry;   // schedule: (offset, first tile, end tile, -) per slot; offset < 0: unused slot
+  const int4* entry;   // schedule, in DISPATCH order: (offset, first tile, end tile, slot) per workgroup; offset < 0: unused
   float* partial;      // [slots][cout][cin]
   long long n_tiles;   // multiple of 64
   int cin, cout, kvol;
@@ -64,7 +64,7 @@ struct WgtArgs {
 // workgroups of the kernel the device holds at once): slots x blocks is a whole number of device fills -- with equal
 // slots, a launch of 2 fills + 6 workgroups costs 3 (PMC: wave slots occupied 68 % of the 64-channel level's launch) --
 // and the device deals exactly that many slots to the offsets by their unit counts (largest remainders).
-// buffer: int4 entry[slots] | int kfirst[33]
+// buffer: int4 dispatch[8 ceil(slots / 8)] | int kfirst[36] | int4 entry[slots]   (dispatch: wgt_order_kernel)
 constexpr int kUnitsPerSlot = 80;
 constexpr int kMaxSlots = 2048;
 
@@ -78,7 +78,9 @@ inline int sched_slots(long long n_tiles, int kvol, int nblk, int resident) {
   slots = std::max<long long>(slots, kvol);
   return (int)std::min<long long>(slots, kMaxSlots);
 }
-inline size_t sched_bytes(int slots) { return (size_t)slots * 16 + 33 * 4; }
+inline int sched_dispatch(int slots) { return (slots + 7) / 8 * 8; }
+__device__ inline int sched_dispatch_dev(int slots) { return (slots + 7) / 8 * 8; }
+inline size_t sched_bytes(int slots) { return (size_t)sched_dispatch(slots) * 16 + 36 * 4 + (size_t)slots * 16; }
 
 __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __restrict__ vm, long long n_tiles, int kvol, int slots,
                                                             int4* __restrict__ entry, int* __restrict__ kfirst) {
@@ -204,10 +206,56 @@ __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __res
     }
   }
   __syncthreads();
-  for (int j = tid; j < sk; j += 256) entry[KF[k] + j] = make_int4(k, lo[j], lo[j + 1], 0);
+  for (int j = tid; j < sk; j += 256) entry[KF[k] + j] = make_int4(k, lo[j], lo[j + 1], KF[k] + j);
   if (k == 0) {
     for (int q = tid; q <= kvol; q += 256) kfirst[q] = KF[q];
-    for (int e = KF[kvol] + tid; e < slots; e += 256) entry[e] = make_int4(-1, 0, 0, 0);
+    for (int e = KF[kvol] + tid; e < slots; e += 256) entry[e] = make_int4(-1, 0x7fffffff, 0x7fffffff, e);
+  }
+}
+
+// Dispatch order.  The slots of the table above are grouped by offset (the reduction needs that), but consecutive
+// workgroups go round-robin to the 8 XCDs and every offset of a tile range reads the SAME grad_out rows and neighbouring
+// input rows: launched in table order, each XCD's L2 sees every row once per offset it happens to draw -- PMC: 192 MB
+// fetched past L2 per launch of the 64-channel kernel for ~21 MB of rows, 282-372 MB on the 16-channel level.  Here the
+// slots are sorted by their first tile (all offsets together) and dealt in eighths: XCD x walks the x-th eighth of the
+// rows in tile order with the offsets of a range next to each other in time (workgroup 8 q + x = q-th slot of the x-th
+// eighth).  One workgroup, an LDS bitonic sort of <= 2048 keys.
+__global__ void __launch_bounds__(1024) wgt_order_kernel(const int4* __restrict__ entry, int slots, int4* __restrict__ dispatch,
+                                                          int by_position) {
+  __shared__ unsigned long long key[kMaxSlots];
+  const int tid = threadIdx.x;
+  int n2 = 1;
+  while (n2 < slots) n2 <<= 1;
+  for (int i = tid; i < n2; i += 1024) {
+    unsigned long long kx = ~0ull;
+    if (i < slots) {
+      const int4 e = entry[i];
+      // empty ranges (and unused slots) last; ties: table order (offset, then range)
+      const unsigned lo = (e.x >= 0 && e.z > e.y) ? (unsigned)e.y : 0x7fffffffu;
+      kx = ((unsigned long long)lo << 16) | (unsigned)i;
+    }
+    key[i] = kx;
+  }
+  __syncthreads();
+  for (int size = 2; size <= n2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n2 >> 1); t += 1024) {
+        const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int j = i | stride;
+        const unsigned long long x = key[i], y = key[j];
+        if ((x > y) == ((i & size) == 0)) {
+          key[i] = y;
+          key[j] = x;
+        }
+      }
+      __syncthreads();
+    }
+  const int d_n = sched_dispatch_dev(slots), per = d_n >> 3;
+  for (int d = tid; d < d_n; d += 1024) dispatch[d] = make_int4(-1, 0, 0, 0);
+  __syncthreads();
+  for (int s = tid; s < slots; s += 1024) {
+    if (by_position) dispatch[8 * (s % per) + s / per] = entry[(int)(key[s] & 0xffffu)];
+    else dispatch[s] = entry[s];   // (A/B: table order)
   }
 }
 
@@ -222,7 +270,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   __shared__ int lst[4][kGroup / 4];           // per wave: its active tiles of the current group
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int4 ent = a.entry[blockIdx.x];   // (the schedule: which offset, which tiles; slot = blockIdx.x)
+  const int4 ent = a.entry[blockIdx.x];   // (the schedule: which offset, which tiles, which slot of the workspace)
   if (ent.x < 0) return;
   const int k = ent.x, yb = blockIdx.y;
   const int co0 = (yb / a.nci_blk) * (NCO * 16), ci0 = (yb % a.nci_blk) * (NCI * 16);
@@ -334,7 +382,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   }
   __syncthreads();
   if (wv > 0) return;
-  float* p = a.partial + (long long)blockIdx.x * a.cout * a.cin;
+  float* p = a.partial + (long long)ent.w * a.cout * a.cin;
   // C/D layout of 16x16x4: M = (lane >> 4) * 4 + reg, N = lane & 15; with the channel bijection of load_data
   // co = co0 + NCO * M + ct and ci = ci0 + NCI * N + it: a lane's NCI values of (ct, reg) are consecutive in memory
 #pragma unroll
@@ -457,9 +505,12 @@ extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, 
   EFG_CHECK_ARG(plan && sched && sched_bytes_given >= sched_bytes(slots), "wgrad_sched: null pointer / buffer too small");
   EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(sched) & 15) == 0, "wgrad_sched: buffer must be 16-byte aligned");
   const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
-  int4* entry = static_cast<int4*>(sched);
-  int* kfirst = reinterpret_cast<int*>(entry + slots);
+  int4* dispatch = static_cast<int4*>(sched);
+  int* kfirst = reinterpret_cast<int*>(dispatch + sched_dispatch(slots));
+  int4* entry = reinterpret_cast<int4*>(kfirst + 36);
   hipLaunchKernelGGL(wgt_schedule_kernel, dim3(kvol), dim3(256), 0, stream, pv.vm, pv.n_tiles, kvol, slots, entry, kfirst);
+  static const int order_env = getenv("EFG_WGT_ORDER") ? atoi(getenv("EFG_WGT_ORDER")) : 1;   // 0: table order (A/B)
+  hipLaunchKernelGGL(wgt_order_kernel, dim3(1), dim3(1024), 0, stream, entry, slots, dispatch, order_env);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
@@ -502,14 +553,14 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   a.cout = cout;
   a.kvol = kvol;
   a.nci_blk = L.nci_blk;
-  const dim3 grid(L.slots, L.nco_blk * L.nci_blk);
+  const dim3 grid(sched_dispatch(L.slots), L.nco_blk * L.nci_blk);
   with_kernel(cin, cout, [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a);
     return 0;
   });
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * cin;
-  const int* kfirst = reinterpret_cast<const int*>(a.entry + L.slots);
+  const int* kfirst = reinterpret_cast<const int*>(a.entry + sched_dispatch(L.slots));
   hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 256)), dim3(256), 0, stream, a.partial, kfirst, kvol, cout,
                      cin, grad_w);
   EFG_LAUNCH_CHECK();
