@@ -126,49 +126,28 @@ __global__ void __launch_bounds__(256) wgt_schedule_kernel(const unsigned* __res
     if ((tid & 63) == 0 && c) atomicAdd(&U[q], c);
   }
   __syncthreads();
-  if (tid == 0) {
-    // exactly `slots` slots (>= kvol) over the offsets: floor of the proportional share, at least one per offset that has
-    // units, the rest by largest remainder (ties: lowest offset) -- integer arithmetic, the same on every workgroup
-    // (slots <= 2048 and U < 2^20: the products fit 32 bits)
-    unsigned total = 0;
-    for (int q = 0; q < kvol; ++q) total += (unsigned)U[q];
-    int rem[32];
-    int used = 0;
-    for (int q = 0; q < kvol; ++q) {
-      const unsigned share = (unsigned)slots * (unsigned)U[q];
-      S[q] = total > 0 ? (int)(share / total) : 0;
-      rem[q] = total > 0 ? (int)(share % total) : 0;
-      if (S[q] == 0 && U[q] > 0) {
-        S[q] = 1;
-        rem[q] = -1;
-      }
-      used += S[q];
+  if (tid < 64) {
+    // Exactly `slots` slots (>= kvol) over the offsets, lane q = offset q: one slot for every offset that has units, the
+    // rest in proportion to the unit counts (floor + largest remainder; ties: lowest offset) -- integer arithmetic, the same
+    // on every workgroup (slots <= 2048 and U < 2^20: the products fit 32 bits).
+    const int q = tid;
+    const int uq = (q < kvol) ? U[q] : 0;
+    const int total = wave_reduce_sum(uq);
+    const int nact = wave_reduce_sum(uq > 0 ? 1 : 0);
+    const int spare = slots - nact;
+    const unsigned share = (unsigned)spare * (unsigned)uq;
+    const int f = total > 0 ? (int)(share / (unsigned)total) : 0;
+    const int r = total > 0 ? (int)(share % (unsigned)total) : 0;
+    const int left = spare - wave_reduce_sum(f);   // < nact
+    int rank = 0;   // offsets with units whose remainder comes before this one's
+    for (int p = 0; p < 32; ++p) {
+      const int rp = __shfl(r, p, 64), up = __shfl(uq, p, 64);
+      if (up > 0 && (rp > r || (rp == r && p < q))) ++rank;
     }
-    while (used < slots && total > 0) {   // hand out what is left
-      int best = 0;
-      bool any = false;
-      for (int q = 1; q < kvol; ++q)
-        if (rem[q] > rem[best]) best = q;
-      ++S[best];
-      rem[best] = -1;
-      ++used;
-      for (int q = 0; q < kvol; ++q) any |= rem[q] >= 0;
-      if (!any)
-        for (int q = 0; q < kvol; ++q) rem[q] = U[q];   // (more than one extra per offset: again, by size)
-    }
-    while (used > slots) {   // the one-per-offset minimum overshot: take from the largest
-      int best = 0;
-      for (int q = 1; q < kvol; ++q)
-        if (S[q] > S[best]) best = q;
-      --S[best];
-      --used;
-    }
-    int acc = 0;
-    for (int q = 0; q < kvol; ++q) {
-      KF[q] = acc;
-      acc += S[q];
-    }
-    KF[kvol] = acc;   // == slots (or 0 for an empty plan)
+    const int sq = uq > 0 ? 1 + f + (rank < left ? 1 : 0) : 0;
+    const int inc = wave_inclusive_scan(sq);
+    if (q < 32) S[q] = sq;
+    if (q <= 32) KF[q] = inc - sq;   // KF[kvol] == slots (0 for an empty plan)
   }
   __syncthreads();
   const int sk = S[k];
