@@ -46,6 +46,7 @@ struct WgtArgs {
   float* partial;      // [slots][cout][cin]
   long long n_tiles;   // multiple of 64
   int cin, cout, kvol;
+  int cin_pad;          // row length of a partial block: cin, or 16 for a reduction width below 16 (the first layer's 5 / 6)
   int nci_blk;          // blocks along cin
 };
 
@@ -277,11 +278,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
     for (int q = 0; q < 4; ++q) {
       // 32-bit byte offsets (saddr + voffset loads; the host checks both tensors are below 4 GB)
       const unsigned ao = ((unsigned)max(ro[q], 0) * (unsigned)a.cout + (unsigned)(co0 + NCO * m)) * 4u;
-      const unsigned bo = ((unsigned)max(rn[q], 0) * (unsigned)a.cin + (unsigned)(ci0 + NCI * m)) * 4u;
+      const unsigned bo = ((unsigned)max(rn[q], 0) * (unsigned)a.cin + (unsigned)min(ci0 + NCI * m, a.cin - NCI)) * 4u;
       A[q] = *reinterpret_cast<const VA*>(reinterpret_cast<const char*>(a.go) + ao);
       B[q] = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(a.in) + bo);
       ok |= (rn[q] >= 0 ? 1u : 0u) << q;
     }
+    if (ci0 + NCI * m >= a.cin) ok = 0;   // (a reduction width below 16: the lanes past it multiply zeros)
     return ok;
   };
   auto mfmas = [&](const VA (&A)[4], const VB (&B)[4], unsigned ok) {
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   }
   __syncthreads();
   if (wv > 0) return;
-  float* p = a.partial + (long long)ent.w * a.cout * a.cin;
+  float* p = a.partial + (long long)ent.w * a.cout * a.cin_pad;
   // C/D layout of 16x16x4: M = (lane >> 4) * 4 + reg, N = lane & 15; with the channel bijection of load_data
   // co = co0 + NCO * M + ct and ci = ci0 + NCI * N + it: a lane's NCI values of (ct, reg) are consecutive in memory
 #pragma unroll
@@ -375,16 +377,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
         v[it] = ((acc[ct][it][r] + red[0][e]) + red[1][e]) + red[2][e];
       }
       const int co = co0 + NCO * (kk * 4 + r) + ct;
-      *reinterpret_cast<VB*>(p + (long long)co * a.cin + ci0 + NCI * m) = v;
+      *reinterpret_cast<VB*>(p + (long long)co * a.cin_pad + ci0 + NCI * m) = v;
     }
 }
 
 // gw[co][k][ci] = sum over the slots of offset k of partial[slot][co][ci], in slot order; 4 consecutive ci per thread
+// (partial rows are cin_pad long: 16 for a reduction width below 16)
 __global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict__ partial,
-                                                          const int* __restrict__ kfirst, int kvol, int cout, int cin,
+                                                          const int* __restrict__ kfirst, int kvol, int cout, int cin, int cin_pad,
                                                           float* __restrict__ gw) {
   __shared__ f32x4 sm[4][64];
-  const long long blk = (long long)cout * cin, per = (long long)kvol * blk;
+  const long long blk = (long long)cout * cin_pad, per = (long long)kvol * blk;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long e = ((long long)blockIdx.x * 64 + lane) * 4;   // (k, co, ci); blk is a multiple of 256: k is block-uniform
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -406,16 +409,27 @@ __global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict
   __syncthreads();
   if (wv == 0 && e < per) {
     const f32x4 s = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-    const int co = (int)(rem / cin), ci = (int)(rem - (long long)co * cin);
-    *reinterpret_cast<f32x4*>(gw + ((long long)co * kvol + k) * cin + ci) = s;
+    const int co = (int)(rem / cin_pad), ci = (int)(rem - (long long)co * cin_pad);
+    float* g = gw + ((long long)co * kvol + k) * cin + ci;
+    if (cin_pad == cin) {
+      *reinterpret_cast<f32x4*>(g) = s;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ci + u < cin) g[u] = s[u];
+    }
   }
 }
 
-// Covered: output and reduction widths of 16, 32 or a multiple of 64 (every convolution of the res18 / res34 and
-// CenterPoint backbones but their first one, whose 5 / 6 input channels keep conv_wgrad_small_kernel).
+// Covered: output widths of 16, 32 or a multiple of 64; reduction widths of 1 .. 16 (the first layer's 5 / 6 point features:
+// one 16-wide tile whose lanes past the width multiply zeros), 32 or a multiple of 64 -- every convolution of the res18 /
+// res34 and CenterPoint backbones.
 bool wgt_width_ok(int c) { return c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
-bool wgt_ok(int cin, int cout, int kvol) { return kvol >= 1 && kvol <= 31 && wgt_width_ok(cin) && wgt_width_ok(cout); }
-inline int wgt_tiles(int c) { return c >= 64 ? 4 : c / 16; }   // 16-channel tiles of a block along one side
+bool wgt_ok(int cin, int cout, int kvol) {
+  return kvol >= 1 && kvol <= 31 && wgt_width_ok(cout) && ((cin >= 1 && cin <= 16) || wgt_width_ok(cin));
+}
+inline int wgt_tiles(int c) { return c >= 64 ? 4 : (c + 15) / 16; }   // 16-channel tiles of a block along one side
+inline int wgt_cin_pad(int cin) { return cin < 16 ? 16 : cin; }
 
 // workgroups of `kernel` the device holds at once
 template <typename K>
@@ -453,7 +467,7 @@ WgtLayout wgt_layout(int64_t m_out, int cin, int cout, int kvol) {
   L.nco_blk = cout >= 64 ? cout / 64 : 1;
   L.nci_blk = cin >= 64 ? cin / 64 : 1;
   L.slots = sched_slots(plan_tiles(m_out), kvol, L.nco_blk * L.nci_blk, resident[nco][nci]);
-  L.bytes = (size_t)L.slots * cout * cin * 4;
+  L.bytes = (size_t)L.slots * cout * wgt_cin_pad(cin) * 4;
   return L;
 }
 
@@ -531,6 +545,7 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   a.cin = cin;
   a.cout = cout;
   a.kvol = kvol;
+  a.cin_pad = wgt_cin_pad(cin);
   a.nci_blk = L.nci_blk;
   const dim3 grid(sched_dispatch(L.slots), L.nco_blk * L.nci_blk);
   with_kernel(cin, cout, [&](auto kern) {
@@ -538,10 +553,10 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
     return 0;
   });
   EFG_LAUNCH_CHECK();
-  const long long per = (long long)kvol * cout * cin;
+  const long long per = (long long)kvol * cout * a.cin_pad;
   const int* kfirst = reinterpret_cast<const int*>(a.entry + sched_dispatch(L.slots));
   hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 256)), dim3(256), 0, stream, a.partial, kfirst, kvol, cout,
-                     cin, grad_w);
+                     cin, a.cin_pad, grad_w);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

@@ -367,6 +367,7 @@ class Rulebook:
         self._pairs = None
         self._order = None
         self._plan_fwd = None
+        self._plan_stream = None
         self._plan_dgrad = None
         self._wgrad_sched = {}
 
@@ -376,6 +377,7 @@ class Rulebook:
             with _on_geometry_stream() as main:
                 self._plan_fwd = _build_plan(self.nbr, self.m_out, self.kvol)
                 _hand_over(main, self._plan_fwd)
+                self._plan_stream = torch.cuda.current_stream() if self._plan_fwd is not None else None
         return self._plan_fwd
 
     def prepare_wgrad(self, cin, cout):
@@ -387,6 +389,9 @@ class Rulebook:
             return
         plan = self.plan_fwd()
         with _on_geometry_stream(wait=False) as main:
+            cur = torch.cuda.current_stream()
+            if self._plan_stream is not None and self._plan_stream != cur:
+                cur.wait_stream(self._plan_stream)   # (a plan built outside the scope this runs in)
             sched = _build_wgrad_sched(plan, self.m_out, cin, cout, self.kvol)
             _hand_over(main, sched)
             event = None

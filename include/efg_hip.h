@@ -206,7 +206,7 @@ int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin, const floa
 /* The same weight gradient over the tile plan of `nbr` (efg_spconv_tile_plan; the plan the forward pass of the layer
  * uses): a (16-row tile, offset) unit of the plan is four K-steps of the fp32 MFMA whose operands are loaded straight
  * from the feature rows in fragment layout -- no pair compaction, no LDS staging, no workgroup barrier (csrc/spconv_wgt.hip).
- * Covered (efg_spconv_wgrad_tiled_ok): cin and cout each 16, 32 or a multiple of 64, kvol <= 31.  Deterministic
+ * Covered (efg_spconv_wgrad_tiled_ok): cout 16, 32 or a multiple of 64; cin 1..16, 32 or a multiple of 64; kvol <= 31.  Deterministic
  * two-pass like efg_spconv_wgrad_f32; the grouping of a weight's partial sums follows the plan's tiles, so the two
  * entry points agree to fp32 rounding, not bit for bit.  Replaces the same spconv call (indice-conv backward, weight
  * part) as efg_spconv_wgrad_f32: efg/modeling/backbones/sparse_net.py:85-95 via spconv.SparseConv3d / SubMConv3d. */

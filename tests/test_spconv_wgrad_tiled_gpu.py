@@ -22,7 +22,7 @@ def _level(dev, n_down):
     return x
 
 
-@pytest.mark.parametrize("kind,n_down,cin,cout", [("subm", 1, 16, 16), ("subm", 1, 16, 32), ("down", 1, 32, 64),
+@pytest.mark.parametrize("kind,n_down,cin,cout", [("down", 0, 5, 16), ("subm", 1, 16, 16), ("subm", 1, 16, 32), ("down", 1, 32, 64),
                                                   ("subm", 2, 64, 64), ("subm", 3, 128, 128), ("down", 3, 128, 256),
                                                   ("head", 3, 128, 128), ("subm", 2, 32, 32)])
 def test_tiled_wgrad_matches_table_kernel(dev, monkeypatch, kind, n_down, cin, cout):
@@ -72,5 +72,5 @@ def L_ok(cin, cout, kvol):
 
 
 def test_uncovered_shapes_keep_the_table_kernel():
-    assert not L_ok(5, 16, 27) and not L_ok(6, 16, 27) and not L_ok(48, 80, 27) and not L_ok(64, 64, 32)
-    assert L_ok(16, 16, 27) and L_ok(16, 32, 27) and L_ok(32, 64, 27) and L_ok(64, 64, 27) and L_ok(256, 256, 3)
+    assert not L_ok(48, 80, 27) and not L_ok(64, 64, 32) and not L_ok(24, 32, 27) and not L_ok(16, 48, 27)
+    assert L_ok(5, 16, 27) and L_ok(6, 16, 27) and L_ok(16, 16, 27) and L_ok(16, 32, 27) and L_ok(32, 64, 27) and L_ok(64, 64, 27) and L_ok(256, 256, 3)
