@@ -18,11 +18,11 @@
 // load (rows 4 kk .. 4 kk + 3 of the tile's row list / neighbour column).
 //
 // Launch: one workgroup = (slot of the schedule below: ONE kernel offset and a range of tiles holding ~80 active ones,
-// 16*NCO x 16*NCI block of dW: 64 x 64 from 64 channels up); its four waves deal the active tiles of the range round-robin, each accumulating the whole
-// block privately over a register pipeline (row numbers of unit u + 2 and operands of unit u + 1 in flight during the
-// 16 * NCI MFMAs of unit u); the four partial blocks are summed through LDS in wave order and the workgroup's block goes to
-// the workspace, which wgt_reduce_kernel folds over the slots of each offset in a fixed order (bit-reproducible run to
-// run, as before).
+// 16 NCO x 16 NCI block of dW: 64 x 64 from 64 channels up); its four waves deal the active tiles of the range
+// round-robin, each accumulating the whole block privately over a register pipeline (row numbers of unit u + 2 and
+// operands of unit u + 1 in flight during the 4 NCO NCI MFMAs of unit u); the four partial blocks are summed through LDS
+// in wave order and the workgroup's block goes to the workspace, which wgt_reduce_kernel folds over the slots of each
+// offset in a fixed order (bit-reproducible run to run, as before).
 #include "common.h"
 #include "tile_plan.h"
 
@@ -43,7 +43,7 @@ struct WgtArgs {
   const int* nb;
   const unsigned* vm;
   const int4* entry;   // schedule, in DISPATCH order: (offset, first tile, end tile, slot) per workgroup; offset < 0: unused
-  float* partial;      // [slots][cout][cin]
+  float* partial;      // [slots][cout][cin_pad]
   long long n_tiles;   // multiple of 64
   int cin, cout, kvol;
   int cin_pad;          // row length of a partial block: cin, or 16 for a reduction width below 16 (the first layer's 5 / 6)
@@ -58,9 +58,8 @@ struct WgtArgs {
 // computed on the device (no host round trip) and a pure function of the plan (reproducible): offset k gets
 // S_k ~ T * U_k / sum U slots (U_k = its active tiles; T ~ one slot per 80 units) and its tiles are cut where the
 // running count of ACTIVE tiles crosses j * U_k / S_k -- every slot of the launch has the same number of units.
-// Slots of one offset are contiguous and in tile order (the reduction walks them in order).  Dealing an offset's ranges
-// to the XCDs by tile position (slot 8 q + x = q-th range of the x-th eighth of the rows, so that the workgroups of XCD x
-// share its L2 at every offset) was measured and lost: 86.7 vs 78.1 us on the 64-channel level, equal elsewhere.
+// Slots of one offset are contiguous and in tile order (the reduction walks them in order); the order the workgroups
+// are DISPATCHED in is a different one (wgt_order_kernel, below).
 // The number of slots is fixed by the HOST from what it knows (tiles, window, the layer's block count, how many
 // workgroups of the kernel the device holds at once): slots x blocks is a whole number of device fills -- with equal
 // slots, a launch of 2 fills + 6 workgroups costs 3 (PMC: wave slots occupied 68 % of the 64-channel level's launch) --
