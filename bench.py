@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-arm", action="store_true", help="skip the third timing (bf16x3 split-precision A/B arm)")
     ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")
     ap.add_argument("--full-graph", action="store_true", help="make the full reference graph the headline run")
+    ap.add_argument("--ddp-mode", default=None, choices=["bucket", "flat", "static", "find_unused", "plain"],
+                    help="N > 1 gradient exchange (engine.Trainer): bucket = three flat buckets all-reduced on a communication "
+                         "stream while backward still runs (default, what the reference's DDP does); flat = one all-reduce "
+                         "after backward; static / find_unused / plain = torch DistributedDataParallel variants")
     return ap.parse_args()
 
 
@@ -213,6 +217,30 @@ def _geometry_report(trainer, batch):
     return {"points": n_points, "input_voxels": int(coords.shape[0]), "tables": tables}
 
 
+def _rank_report(trainer, batch, world, dev):
+    """Per-rank facts gathered after the timed region: input voxels of the rank's first batch (scenes differ in size: this
+    is the weak-scaling imbalance) and the number of stream-K units that had to be recomputed because a share did not
+    arrive within the bounded wait (csrc/spconv_tiles.hip; 0 in a healthy run -- a non-zero count means a silent 2x on
+    those units, e.g. two processes spinning on one device)."""
+    import ctypes
+
+    from efg_amd import _lib
+    from efg_amd.operators import voxelize_batch
+
+    cfg = trainer.cfg.dataset
+    vox = cfg.processors.train.Voxelization
+    out = voxelize_batch([b[0]["points"] for b in batch], list(cfg.voxel_size), list(cfg.pc_range),
+                         vox.max_points_in_voxel, vox.max_voxel_num, with_mean=False)
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.lib().efg_spconv_streamk_fallbacks(ctypes.byref(n), 0))
+    mine = torch.tensor([sum(out["num_voxels"]), n.value], device=dev, dtype=torch.int64)
+    every = [mine]
+    if world > 1:
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+    return {"rank_input_voxels": [int(t[0]) for t in every], "streamk_fallbacks": [int(t[1]) for t in every]}
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with one rank per
     GPU (what the reference's efg/engine/launch.py:52-57 does with mp.spawn), rendezvous on 127.0.0.1, rank 0 prints the
@@ -260,7 +288,7 @@ def main():
     overrides = {"model.transformer.num_queries": args.queries}
     if args.full_graph:
         overrides["model.eval_unused_levels"] = True
-    trainer = Trainer(config=config, device=dev, overrides=overrides, seed=0)
+    trainer = Trainer(config=config, device=dev, overrides=overrides, seed=0, ddp_mode=args.ddp_mode)
     # rank-sharded scenes: scene ids are disjoint across ranks (weak scaling: fixed per-GPU work)
     pool = [synthetic_batch(2000 + 100 * p + rank * args.scenes, args.scenes, n_points=args.points, device=dev,
                             n_sweeps=args.sweeps, clutter=0.55 if args.dense else 0.0) for p in range(args.pool)]
@@ -269,6 +297,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    stats = {}
 
     def timed_run(tr, steps, warmup):
         if warmup == 0:
@@ -281,17 +311,25 @@ def main():
         t0 = time.perf_counter()
         for s in range(steps):
             tr.step(pool[s % len(pool)])
+        issued = time.perf_counter() - t0     # the host has QUEUED the last step here; the device may still be running
         barrier()
         elapsed = time.perf_counter() - t0
+        stats["host_issue_ms_per_step"] = 1000.0 * issued / steps
+        stats["rank_ms_per_step"] = [1000.0 * elapsed / steps]
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            mine = torch.tensor([elapsed, issued], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            stats["rank_ms_per_step"] = [1000.0 * float(t[0]) / steps for t in every]
+            stats["host_issue_ms_per_step"] = max(1000.0 * float(t[1]) / steps for t in every)
+            elapsed = max(float(t[0]) for t in every)     # MAX over ranks
         return elapsed
 
     elapsed = timed_run(trainer, args.steps, args.warmup)
     scenes_total = args.scenes * world * args.steps
-    graph = "full reference graph" if args.full_graph else "unused FPN levels not evaluated"
+    graph = ("full reference graph" if args.full_graph else
+             "FPN levels / heads the reference evaluates and never reads are skipped (same losses and gradients; the line's "
+             "`full_graph` object times the full reference graph)")
     line = {
         "metric": "scenes/sec %s 1-frame Waymo train step" % {"conquer": "ConQueR", "voxeldetr": "Voxel-DETR"}[args.model],
         "value": scenes_total / elapsed,
@@ -310,7 +348,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s res18 p3, %d-sweep Waymo-shaped scenes%s, %d pts/scene, 0.1 m voxels, %d scenes/GPU, %d queries, "
-                        "fwd+bwd+AdamW+OneCycle, %s" % ({"conquer": "ConQueR", "voxeldetr": "Voxel-DETR"}[args.model],
+                        "fwd+bwd+AdamW+OneCycle, graph of `value`: %s" % ({"conquer": "ConQueR", "voxeldetr": "Voxel-DETR"}[args.model],
                                                         args.sweeps, " (dense preset: voxel cap hit)" if args.dense else "",
                                                         args.points, args.scenes, args.queries, graph),
             "global_batch": args.scenes * world,
@@ -319,7 +357,15 @@ def main():
         # what the collective library saw (the driver can check that RCCL ran with N ranks)
         "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
         "dist_backend": ("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if dist.is_initialized() else None,
+        # N > 1 readiness: which exchange ran, every rank's own step time (the spread is the load imbalance between the
+        # ranks' scenes plus host jitter), and the time the slowest HOST needed to queue a step (the step is within a few
+        # ms of host-bound: value cannot drop below this)
+        "ddp_mode": trainer.ddp_mode,
+        "rank_ms_per_step": {"min": round(min(stats["rank_ms_per_step"]), 3), "max": round(max(stats["rank_ms_per_step"]), 3),
+                             "all": [round(t, 3) for t in stats["rank_ms_per_step"]]},
+        "host_issue_ms_per_step": round(stats["host_issue_ms_per_step"], 3),
     }
+    line.update(_rank_report(trainer, pool[0], world, dev))
     # ---- per-kernel numbers: extra steps, outside the timed region ------------------------------------------------
     if args.profile_steps > 0:
         _prof.enable(True)
@@ -402,6 +448,20 @@ def main():
         line["full_graph"] = {"ms_per_step": 1000.0 * e2 / steps, "value": args.scenes * steps / e2, "steps": steps,
                               "note": "also evaluates FPN p2 / p4-output / p5 and res2_out like the reference; "
                                       "same losses and gradients"}
+    # ---- BASELINE.json configs[2] names 900 queries where the reference YAML (and `value` above) has 1000 ----------------
+    if args.queries != 900 and world == 1 and not args.no_full_graph and args.model == "conquer":
+        torch.cuda.empty_cache()
+        ov = dict(overrides)
+        ov["model.transformer.num_queries"] = 900
+        b900 = Trainer(config=config, device=dev, overrides=ov, seed=0, ddp_mode=args.ddp_mode)
+        steps = max(5, args.steps // 2)
+        e9 = timed_run(b900, steps, 3)
+        b900.close()
+        del b900
+        line["baseline_config"] = {"ms_per_step": 1000.0 * e9 / steps, "value": args.scenes * steps / e9, "unit": "scenes/s",
+                                   "steps": steps, "queries": 900,
+                                   "note": "the same step with BASELINE.json configs[2]'s 900 queries (per-GPU share of the "
+                                           "batch-16 / 8-GPU config: 2 scenes); `value` uses the reference YAML's 1000"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             base = cpu_baseline(args)

@@ -21,9 +21,10 @@ _SIGS = {
     "efg_capture_stream_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "efg_capture_stream_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "efg_dynamic_voxelize_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "efg_hard_voxelize_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "efg_hard_voxelize_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "efg_hard_voxelize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_hard_voxelize_debug_timeline": (c_size_t, [c_void_p]),
     "efg_scatter_workspace_bytes": (c_size_t, [c_int64, c_int, c_void_p]),
     "efg_scatter_index": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p]),
@@ -53,6 +54,7 @@ _SIGS = {
     "efg_spconv_forward_tiled_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                              c_int64, c_int, c_void_p, c_void_p]),
     "efg_spconv_tile_bf16x3_ok": (c_int, [c_int, c_int, c_int, c_int64, c_int64]),
+    "efg_spconv_streamk_fallbacks": (c_int, [c_void_p, c_int]),
     "efg_spconv_parity_order": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "efg_spconv_wgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,

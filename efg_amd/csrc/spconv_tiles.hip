@@ -160,6 +160,7 @@ struct TileArgs {
   int* sk_flags;         // [grid] epoch of the last share a workgroup published
   int sk_epoch;
   int sk_polls;          // polls of a share's flag before the unit is recomputed instead (EFG_TILE_SK_POLLS, default 20000)
+  int* sk_fallbacks;     // device counter: units recomputed because a share did not arrive in time (efg_spconv_streamk_fallbacks)
   unsigned ux, uy;       // the unit grid (what gridDim is otherwise)
   long long zero_off;    // byte offset from `in` of 16 zero bytes (absent rows / channel pieces past cin gather those)
   int bf3;               // 1: split-precision arm (MODE & 4), weights packed by efg_spconv_pack_weight_f32 with flag 4
@@ -553,7 +554,10 @@ conv_tile_kernel(TileArgs a) {
       }
       ok = __builtin_amdgcn_readfirstlane(ok);
       if (!ok) {
-        if (lane == 0) *s_redo = 1;
+        if (lane == 0) {
+          *s_redo = 1;
+          atomicAdd(a.sk_fallbacks, 1);   // never silent: the bench line and the stream-K test read this counter
+        }
         return;
       }
       __builtin_amdgcn_wave_barrier();
@@ -776,23 +780,25 @@ void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* n
 // use, kept for the life of the process (a few MB).  The flags are monotonic: a launch publishes its own epoch.
 struct StreamKState {
   float* scratch = nullptr;
-  int* flags = nullptr;
+  int* flags = nullptr;      // [kStreamKMaxGrid] epochs + [1] fallback counter
   int epoch = 0;
 };
 
+std::mutex g_sk_mu;
+std::map<std::pair<int, hipStream_t>, StreamKState> g_sk_pool;
+
 int streamk_for_stream(hipStream_t stream, StreamKState** out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, StreamKState> pool;
+  auto& pool = g_sk_pool;
   int dev = 0;
   EFG_HIP_TRY(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
+  std::lock_guard<std::mutex> lock(g_sk_mu);
   auto key = std::make_pair(dev, stream);
   auto it = pool.find(key);
   if (it == pool.end()) {
     StreamKState st;
     EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.scratch), (size_t)kStreamKMaxGrid * 2 * 4 * 256 * sizeof(float)));
-    EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.flags), (size_t)kStreamKMaxGrid * sizeof(int)));
-    EFG_HIP_TRY(hipMemset(st.flags, 0, (size_t)kStreamKMaxGrid * sizeof(int)));
+    EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.flags), (size_t)(kStreamKMaxGrid + 1) * sizeof(int)));
+    EFG_HIP_TRY(hipMemset(st.flags, 0, (size_t)(kStreamKMaxGrid + 1) * sizeof(int)));
     it = pool.emplace(key, st).first;
   }
   *out = &it->second;
@@ -878,13 +884,20 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.sk_epoch = 0;
   a.ux = a.uy = 0;
   a.sk_polls = sk_polls_env;
-  if (sk_env && nt == 4 && ks == 4 && !a.v4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
+  a.sk_fallbacks = nullptr;
+  // A launch that is being CAPTURED into a HIP graph must not use stream-K: the epoch is a kernel argument, every replay
+  // would carry the same value, find the flags already equal to it and sum stale shares without waiting; the first-use
+  // hipMalloc / hipMemset would invalidate the capture as well.  Captured launches take the plain (non-split) path.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream) (void)hipStreamIsCapturing(stream, &cap);
+  if (cap == hipStreamCaptureStatusNone && sk_env && nt == 4 && ks == 4 && !a.v4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
     StreamKState* st = nullptr;
     if (int rc = streamk_for_stream(stream, &st)) return rc;
     a.sk_prefix = r == 2 ? pv.pfx2 : pv.pfx1;
     a.sk_scratch = st->scratch;
     a.sk_flags = st->flags;
     a.sk_epoch = ++st->epoch;   // (under the caller's serialisation of the stream)
+    a.sk_fallbacks = st->flags + kStreamKMaxGrid;
   }
   if (r == 2) {
     switch (nt) {
@@ -939,6 +952,23 @@ extern "C" int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, 
                                             int flip_offsets, float* out_feat, void* stream) {
   return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets & 1, (flip_offsets >> 1) & 1,
                    (flip_offsets >> 2) & 1, (hipStream_t)stream);
+}
+
+extern "C" int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset) {
+  EFG_CHECK_ARG(count_out != nullptr, "streamk_fallbacks: null output");
+  int dev = 0;
+  EFG_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  int64_t total = 0;
+  for (auto& kv : g_sk_pool) {
+    if (kv.first.first != dev) continue;
+    int v = 0;
+    EFG_HIP_TRY(hipMemcpy(&v, kv.second.flags + kStreamKMaxGrid, sizeof(int), hipMemcpyDeviceToHost));  // (synchronises)
+    total += v;
+    if (reset && v) EFG_HIP_TRY(hipMemset(kv.second.flags + kStreamKMaxGrid, 0, sizeof(int)));
+  }
+  *count_out = total;
+  return EFG_OK;
 }
 
 extern "C" int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {

@@ -490,7 +490,8 @@ extern "C" size_t efg_spconv_wgrad_sched_bytes(int64_t m_out, int cin, int cout,
 extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, int cout, int kvol, void* sched,
                                       size_t sched_bytes_given, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EFG_CHECK_ARG(m_out >= 0 && m_out < (1ll << 31) && wgt_ok(cin, cout, kvol), "wgrad_sched: bad sizes (m=%lld, %d -> %d, kvol=%d)",
+  // (the schedule kernel multiplies tile counts in 32 bits: fewer than 2^21 16-row tiles)
+  EFG_CHECK_ARG(m_out >= 0 && m_out < (1ll << 25) && wgt_ok(cin, cout, kvol), "wgrad_sched: bad sizes (m=%lld, %d -> %d, kvol=%d)",
                 (long long)m_out, cin, cout, kvol);
   if (m_out == 0) return EFG_OK;
   const int slots = wgt_layout(m_out, cin, cout, kvol).slots;

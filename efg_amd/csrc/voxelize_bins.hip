@@ -1,0 +1,974 @@
+// Hard voxelization, generation 2: points binned into BEV supercells, per-bin cell tables in LDS.
+//
+// Replaces efg::hard_voxelize (efg/operators/src/voxelize/voxelization.h:51-69; CPU semantics
+// voxelization_cpu.cpp:43-99: voxels in first-occurrence order, at most max_points points per voxel in point order,
+// processing stops at the first point that would open voxel number max_voxels).  Bit-exact.
+//
+// The cloud is shuffled (PointShuffle p=1.0), so any per-cell state kept in HBM costs a random device-scope access per
+// point and visit (generation 1, voxelize_hash.hip: 8.7x the algorithmic bytes).  Here the only random HBM accesses
+// are ONE 8-byte + ONE 32-byte scattered store per point (the binning); every per-cell decision is taken in LDS:
+//
+//   K1 bin_count   a workgroup stages a 1024-point tile in LDS with 16-byte coalesced loads, computes each point's
+//                  supercell (8 x 8 x <=40 cells), aggregates the tile's points per supercell in an LDS hash table and
+//                  reserves their places with ONE returning atomic per (tile, supercell) -- on a counter PRIVATE TO
+//                  THE XCD the workgroup runs on (count[supercell][xcd]), so the atomic is executed in that XCD's L2.
+//                  (A device-scope atomic is executed past the L2s, at the memory side: the ~90k group atomics of a
+//                  2 x 180k-point call took 35 us of a 44 us kernel, `scripts/vox_timeline.py`.)
+//   K2 bin_scan    exclusive scan over the count[supercell][xcd] array (8192 counters per workgroup, chunk totals
+//                  chained by decoupled look-back): the place of every (supercell, xcd) group -- a supercell's eight
+//                  groups are adjacent, so a bin is one contiguous range -- plus the two work lists of K4 / K5
+//                  (bins of <= 256 points, bins above).
+//   K3 bin_scatter writes {point index, cell inside the supercell} and the padded row of every point to its place.
+//   K4 first       per bin: first occurrence of every cell = minimum point index (ds_min in LDS; a wave per bin with
+//                  an LDS hash table for bins of <= 256 points, a workgroup with the dense 2560-cell table above);
+//                  the winners set their bit in a per-scene bitmap over the points.  The last workgroup of a scene
+//                  scans the bitmap: prefix[word] = number of first points before it = the voxel ids of the serial
+//                  loop; rank == max_voxels marks i_break (the reference's `break`).
+//   K5 write       per bin again: points before i_break are counting-sorted by cell in LDS (count, scan, scatter), the
+//                  occupied cells are compacted into a voxel list, then one thread per voxel takes the max_points
+//                  lowest point indices in order, looks its voxel id up in the bitmap prefix (rank of its first point)
+//                  and writes rows, zero padding, coordinates, count and the fused mean.
+// 5 kernels + 1 memset (counters, chunk totals, tickets) per call.  All scenes of a batch go through one launch per
+// stage (blockIdx.y = scene).  K4 / K5 run a fixed grid whose workgroups loop over the work lists (a launch sized for
+// the worst case -- 19k workgroups, 5 % of them with work -- spent 20 us on dispatching the empty ones).
+#include "voxelize_common.h"
+
+namespace efg {
+namespace {
+
+constexpr int kTile = 1024;            // points per workgroup in K1 / K3 (256 threads x 4)
+constexpr int kSB = 3;                 // supercell = 8 x 8 x min(grid_z, 40) cells (one BEV token column of the
+constexpr int kSXY = 1 << kSB;         // res18 backbone's stride-8 map): the synthetic Waymo scenes put 80 % of their
+constexpr int kSZ = 40;                // points into ~5 % of the columns, smaller bins = more workgroups on them
+constexpr int kCells = kSXY * kSXY * kSZ;  // 2560 cells: the dense table of a big bin = 10 KB of LDS
+constexpr int kSegLds = 1024;          // a big bin's cell-sorted point list lives in LDS up to this many points
+constexpr int kSmall = 256;            // bins up to this many points are handled by one wave
+constexpr int kSmallT = 512;           // hash slots of a wave's bin
+constexpr int kAggSlots = 2048;        // LDS hash slots of the per-tile aggregation in K1
+constexpr int kXcd = 8;                // XCDs of an MI355X: one private counter per supercell and XCD
+constexpr int kScanChunk = 8192;       // counters per workgroup of K2 (256 threads x 32 = 4 supercells per thread)
+constexpr int kItemGrid = 1024;        // workgroups of K4 / K5 over all scenes (each loops over the bins)
+constexpr unsigned kNone = 0xffffffffu;
+
+// Optional per-workgroup timeline (efg_hard_voxelize_debug_timeline): thread 0 of every workgroup stores the 100 MHz
+// wall clock at up to 8 markers per kernel.  nullptr in normal operation (one predictable branch per marker).
+constexpr int kDbgMaxWg = 1 << 15;
+__device__ __forceinline__ void mark(unsigned long long* dbg, int kernel, int marker) {
+  if (dbg != nullptr && threadIdx.x == 0) {
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < (unsigned)kDbgMaxWg) dbg[(size_t)(kernel * 8 + marker) * kDbgMaxWg + wg] = wall_clock64();
+  }
+}
+unsigned long long* g_dbg = nullptr;
+
+struct BinGeom {
+  int sz, nsx, nsy, nsz, s_scene, cells;
+  int s_stride;  // s_scene rounded up to 4 supercells: a scene's counters are whole 32-counter thread chunks of K2
+};
+
+struct SceneWords {
+  int wb[kMaxBatch + 1];  // first bitmap word of every scene
+};
+
+BinGeom bin_geom(const VoxGeom& g) {
+  BinGeom b;
+  b.sz = std::min(g.grid[2], kSZ);
+  b.nsx = (g.grid[0] + kSXY - 1) / kSXY;
+  b.nsy = (g.grid[1] + kSXY - 1) / kSXY;
+  b.nsz = (g.grid[2] + b.sz - 1) / b.sz;
+  const long long s = (long long)b.nsx * b.nsy * b.nsz;
+  b.s_scene = s < (1ll << 26) ? (int)s : -1;
+  b.cells = kSXY * kSXY * b.sz;
+  b.s_stride = b.s_scene < 0 ? -1 : (b.s_scene + 3) / 4 * 4;
+  return b;
+}
+
+__device__ __forceinline__ void bin_of(int cx, int cy, int cz, const BinGeom& bg, unsigned& sc, unsigned& lc) {
+  const int bz = cz / bg.sz;
+  sc = (unsigned)((bz * bg.nsy + (cy >> kSB)) * bg.nsx + (cx >> kSB));
+  lc = (unsigned)((((cz - bz * bg.sz) << kSB) + (cy & (kSXY - 1))) << kSB) + (cx & (kSXY - 1));
+}
+
+// the XCD this wave runs on (hardware register XCC_ID, bits 3:0)
+__device__ __forceinline__ unsigned xcd_id() {
+  // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4): immediate = (size - 1) << 11 | offset << 6 | id
+  return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (kXcd - 1);
+}
+
+// Copy rows [row0, row0 + nrows) of the [total_rows, f] matrix into LDS as one flat float stream with 16-byte loads
+// (a 20 / 24-byte row read by its own lane costs three strided 4-byte loads per row).  Returns the LDS float index
+// of row 0's first element.
+__device__ __forceinline__ int stage_rows(const float* __restrict__ pts, long long row0, int nrows, int f,
+                                          long long total_rows, float* lds) {
+  const long long s = row0 * f, e = s + (long long)nrows * f, s4 = s & ~3ll, lim = total_rows * f;
+  const bool aligned = (reinterpret_cast<uintptr_t>(pts) & 15) == 0;
+  for (long long k = s4 + threadIdx.x * 4; k < e; k += 256 * 4) {
+    float4 v;
+    if (aligned && k + 3 < lim) {
+      v = *reinterpret_cast<const float4*>(pts + k);
+    } else {
+      v.x = k < lim ? pts[k] : 0.0f;
+      v.y = k + 1 < lim ? pts[k + 1] : 0.0f;
+      v.z = k + 2 < lim ? pts[k + 2] : 0.0f;
+      v.w = k + 3 < lim ? pts[k + 3] : 0.0f;
+    }
+    *reinterpret_cast<float4*>(lds + (k - s4)) = v;
+  }
+  return (int)(s - s4);
+}
+
+// K1 ------------------------------------------------------------------------------------------------------------
+// pos[i] = xcd << 28 | place of point i inside its (supercell, xcd) group; kNone for points outside the range.
+template <bool STAGE>
+__global__ void __launch_bounds__(256)
+vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords sw, int f, VoxGeom g, BinGeom bg,
+                     unsigned* __restrict__ count, unsigned* __restrict__ pos, unsigned* __restrict__ bits,
+                     unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGE ? kTile * 8 + 8 : 4];
+  __shared__ unsigned hkey[kAggSlots], hcnt[kAggSlots];
+  mark(dbg, 0, 0);
+  const int scene = blockIdx.y, tid = threadIdx.x;
+  const long long beg = so.off[scene], end = so.off[scene + 1];
+  const long long row0 = beg + (long long)blockIdx.x * kTile;
+  const int nrows = (int)max(0ll, min((long long)kTile, end - row0));
+  const unsigned xcd = xcd_id();
+  unsigned* cnt_x = count + (size_t)scene * bg.s_stride * kXcd + xcd;  // [supercell][xcd]
+  if (tid < kTile / 32) {  // this tile's words of the first-point bitmap start empty
+    const int w = sw.wb[scene] + blockIdx.x * (kTile / 32) + tid;
+    if (w < sw.wb[scene + 1]) bits[w] = 0u;
+  }
+  if (nrows == 0) return;
+  int shift = 0;
+  if (STAGE) shift = stage_rows(pts, row0, nrows, f, so.off[kMaxBatch], stage);
+  for (int s = tid; s < kAggSlots; s += 256) {
+    hkey[s] = kNone;
+    hcnt[s] = 0u;
+  }
+  __syncthreads();
+  mark(dbg, 0, 1);   // tile staged
+  unsigned slot[4], rank[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = tid + 256 * j;
+    slot[j] = kNone;
+    rank[j] = 0u;
+    if (p < nrows) {
+      const float* r = STAGE ? stage + shift + p * f : pts + (row0 + p) * f;
+      int cx, cy, cz;
+      if (cell_of(r[0], r[1], r[2], g, cx, cy, cz)) {
+        unsigned sc, lc;
+        bin_of(cx, cy, cz, bg, sc, lc);
+        unsigned h = (sc * 2654435761u) >> 21;
+        while (true) {
+          const unsigned k = atomicCAS(&hkey[h], kNone, sc);
+          if (k == kNone || k == sc) break;
+          h = (h + 1) & (kAggSlots - 1);
+        }
+        rank[j] = atomicAdd(&hcnt[h], 1u);
+        slot[j] = h;
+      }
+    }
+  }
+  __syncthreads();
+  mark(dbg, 0, 2);   // LDS aggregation done
+  {  // group size -> first place of the group inside its (supercell, xcd) range.  The counter belongs to this XCD alone, so
+     // the read-modify-write may stay in this XCD's L2 (workgroup scope: no sc1, not forwarded to the memory side); the
+     // L2 is written back at the end of the kernel like any other store.  All of a thread's atomics are in flight
+     // together.
+    unsigned r[kAggSlots / 256];
+#pragma unroll
+    for (int i = 0; i < kAggSlots / 256; ++i) {
+      const int sl = tid + 256 * i;
+      r[i] = hkey[sl] != kNone ? __hip_atomic_fetch_add(cnt_x + (size_t)hkey[sl] * kXcd, hcnt[sl], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP)
+                               : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kAggSlots / 256; ++i) hcnt[tid + 256 * i] = r[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = tid + 256 * j;
+    if (p < nrows) pos[row0 + p] = slot[j] == kNone ? kNone : (xcd << 28) | (hcnt[slot[j]] + rank[j]);
+  }
+  mark(dbg, 0, 3);   // group atomics returned, places written
+}
+
+// K2 ------------------------------------------------------------------------------------------------------------
+// part[chunk] = 1 << 63 | chunk's points << 30 | big bins << 15 | small bins; 0 = not published yet.
+__global__ void __launch_bounds__(256)
+vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ count, unsigned long long* __restrict__ part,
+                    int nchunks, unsigned* __restrict__ basex, uint4* __restrict__ small_list,
+                    uint4* __restrict__ big_list, unsigned* __restrict__ nlist,
+                    unsigned long long* dbg) {
+  __shared__ int smem[17];
+  __shared__ unsigned long long s_w[4];
+  mark(dbg, 1, 0);
+  const int scene = blockIdx.y, tid = threadIdx.x, chunk = blockIdx.x;
+  const size_t xbase = (size_t)scene * bg.s_stride * kXcd;
+  const int e0 = chunk * kScanChunk + tid * 32;          // first counter of this thread: supercells e0 / 8 .. + 3
+  const int ne = bg.s_stride * kXcd;
+  uint4 v[8];
+  int sum = 0, ns = 0, nb = 0;
+  unsigned tot[4];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    v[q] = e0 + q * 4 < ne ? *reinterpret_cast<const uint4*>(count + xbase + e0 + q * 4) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    tot[b] = v[2 * b].x + v[2 * b].y + v[2 * b].z + v[2 * b].w + v[2 * b + 1].x + v[2 * b + 1].y + v[2 * b + 1].z +
+             v[2 * b + 1].w;
+    sum += (int)tot[b];
+    ns += (tot[b] > 0u && tot[b] <= (unsigned)kSmall) ? 1 : 0;
+    nb += (tot[b] > (unsigned)kSmall) ? 1 : 0;
+  }
+  int csum, clist;
+  const int psum = block_exclusive_scan(sum, smem, &csum);
+  const int plist = block_exclusive_scan(ns | (nb << 15), smem, &clist);   // <= 1024 supercells per chunk: 15 bits each
+  unsigned long long* part_s = part + (size_t)scene * nchunks;
+  if (tid == 0)  // publish this chunk's totals at once; nothing has been waited for
+    __hip_atomic_store(part_s + chunk, (1ull << 63) | ((unsigned long long)(unsigned)csum << 30) | (unsigned)clist,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mark(dbg, 1, 1);   // chunk reduced + published
+  // Decoupled look-back: the totals of the chunks before this one.  A workgroup only waits for workgroups with a LOWER
+  // index, which are dispatched before it and publish without waiting for anybody -- the wait always ends.  (Bounded
+  // all the same: a broken invariant should fail a test, not hang the device.)  The three fields are summed separately:
+  // a scene may hold more than 2^15 small bins.
+  unsigned long long a_pts = 0;
+  unsigned a_s = 0, a_b = 0;
+  for (int c = tid; c < chunk; c += 256) {
+    unsigned long long x = 0;
+    for (int polls = 0; polls < (1 << 22); ++polls) {
+      x = __hip_atomic_load(part_s + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (x) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    a_pts += (x >> 30) & 0x1ffffffffull;
+    a_s += (unsigned)x & 0x7fffu;
+    a_b += ((unsigned)x >> 15) & 0x7fffu;
+  }
+  unsigned long long acc = (a_pts << 32) | 0;   // points in the high word; the lists in a second 64-bit sum
+  unsigned long long acl = ((unsigned long long)a_b << 32) | a_s;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    acc += __shfl_xor(acc, d, 64);
+    acl += __shfl_xor(acl, d, 64);
+  }
+  __shared__ unsigned long long s_l[4];
+  if ((tid & 63) == 0) {
+    s_w[tid >> 6] = acc;
+    s_l[tid >> 6] = acl;
+  }
+  __syncthreads();
+  const unsigned long long pre = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  const unsigned long long prl = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+  mark(dbg, 1, 2);   // look-back done
+  unsigned run = (unsigned)so.off[scene] + (unsigned)(pre >> 32) + (unsigned)psum;
+  int ps = (int)(unsigned)prl + (plist & 0x7fff);
+  int pb = (int)(unsigned)(prl >> 32) + (plist >> 15);
+  uint4* small_s = small_list + (size_t)scene * bg.s_stride;
+  uint4* big_s = big_list + (size_t)scene * bg.s_stride;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int sc = e0 / kXcd + b;
+    if (sc < bg.s_scene) {
+      // one 16-byte record per bin {supercell, first place, points}: K4 / K5 read everything they need in ONE load
+      if (tot[b] > (unsigned)kSmall)
+        big_s[pb++] = make_uint4((unsigned)sc, run, tot[b], 0u);
+      else if (tot[b] > 0u)
+        small_s[ps++] = make_uint4((unsigned)sc, run, tot[b], 0u);
+    }
+    uint4 o0, o1;
+    o0.x = run;
+    o0.y = o0.x + v[2 * b].x;
+    o0.z = o0.y + v[2 * b].y;
+    o0.w = o0.z + v[2 * b].z;
+    o1.x = o0.w + v[2 * b].w;
+    o1.y = o1.x + v[2 * b + 1].x;
+    o1.z = o1.y + v[2 * b + 1].y;
+    o1.w = o1.z + v[2 * b + 1].z;
+    run = o1.w + v[2 * b + 1].w;
+    if (e0 + b * 8 < ne) {
+      *reinterpret_cast<uint4*>(basex + xbase + e0 + b * 8) = o0;
+      *reinterpret_cast<uint4*>(basex + xbase + e0 + b * 8 + 4) = o1;
+    }
+  }
+  if (chunk == nchunks - 1 && tid == 255) {  // (the last thread's running list positions are the scene's totals)
+    nlist[scene * 2] = (unsigned)ps;
+    nlist[scene * 2 + 1] = (unsigned)pb;
+  }
+  mark(dbg, 1, 3);
+}
+
+// K3 ------------------------------------------------------------------------------------------------------------
+template <bool STAGE>
+__global__ void __launch_bounds__(256)
+vox_bin_scatter_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom g, BinGeom bg,
+                       const unsigned* __restrict__ pos, const unsigned* __restrict__ basex, uint2* __restrict__ meta,
+                       float* __restrict__ rows, int rs, unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) float stage[STAGE ? kTile * 8 + 8 : 4];
+  const int scene = blockIdx.y, tid = threadIdx.x;
+  mark(dbg, 2, 0);
+  const long long beg = so.off[scene], end = so.off[scene + 1];
+  const long long row0 = beg + (long long)blockIdx.x * kTile;
+  const int nrows = (int)max(0ll, min((long long)kTile, end - row0));
+  if (nrows == 0) return;
+  int shift = 0;
+  if (STAGE) {
+    shift = stage_rows(pts, row0, nrows, f, so.off[kMaxBatch], stage);
+    __syncthreads();
+  }
+  const unsigned* basex_s = basex + (size_t)scene * bg.s_stride * kXcd;
+  unsigned pv[4], lcs[4];
+  size_t dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {   // all four look-ups in flight before the first store
+    const int p = tid + 256 * j;
+    pv[j] = p < nrows ? pos[row0 + p] : kNone;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dst[j] = 0;
+    lcs[j] = 0;
+    if (pv[j] != kNone) {
+      const int p = tid + 256 * j;
+      const float* r = STAGE ? stage + shift + p * f : pts + (row0 + p) * f;
+      int cx, cy, cz;
+      cell_of(r[0], r[1], r[2], g, cx, cy, cz);  // same arithmetic as K1: same bin
+      unsigned sc;
+      bin_of(cx, cy, cz, bg, sc, lcs[j]);
+      dst[j] = (size_t)basex_s[(size_t)sc * kXcd + (pv[j] >> 28)] + (pv[j] & 0x0fffffffu);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (pv[j] == kNone) continue;
+    const int p = tid + 256 * j;
+    const float* r = STAGE ? stage + shift + p * f : pts + (row0 + p) * f;
+    meta[dst[j]] = make_uint2((unsigned)(row0 + p), lcs[j]);
+    float* o = rows + dst[j] * rs;
+    for (int k = 0; k < rs; k += 4) {
+      float4 v;
+      v.x = r[k];  // k < f always (rs = f rounded up to 4)
+      v.y = k + 1 < f ? r[k + 1] : 0.0f;
+      v.z = k + 2 < f ? r[k + 2] : 0.0f;
+      v.w = k + 3 < f ? r[k + 3] : 0.0f;
+      *reinterpret_cast<float4*>(o + k) = v;
+    }
+  }
+  mark(dbg, 2, 1);
+}
+
+// claim / find the slot of `key` in an LDS open-addressing table of t slots (power of two)
+__device__ __forceinline__ unsigned lds_slot(unsigned* keys, unsigned t, unsigned key) {
+  unsigned h = (key * 2654435761u) >> 16 & (t - 1);
+  while (true) {
+    const unsigned k = atomicCAS(&keys[h], kNone, key);
+    if (k == kNone || k == key) return h;
+    h = (h + 1) & (t - 1);
+  }
+}
+
+__device__ __forceinline__ unsigned small_table_size(unsigned p) {
+  unsigned t = 64;
+  while (t < 2 * p) t <<= 1;
+  return t;  // <= kSmallT for p <= kSmall
+}
+
+// K4 ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vox_first_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, const uint4* __restrict__ small_list,
+                 const uint4* __restrict__ big_list, const unsigned* __restrict__ nlist,
+                 const uint2* __restrict__ meta, unsigned* __restrict__ bits, unsigned* __restrict__ prefix,
+                 unsigned* __restrict__ ticket, int* __restrict__ voxel_num, unsigned* __restrict__ i_break,
+                 int max_voxels, unsigned long long* dbg) {
+  __shared__ unsigned tab[kCells > 8 * kSmallT ? kCells : 8 * kSmallT];
+  __shared__ int smem[17];
+  __shared__ unsigned s_last;
+  mark(dbg, 3, 0);
+  const int scene = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned beg = (unsigned)so.off[scene];
+  const unsigned nsmall = nlist[scene * 2], nbig = nlist[scene * 2 + 1];
+  const size_t sbase = (size_t)scene * bg.s_stride;
+  unsigned* bits_s = bits + sw.wb[scene];
+  // items: [0, nbig) the big bins, then groups of four small bins (one per wave)
+  const unsigned items = nbig + (nsmall + 3) / 4;
+  // Only workgroups that own a bin take a ticket: the ticket is ONE address, a device-scope atomic on it costs ~15 ns
+  // of serialised time.
+  const unsigned takers = min(items, gridDim.x);
+  if (blockIdx.x >= takers && !(items == 0 && blockIdx.x == 0)) return;   // (empty scene: workgroup 0 writes the zeros)
+  unsigned sink = 0u;  // the returned values of the bit atomics: keeps them RETURNING, i.e. complete before the ticket
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    if (item < nbig) {
+      const uint4 rec = big_list[sbase + item];
+      const unsigned p = rec.z, b = rec.y;
+      for (int c = tid; c < bg.cells; c += 256) tab[c] = kNone;
+      __syncthreads();
+      // (four loads in flight per thread: one at a time the loop is a chain of L2 round trips, P / 256 of them)
+      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+        uint2 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m[j].x != kNone) atomicMin(&tab[m[j].y], m[j].x);
+      }
+      __syncthreads();
+      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+        uint2 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+        unsigned old[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          old[j] = 0u;
+          if (m[j].x != kNone && tab[m[j].y] == m[j].x) {
+            const unsigned jj = m[j].x - beg;
+            old[j] = atomicOr(&bits_s[jj >> 5], 1u << (jj & 31));
+          }
+        }
+        sink |= old[0] | old[1] | old[2] | old[3];
+      }
+      __syncthreads();
+    } else {
+      const unsigned bin = (item - nbig) * 4 + wave;
+      unsigned* key = tab + wave * (2 * kSmallT);
+      unsigned* val = key + kSmallT;
+      unsigned p = 0, b = 0;
+      if (bin < nsmall) {
+        const uint4 rec = small_list[sbase + bin];
+        p = rec.z;
+        b = rec.y;
+      }
+      const unsigned t = small_table_size(p);
+      for (unsigned s = lane; s < t; s += 64) {
+        key[s] = kNone;
+        val[s] = kNone;
+      }
+      __syncthreads();
+      uint2 m[4];
+      unsigned sl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = lane + 64 * j < p ? meta[b + lane + 64 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sl[j] = 0;
+        if (m[j].x != kNone) {
+          sl[j] = lds_slot(key, t, m[j].y);
+          atomicMin(&val[sl[j]], m[j].x);
+        }
+      }
+      __syncthreads();
+      unsigned old[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        old[j] = 0u;
+        if (m[j].x != kNone && val[sl[j]] == m[j].x) {
+          const unsigned jj = m[j].x - beg;
+          old[j] = atomicOr(&bits_s[jj >> 5], 1u << (jj & 31));
+        }
+      }
+      sink |= old[0] | old[1] | old[2] | old[3];
+      __syncthreads();
+    }
+  }
+  asm volatile("" ::"v"(sink));  // the wave has waited for every returned value here
+  __syncthreads();
+  mark(dbg, 3, 1);   // bin work done
+  if (tid == 0) s_last = (items == 0 || atomicAdd(&ticket[scene], 1u) == takers - 1) ? 1u : 0u;
+  __syncthreads();
+  mark(dbg, 3, 2);   // ticket
+  if (!s_last) return;
+  // ---- last workgroup of the scene: prefix[w] = first points before word w; voxel count; i_break ----
+  // The bits were set by device-scope atomics of other XCDs: one acquire, then plain 16-byte loads, 4096 words per
+  // round held in registers (an agent-scope atomic load per word is a ~1 us round trip each and they do not pipeline).
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int nw = sw.wb[scene + 1] - sw.wb[scene];
+  unsigned* prefix_s = prefix + sw.wb[scene];
+  int run0 = 0;
+  constexpr int kQ = 4;   // 16 words = 512 points per thread and round (kQ = 8 costs the kernel two waves per SIMD)
+  for (int r0 = 0; r0 < nw; r0 += 256 * 4 * kQ) {
+    const int w0 = r0 + tid * 4 * kQ;
+    uint4 v[kQ];
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      const int w = w0 + q * 4;
+      v[q] = w < nw ? *reinterpret_cast<const uint4*>(bits_s + w) : make_uint4(0, 0, 0, 0);
+      unsigned* e = reinterpret_cast<unsigned*>(&v[q]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (w + k >= nw) e[k] = 0u;   // (alignment padding of the scene's words)
+        sum += __popc(e[k]);
+      }
+    }
+    int tot;
+    int run = run0 + block_exclusive_scan(sum, smem, &tot);
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      const int w = w0 + q * 4;
+      const unsigned* e = reinterpret_cast<const unsigned*>(&v[q]);
+      uint4 o;
+      unsigned* oe = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = __popc(e[k]);
+        oe[k] = (unsigned)run;
+        if (run <= max_voxels && max_voxels < run + c) {  // the first point of voxel number max_voxels: the `break`
+          unsigned y = e[k];
+          for (int i = run; i < max_voxels; ++i) y &= y - 1;
+          i_break[scene] = beg + (unsigned)(w + k) * 32u + (unsigned)__ffs(y) - 1u;
+        }
+        run += c;
+      }
+      if (w < nw) *reinterpret_cast<uint4*>(prefix_s + w) = o;
+    }
+    run0 += tot;
+  }
+  if (tid == 0) {
+    voxel_num[scene] = min(run0, max_voxels);
+    if (run0 <= max_voxels) i_break[scene] = kNone;
+  }
+  mark(dbg, 3, 3);   // tail of the last workgroup
+}
+
+// One voxel: the cell's points are seg_idx[start .. start + n) (point indices) / seg_e (their places in the bin).
+struct WriteArgs {
+  const float* rows;
+  const unsigned* bits_s;
+  const unsigned* prefix_s;
+  float* voxels;
+  int* coors;
+  int* npv;
+  float* mean;
+  int f, rs, max_points, coors_cols, out_base, scene;
+  unsigned beg;
+};
+
+__device__ __forceinline__ void voxel_coords(const WriteArgs& a, const BinGeom& bg, unsigned sc, unsigned lc, long long vid,
+                                             int kept) {
+  const int bx = sc % bg.nsx, by = (sc / bg.nsx) % bg.nsy, bz = sc / (bg.nsx * bg.nsy);
+  int* c = a.coors + vid * a.coors_cols;
+  if (a.coors_cols == 4) *c++ = a.scene;
+  c[0] = bz * bg.sz + (int)(lc >> (2 * kSB));
+  c[1] = by * kSXY + (int)((lc >> kSB) & (kSXY - 1));
+  c[2] = bx * kSXY + (int)(lc & (kSXY - 1));
+  a.npv[vid] = kept;
+}
+
+// FAST (KMAX = 5 or 8 >= max_points, f <= 8: every configuration of the reference's playground): the max_points lowest point
+// indices of the cell by streaming insertion into a sorted register array -- one pass over the segment -- then ALL
+// global loads of the voxel (bitmap word, prefix word, up to eight 32-byte rows; rows past `kept` re-read row 0) issued
+// together and branch-free, so the voxel costs ONE memory round trip before its stores (loads inside `if (k < kept)`
+// were waited for one row at a time: five round trips per voxel).  The mean comes from registers.
+// Generic: selection by repeated minimum (O(n * kept) dependent loads), rows and mean through memory.
+template <int KMAX>   // 0: generic path; 5 / 8: FAST with max_points <= KMAX
+__device__ __forceinline__ void emit_voxel(const WriteArgs& a, const BinGeom& bg, unsigned sc, unsigned lc,
+                                           unsigned bin_base, const unsigned* seg_idx, const unsigned* seg_e,
+                                           unsigned start, unsigned n) {
+  const int kept = (int)min(n, (unsigned)a.max_points);
+  if constexpr (KMAX > 0) {
+    unsigned bi[KMAX], be[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+      bi[s] = kNone;
+      be[s] = 0u;
+    }
+#pragma unroll 4
+    for (unsigned j = start; j < start + n; ++j) {
+      unsigned v = seg_idx[j], e = seg_e[j];
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) {
+        const bool lt = v < bi[s];
+        const unsigned tv = lt ? bi[s] : v, te = lt ? be[s] : e;
+        bi[s] = lt ? v : bi[s];
+        be[s] = lt ? e : be[s];
+        v = tv;
+        e = te;
+      }
+    }
+    const unsigned jf = bi[0] - a.beg;
+    const unsigned pw = a.prefix_s[jf >> 5], bw = a.bits_s[jf >> 5];
+    float4 r0[KMAX], r1[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float4* r = reinterpret_cast<const float4*>(a.rows + ((size_t)bin_base + be[k < kept ? k : 0]) * a.rs);
+      r0[k] = r[0];
+      r1[k] = a.rs > 4 ? r[1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // voxel id = number of first points of the scene before this voxel's first point
+    const long long vid = a.out_base + (long long)(pw + __popc(bw & ((1u << (jf & 31)) - 1u)));
+    voxel_coords(a, bg, sc, lc, vid, kept);
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.0f;
+    float* o = a.voxels + vid * a.max_points * a.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < kept) {
+#define EFG_VOX_PUT(t, val)                  \
+  if (t < a.f) {                             \
+    o[k * a.f + t] = val;                    \
+    acc[t] = __fadd_rn(acc[t], val); /* slot order, like the reader's sum(dim=1) */ \
+  }
+        EFG_VOX_PUT(0, r0[k].x)
+        EFG_VOX_PUT(1, r0[k].y)
+        EFG_VOX_PUT(2, r0[k].z)
+        EFG_VOX_PUT(3, r0[k].w)
+        EFG_VOX_PUT(4, r1[k].x)
+        EFG_VOX_PUT(5, r1[k].y)
+        EFG_VOX_PUT(6, r1[k].z)
+        EFG_VOX_PUT(7, r1[k].w)
+#undef EFG_VOX_PUT
+      }
+    }
+    for (int k = kept * a.f; k < a.max_points * a.f; ++k) o[k] = 0.0f;
+    if (a.mean) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < a.f) a.mean[vid * a.f + t] = __fdiv_rn(acc[t], (float)kept);
+    }
+  } else {
+    long long vid = 0;
+    unsigned prev = 0;
+    for (int k = 0; k < kept; ++k) {
+      unsigned best = kNone, be = 0;
+      for (unsigned j = start; j < start + n; ++j) {
+        const unsigned v = seg_idx[j];
+        if ((k == 0 || v > prev) && v < best) {
+          best = v;
+          be = seg_e[j];
+        }
+      }
+      prev = best;
+      if (k == 0) {
+        const unsigned jf = best - a.beg;
+        vid = a.out_base + (long long)(a.prefix_s[jf >> 5] + __popc(a.bits_s[jf >> 5] & ((1u << (jf & 31)) - 1u)));
+        voxel_coords(a, bg, sc, lc, vid, kept);
+      }
+      const float* r = a.rows + ((size_t)bin_base + be) * a.rs;
+      float* o = a.voxels + (vid * a.max_points + k) * a.f;
+      for (int t = 0; t < a.f; ++t) o[t] = r[t];
+    }
+    float* o = a.voxels + vid * a.max_points * a.f;
+    for (int k = kept * a.f; k < a.max_points * a.f; ++k) o[k] = 0.0f;
+    if (a.mean) {
+      for (int t = 0; t < a.f; ++t) {
+        float sm = 0.0f;
+        for (int k = 0; k < kept; ++k) sm = __fadd_rn(sm, o[k * a.f + t]);
+        a.mean[vid * a.f + t] = __fdiv_rn(sm, (float)kept);
+      }
+    }
+  }
+}
+
+// K5 ------------------------------------------------------------------------------------------------------------
+// LDS: a big bin uses [cell table | point list | voxel list], four small bins use 4 x [keys | offsets | point list | voxel list]
+constexpr int kSmallLds = 2 * kSmallT + 2 * kSmall + kSmallT;   // words per wave
+constexpr int kBigLds = 2 * kCells + 2 * kSegLds;
+constexpr int kWriteLds = kBigLds > 4 * kSmallLds ? kBigLds : 4 * kSmallLds;
+
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, const uint4* __restrict__ small_list,
+                 const uint4* __restrict__ big_list, const unsigned* __restrict__ nlist,
+                 const uint2* __restrict__ meta, const float* __restrict__ rows, const unsigned* __restrict__ bits,
+                 const unsigned* __restrict__ prefix, const unsigned* __restrict__ i_break,
+                 const int* __restrict__ voxel_num, int max_points, int coors_cols, float* __restrict__ voxels,
+                 int* __restrict__ coors, int* __restrict__ npv, float* __restrict__ mean,
+                 unsigned* __restrict__ seg_idx_g, unsigned* __restrict__ seg_e_g, unsigned long long* dbg) {
+  __shared__ unsigned tab[kWriteLds];
+  __shared__ int smem[17];
+  mark(dbg, 4, 0);
+  const int scene = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned nsmall = nlist[scene * 2], nbig = nlist[scene * 2 + 1];
+  const size_t sbase = (size_t)scene * bg.s_stride;
+  const unsigned items = nbig + (nsmall + 3) / 4;
+  if (blockIdx.x >= items) return;
+  WriteArgs a;
+  a.rows = rows;
+  a.bits_s = bits + sw.wb[scene];
+  a.prefix_s = prefix + sw.wb[scene];
+  a.voxels = voxels;
+  a.coors = coors;
+  a.npv = npv;
+  a.mean = mean;
+  a.f = f;
+  a.rs = rs;
+  a.max_points = max_points;
+  a.coors_cols = coors_cols;
+  a.scene = scene;
+  a.beg = (unsigned)so.off[scene];
+  a.out_base = 0;
+  for (int b = 0; b < scene; ++b) a.out_base += voxel_num[b];
+  const unsigned ib = i_break[scene];  // points from here on are never processed (voxelization_cpu.cpp:78-79)
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    if (item < nbig) {
+      unsigned* seg_lds = tab + kCells;
+      unsigned* vlist = tab + kCells + 2 * kSegLds;   // occupied cells, compacted
+      const uint4 rec = big_list[sbase + item];
+      const unsigned sc = rec.x, p = rec.z, b = rec.y;
+      for (int c = tid; c < bg.cells; c += 256) tab[c] = 0u;
+      __syncthreads();
+      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+        uint2 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m[j].x < ib) atomicAdd(&tab[m[j].y], 1u);   // (kNone >= ib always)
+      }
+      __syncthreads();
+      int nvox;
+      {  // exclusive scan over the cells in place (thread t owns cells [t * per, (t + 1) * per)) and, in the same pass,
+         // the list of occupied cells in cell order
+        const int per = (bg.cells + 255) / 256, c0 = min(tid * per, bg.cells), c1 = min(c0 + per, bg.cells);
+        int sum = 0, occ = 0;
+        for (int c = c0; c < c1; ++c) {
+          sum += (int)tab[c];
+          occ += tab[c] ? 1 : 0;
+        }
+        int tot;
+        int run = block_exclusive_scan(sum, smem, &tot);
+        int vpos = block_exclusive_scan(occ, smem, &nvox);
+        for (int c = c0; c < c1; ++c) {
+          const int v = (int)tab[c];
+          tab[c] = (unsigned)run;
+          run += v;
+          if (v) vlist[vpos++] = (unsigned)c;
+        }
+      }
+      __syncthreads();
+      // the bin's points sorted by cell: in LDS when they fit, else in the bin's own range of a global scratch
+      const bool in_lds = p <= (unsigned)kSegLds;
+      unsigned* si = in_lds ? seg_lds : seg_idx_g + b;
+      unsigned* se = in_lds ? seg_lds + kSegLds : seg_e_g + b;
+      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+        uint2 m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (m[j].x < ib) {
+            const unsigned q = atomicAdd(&tab[m[j].y], 1u);  // afterwards tab[c] = END of cell c = start of cell c + 1
+            si[q] = m[j].x;
+            se[q] = e0 + 256 * j;
+          }
+        }
+      }
+      __syncthreads();
+      mark(dbg, 4, 1);   // sorted by cell
+      for (int v = tid; v < nvox; v += 256) {
+        const unsigned c = vlist[v];
+        const unsigned en = tab[c], st = c ? tab[c - 1] : 0u;
+        emit_voxel<KMAX>(a, bg, sc, c, b, si, se, st, en - st);
+      }
+      __syncthreads();
+      mark(dbg, 4, 2);   // big bin written
+    } else {
+      const unsigned bin = (item - nbig) * 4 + wave;
+      unsigned* key = tab + wave * kSmallLds;
+      unsigned* off = key + kSmallT;
+      unsigned* si = off + kSmallT;
+      unsigned* se = si + kSmall;
+      unsigned* vlist = se + kSmall;
+      unsigned p = 0, b = 0, sc = 0;
+      if (bin < nsmall) {
+        const uint4 rec = small_list[sbase + bin];
+        sc = rec.x;
+        p = rec.z;
+        b = rec.y;
+      }
+      const unsigned t = small_table_size(p);
+      for (unsigned s = lane; s < t; s += 64) {
+        key[s] = kNone;
+        off[s] = 0u;
+      }
+      __syncthreads();
+      uint2 m[4];
+      unsigned sl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = lane + 64 * j < p ? meta[b + lane + 64 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sl[j] = 0;
+        if (m[j].x < ib) {   // (kNone >= ib always)
+          sl[j] = lds_slot(key, t, m[j].y);
+          atomicAdd(&off[sl[j]], 1u);
+        }
+      }
+      __syncthreads();
+      int nvox;
+      {  // exclusive scan over the t slots of this wave's table (lane l owns slots [l * t / 64, (l + 1) * t / 64)) and the
+         // list of occupied slots: positions from the wave's inclusive scan of the per-lane counts
+        const unsigned per = t >> 6, s0 = lane * per;
+        int sum = 0, occ = 0;
+        for (unsigned s = 0; s < per; ++s) {
+          sum += (int)off[s0 + s];
+          occ += off[s0 + s] ? 1 : 0;
+        }
+        int run = wave_inclusive_scan(sum) - sum;
+        const int vinc = wave_inclusive_scan(occ);
+        int vpos = vinc - occ;
+        nvox = __shfl(vinc, 63, 64);
+        for (unsigned s = 0; s < per; ++s) {
+          const int v = (int)off[s0 + s];
+          off[s0 + s] = (unsigned)run;
+          run += v;
+          if (v) vlist[vpos++] = s0 + s;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (m[j].x < ib) {
+          const unsigned q = atomicAdd(&off[sl[j]], 1u);
+          si[q] = m[j].x;
+          se[q] = lane + 64 * j;
+        }
+      }
+      __syncthreads();
+      mark(dbg, 4, 3);   // small bins sorted
+      for (int v = lane; v < nvox; v += 64) {
+        const unsigned s = vlist[v];
+        const unsigned en = off[s], st = s ? off[s - 1] : 0u;
+        emit_voxel<KMAX>(a, bg, sc, key[s], b, si, se, st, en - st);
+      }
+      __syncthreads();
+      mark(dbg, 4, 4);   // small bins written
+    }
+  }
+}
+
+struct BinsLayout {
+  BinGeom bg;
+  size_t s_total;
+  int rs, nchunks;
+  int64_t n;
+};
+
+bool bins_layout(int64_t n_total, int batch, int f, const VoxGeom& g, BinsLayout* L) {
+  L->bg = bin_geom(g);
+  if (L->bg.s_scene < 0) return false;
+  L->s_total = (size_t)L->bg.s_stride * batch;
+  // a grid with far more supercells than points (or than 4M) is not worth binning, and K1 packs a point's place inside
+  // its group into 28 bits: the hash path takes the rest
+  if (L->s_total > (size_t)std::max<int64_t>(1 << 18, 8 * n_total) || L->s_total > (1u << 22)) return false;
+  if (n_total >= (1ll << 28)) return false;
+  L->rs = (f + 3) / 4 * 4;
+  L->nchunks = (int)ceil_div((int64_t)L->bg.s_stride * kXcd, kScanChunk);
+  L->n = std::max<int64_t>(n_total, 1);
+  return true;
+}
+
+}  // namespace
+
+void bins_set_debug_timeline(unsigned long long* buf) { g_dbg = buf; }
+size_t bins_debug_timeline_words() { return (size_t)5 * 8 * kDbgMaxWg; }
+
+size_t bins_workspace_bytes(int64_t n_total, int batch, int f, const VoxGeom& g) {
+  BinsLayout L;
+  if (!bins_layout(n_total, batch, f, g, &L)) return 0;
+  const size_t words = (size_t)(n_total / 32 + 4 * batch + 4);
+  size_t b = 0;
+  b += align_up((L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + kMaxBatch) * 4, 256);  // count, part, tickets (cleared)
+  b += align_up(L.s_total * kXcd * 4, 256);                    // basex
+  b += 2 * align_up(L.s_total * 16, 256);                      // small_list, big_list (16-byte bin records)
+  b += align_up(4 * kMaxBatch * 4, 256);                       // nlist, i_break
+  b += align_up((size_t)L.n * 4, 256);                         // pos
+  b += align_up((size_t)L.n * 8, 256);                         // meta
+  b += align_up((size_t)L.n * L.rs * 4, 256);                  // rows
+  b += 2 * align_up((size_t)L.n * 4, 256);                     // seg_idx, seg_e (bins above kSegLds points)
+  b += 2 * align_up(words * 4, 256);                           // bits, prefix
+  return b + 256;
+}
+
+int bins_hard_voxelize(const HardArgs& a) {
+  hipStream_t stream = a.stream;
+  BinsLayout L;
+  if (!bins_layout(a.n_total, a.batch, a.f, a.g, &L)) {
+    set_error("hard_voxelize: grid cannot be binned");
+    return EFG_E_INVALID;
+  }
+  const int batch = a.batch, f = a.f;
+  EFG_CHECK_ARG((long long)batch * a.max_voxels * a.max_points < (1ll << 31), "voxel capacity too large");
+  SceneWords sw;
+  SceneOffsets so = a.so;
+  sw.wb[0] = 0;
+  for (int b = 0; b < batch; ++b)   // every scene's words start on a 16-byte boundary (vector loads of the scan)
+    sw.wb[b + 1] = sw.wb[b] + (int)(ceil_div(so.off[b + 1] - so.off[b], 128) * 4);
+  for (int b = batch + 1; b <= kMaxBatch; ++b) so.off[b] = so.off[batch];  // off[kMaxBatch] = total rows (stage_rows)
+  const size_t words = (size_t)(a.n_total / 32 + 4 * batch + 4);
+  Workspace w(a.ws, a.ws_bytes);
+  const size_t cleared_words = L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + kMaxBatch;
+  unsigned* count = w.take<unsigned>(cleared_words);
+  // (8-byte aligned: s_total is a multiple of 4)
+  unsigned long long* part = count ? reinterpret_cast<unsigned long long*>(count + L.s_total * kXcd) : nullptr;
+  unsigned* ticket = count ? count + L.s_total * kXcd + (size_t)L.nchunks * batch * 2 : nullptr;
+  unsigned* basex = w.take<unsigned>(L.s_total * kXcd);
+  uint4* small_list = w.take<uint4>(L.s_total);
+  uint4* big_list = w.take<uint4>(L.s_total);
+  unsigned* nlist = w.take<unsigned>(4 * kMaxBatch);
+  unsigned* i_break = nlist ? nlist + 2 * kMaxBatch : nullptr;
+  unsigned* pos = w.take<unsigned>(L.n);
+  uint2* meta = w.take<uint2>(L.n);
+  float* rows = w.take<float>((size_t)L.n * L.rs);
+  unsigned* seg_idx = w.take<unsigned>(L.n);
+  unsigned* seg_e = w.take<unsigned>(L.n);
+  unsigned* bits = w.take<unsigned>(words);
+  unsigned* prefix = w.take<unsigned>(words);
+  if (!w.ok) {
+    set_error("hard_voxelize workspace too small: need %zu bytes, got %zu",
+              bins_workspace_bytes(a.n_total, batch, f, a.g), a.ws_bytes);
+    return EFG_E_WORKSPACE;
+  }
+  EFG_HIP_TRY(hipMemsetAsync(count, 0, cleared_words * 4, stream));
+  const dim3 blk(256);
+  const int tiles = (int)std::max<int64_t>(1, ceil_div(a.max_scene, kTile));
+  const bool stage = f <= 8;
+  if (stage)
+    hipLaunchKernelGGL(vox_bin_count_kernel<true>, dim3(tiles, batch), blk, 0, stream, a.points, so, sw, f, a.g, L.bg, count,
+                       pos, bits, g_dbg);
+  else
+    hipLaunchKernelGGL(vox_bin_count_kernel<false>, dim3(tiles, batch), blk, 0, stream, a.points, so, sw, f, a.g, L.bg, count,
+                       pos, bits, g_dbg);
+  EFG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vox_bin_scan_kernel, dim3(L.nchunks, batch), blk, 0, stream, so, L.bg, count, part, L.nchunks, basex,
+                     small_list, big_list, nlist, g_dbg);
+  EFG_LAUNCH_CHECK();
+  if (a.n_total > 0) {
+    if (stage)
+      hipLaunchKernelGGL(vox_bin_scatter_kernel<true>, dim3(tiles, batch), blk, 0, stream, a.points, so, f, a.g, L.bg, pos,
+                         basex, meta, rows, L.rs, g_dbg);
+    else
+      hipLaunchKernelGGL(vox_bin_scatter_kernel<false>, dim3(tiles, batch), blk, 0, stream, a.points, so, f, a.g, L.bg, pos,
+                         basex, meta, rows, L.rs, g_dbg);
+    EFG_LAUNCH_CHECK();
+  }
+  // the bins are listed on the device; a fixed grid loops over them (bounded by what the host knows: a bin holds a point)
+  const int64_t items_ub = std::min<int64_t>(L.bg.s_scene, std::max<int64_t>(a.max_scene, 1));
+  // as many workgroups as are resident at once (4 per CU x 256 CUs), shared by the scenes of the batch
+  const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(items_ub, std::max(256, kItemGrid / batch)));
+  hipLaunchKernelGGL(vox_first_kernel, dim3(gx, batch), blk, 0, stream, so, sw, L.bg, small_list, big_list,
+                     nlist, meta, bits, prefix, ticket, a.voxel_num, i_break, a.max_voxels, g_dbg);
+  EFG_LAUNCH_CHECK();
+  if (a.n_total > 0) {
+    if (a.max_points <= 5 && f <= 8)
+      hipLaunchKernelGGL(vox_write_kernel<5>, dim3(gx, batch), blk, 0, stream, so, sw, L.bg, f, L.rs,
+                         small_list, big_list, nlist, meta, rows, bits, prefix, i_break, a.voxel_num, a.max_points,
+                         a.coors_cols, a.voxels, a.coors, a.npv, a.mean, seg_idx, seg_e, g_dbg);
+    else if (a.max_points <= 8 && f <= 8)
+      hipLaunchKernelGGL(vox_write_kernel<8>, dim3(gx, batch), blk, 0, stream, so, sw, L.bg, f, L.rs,
+                         small_list, big_list, nlist, meta, rows, bits, prefix, i_break, a.voxel_num, a.max_points,
+                         a.coors_cols, a.voxels, a.coors, a.npv, a.mean, seg_idx, seg_e, g_dbg);
+    else
+      hipLaunchKernelGGL(vox_write_kernel<0>, dim3(gx, batch), blk, 0, stream, so, sw, L.bg, f, L.rs,
+                         small_list, big_list, nlist, meta, rows, bits, prefix, i_break, a.voxel_num, a.max_points,
+                         a.coors_cols, a.voxels, a.coors, a.npv, a.mean, seg_idx, seg_e, g_dbg);
+    EFG_LAUNCH_CHECK();
+  }
+  return EFG_OK;
+}
+
+}  // namespace efg

@@ -110,9 +110,9 @@ class DeviceLoader:
                 if self._stop.is_set():
                     raise StopIteration from None
                 if not self._thread.is_alive() and self._queue.empty():
-                    self._served = self.length
+                    served, self._served = self._served, self.length
                     raise RuntimeError("DeviceLoader: the producer thread exited after %d of %d batches without "
-                                       "reporting an error" % (self._served, self.length)) from None
+                                       "reporting an error" % (served, self.length)) from None
         if isinstance(item, _Failure):
             self._served = self.length
             raise item.exc

@@ -170,6 +170,10 @@ class Transformer(nn.Module):
         self._ref_cache_key, self._ref_cache = key, torch.cat(ref_windows, dim=1).contiguous()
         return self._ref_cache
 
+    def _select_proposals(self, probs):
+        """(scores, token indexes) of the num_queries best proposals per scene, unsorted ($CQ/transformer.py:65)."""
+        return torch.topk(probs, self.num_queries, dim=1, sorted=False)
+
     def _get_enc_proposals(self, enc_embed, ref_windows):
         """top-k (unsorted, :65) proposals of the 1-class proposal head, detached (:60-81).
 
@@ -180,17 +184,7 @@ class Transformer(nn.Module):
         head = self.proposal_head
         out_logits = head.class_embed[0](enc_embed)
         out_probs = out_logits[..., 0].sigmoid()
-        forced = getattr(self, "forced_topk_indexes", None)
-        if forced is None:
-            topk_probs, indexes = torch.topk(out_probs.detach(), self.num_queries, dim=1, sorted=False)
-        else:
-            # parity tests: WHICH tokens make the cut is ill-defined when the k-th best score is shared by many tokens
-            # (empty BEV cells all produce the same logit; on a random-init model the cut often falls inside that
-            # plateau, and two devices whose logits differ in the last bit then pick different members of it).  The
-            # comparison feeds both sides one set of proposals; the tests check separately that the sets differ only
-            # inside the tie.
-            indexes = forced.to(out_probs.device)
-            topk_probs = torch.gather(out_probs.detach(), 1, indexes)
+        topk_probs, indexes = self._select_proposals(out_probs.detach())
         topk_probs, indexes = topk_probs.unsqueeze(-1), indexes.unsqueeze(-1)
         emb_k = torch.gather(enc_embed, 1, indexes.expand(-1, -1, enc_embed.shape[-1]))
         ref_k = torch.gather(ref_windows, 1, indexes.expand(-1, -1, ref_windows.shape[-1]))

@@ -71,6 +71,9 @@ def collate(samples, device):
 
 
 class VoxelDETR(nn.Module):
+    # set by engine.Trainer for the bucketed (overlapped) gradient exchange: callable(key, activation); see forward()
+    grad_watch = None
+
     def __init__(self, config):
         super().__init__()
         self.device = torch.device(config.model.device)

@@ -130,6 +130,7 @@ class FlatGradientAllReduce:
     def __init__(self, model, world):
         self.model, self.world = model, world
         self.params = self.flat = self.views = None
+        self.found_inf = None   # in: this rank's flag (set by Trainer.step before backward); out: any rank's
         self.avg = dist.get_backend() == "nccl"  # gloo has no AVG
         # every rank starts from rank 0's parameters and buffers (DDP's constructor does the same)
         tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
@@ -154,7 +155,8 @@ class FlatGradientAllReduce:
                                    "(%d parameters, e.g. %s); use EFG_DDP_MODE=find_unused" % (len(bad), bad[:3]))
             self.params = [p for _, p in named if p.grad is not None]
             total = sum(p.numel() for p in self.params)
-            self.flat = torch.empty(total, dtype=self.params[0].dtype, device=self.params[0].device)
+            # + 1: the step's `found_inf` flag travels with the gradients (see Trainer.step)
+            self.flat = torch.zeros(total + 1, dtype=self.params[0].dtype, device=self.params[0].device)
             self.views, off = [], 0
             for p in self.params:
                 self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -163,6 +165,7 @@ class FlatGradientAllReduce:
         if any(g is None for g in grads):  # a data-dependent branch skipped a parameter this step: it sends zeros
             grads = [v.zero_() if g is None else g for g, v in zip(grads, self.views)]
         torch._foreach_copy_(self.views, grads)  # multi-tensor pack into the flat buffer
+        _pack_found_inf(self.flat, self.found_inf)
         if self.avg:
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
         else:
@@ -170,6 +173,24 @@ class FlatGradientAllReduce:
             self.flat.div_(self.world)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self.found_inf = _unpack_found_inf(self.flat, self.found_inf)
+
+
+def _pack_found_inf(buf, flag):
+    """Last element of an exchange buffer := this rank's "the loss is not finite" flag (0 / 1)."""
+    if flag is None:
+        buf[-1:].zero_()
+    else:
+        buf[-1:].copy_(flag.reshape(1))
+
+
+def _unpack_found_inf(buf, flag):
+    """After the SUM / AVG all-reduce the element is > 0 on EVERY rank iff ANY rank raised it: all ranks skip the
+    update together (a rank-local flag lets the failing rank skip while the others write the NaN gradients it sent
+    into their weights -- the replicas diverge).  Stays on the device."""
+    if flag is None:
+        return None
+    return (buf[-1:] > 0).to(torch.float32)
 
 
 def build_optimizer(cfg, model):
@@ -190,6 +211,17 @@ def build_optimizer(cfg, model):
     return torch.optim.AdamW(params, **oc)
 
 
+def _scheduler_block(cfg):
+    """`solver.lr_scheduler`, or None when the config has no scheduler.  The merged defaults always carry a block of
+    placeholders ({max_epochs: None, max_iters: None}): a block that names no type and no length IS "no scheduler"."""
+    sc = cfg.solver.get("lr_scheduler") if hasattr(cfg.solver, "get") else None
+    if not sc:
+        return None
+    if not sc.get("type") and not sc.get("max_iters") and not sc.get("max_epochs"):
+        return None
+    return sc
+
+
 def resolve_max_iters(cfg, max_iters=None, iters_per_epoch=None):
     """Length of the schedule, per CONFIG, as the reference's trainer derives it (efg/engine/trainer.py:158-161:
     `max_iters = len(dataloader) * lr_scheduler.max_epochs`, written back as lr_scheduler.max_iters / epoch_iters).
@@ -198,7 +230,7 @@ def resolve_max_iters(cfg, max_iters=None, iters_per_epoch=None):
     neither is an error (a ConQueR-sized constant would give CenterPoint's 36-epoch run the wrong rate and momentum)."""
     if max_iters is not None:
         return int(max_iters)
-    sc = cfg.solver.get("lr_scheduler") if hasattr(cfg.solver, "get") else None
+    sc = _scheduler_block(cfg)
     if not sc:
         return None
     if sc.get("max_iters"):
@@ -215,7 +247,7 @@ def build_one_cycle(cfg, optimizer, max_iters):
     builds it: max_lr = solver.optimizer.lr for EVERY parameter group (the scalar overrides the per-group rates of
     AdamWMulti -- kept, it is what the reference trains with), total_steps = max_iters, cycled Adam beta1 between
     base_momentum and max_momentum.  None when the config has no scheduler."""
-    sc = cfg.solver.get("lr_scheduler") if hasattr(cfg.solver, "get") else None
+    sc = _scheduler_block(cfg)
     if not sc:
         return None
     if sc.get("type", "OneCycle") != "OneCycle":
@@ -249,6 +281,7 @@ class BucketedGradientAllReduce:
         self.comm = None
         self.pending = []
         self.done = set()
+        self.found_inf = None   # as in FlatGradientAllReduce; rides in the LAST bucket (backbone)
 
     def _build(self):
         names = {"transformer": [], "neck": [], "backbone": []}
@@ -273,7 +306,7 @@ class BucketedGradientAllReduce:
         if self.layout is None:   # first step: nothing is launched from the hooks, reduce() freezes the membership
             return
         params, buf, views = self.layout[key]
-        if not params:
+        if not params and key != "backbone":
             return
         dev = buf.device
         main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
@@ -282,6 +315,8 @@ class BucketedGradientAllReduce:
         if missing:
             grads = [v.zero_() if g is None else g for g, v in zip(grads, views)]
         torch._foreach_copy_(views, grads)  # on the compute stream, right behind the producers
+        if key == "backbone":
+            _pack_found_inf(buf, self.found_inf)
         if main is not None:
             if self.comm is None:
                 self.comm = torch.cuda.Stream(device=dev)
@@ -308,8 +343,8 @@ class BucketedGradientAllReduce:
         self.layout = {}
         for key in ("transformer", "neck", "backbone"):
             params = [p for p in self.groups[key] if p.grad is not None]
-            total = sum(p.numel() for p in params)
-            buf = torch.empty(total, dtype=params[0].dtype if params else torch.float32, device=dev)
+            total = sum(p.numel() for p in params) + (1 if key == "backbone" else 0)   # + the found_inf element
+            buf = torch.zeros(total, dtype=params[0].dtype if params else torch.float32, device=dev)
             views, off = [], 0
             for p in params:
                 views.append(buf[off:off + p.numel()].view_as(p))
@@ -349,6 +384,7 @@ class BucketedGradientAllReduce:
                 p.grad = v
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
+        self.found_inf = _unpack_found_inf(self.layout["backbone"][1], self.found_inf)
 
 
 class Trainer:
@@ -357,7 +393,7 @@ class Trainer:
     losses, non-finite check, backward, gradient exchange, optional clipping, optimizer step, scheduler step."""
 
     def __init__(self, config=None, overrides=None, device=None, seed=0, ddp=None, max_iters=None, model_cls=None,
-                 iters_per_epoch=None):
+                 iters_per_epoch=None, ddp_mode=None):
         cfg = load_config(config or DEFAULT_CONFIG, overrides)
         if str(cfg.model.device if device is None else device).startswith("cuda"):
             configure_hip_runtime()
@@ -388,13 +424,20 @@ class Trainer:
         self._steps = 0
         self._manual_gc = (self.model.device.type == "cuda" and os.environ.get("EFG_MANUAL_GC", "1") != "0")
         self.grad_sync = None
+        self.ddp_mode = None
         if use_ddp:
-            # "flat" (default): one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
+            # "bucket" (default): three flat buckets, each all-reduced on a communication stream as soon as backward has
+            # produced it -- the exchange OVERLAPS backward, as the reference's DDP reducer does
+            # (efg/engine/trainer.py:191-198) and BASELINE.json's north_star asks (BucketedGradientAllReduce).
+            # "flat": one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
             # "static" / "find_unused" / "plain": torch DistributedDataParallel as in the reference, with
             # static_graph=True / find_unused_parameters=True ($CQ/config.yaml:183) / neither.  The literal
             # find_unused_parameters setting costs +14 ms/step: with locally unused parameters (the skipped FPN
             # levels) DDP makes a BLOCKING D2H copy of its "used" bitmap at the end of every backward.
-            mode = os.environ.get("EFG_DDP_MODE", "flat")
+            mode = ddp_mode or os.environ.get("EFG_DDP_MODE", "bucket")
+            self.ddp_mode = mode
+            if mode == "bucket" and not hasattr(self.model, "grad_watch"):
+                mode = self.ddp_mode = "flat"   # a model without the bucket hooks (CenterPoint, TrajectoryFormer)
             if mode == "flat":
                 self.grad_sync = FlatGradientAllReduce(self.model, world)
             elif mode == "bucket":
@@ -484,10 +527,14 @@ class Trainer:
             # on the GPU the error is REPORTED every `anomaly_every` steps (_check_anomaly), but a non-finite step never
             # reaches the weights: the fused AdamW skips its update on a device-side flag
             self.optimizer.found_inf = torch.logical_not(torch.isfinite(losses.detach())).to(torch.float32).reshape(1)
+            if hasattr(self.grad_sync, "found_inf"):   # exchanged with the gradients: every rank skips, or none
+                self.grad_sync.found_inf = self.optimizer.found_inf
         with record_function("efg::backward"):
             losses.backward()
             if self.grad_sync is not None:
                 self.grad_sync.reduce()
+                if getattr(self.grad_sync, "found_inf", None) is not None and hasattr(self.optimizer, "_plan"):
+                    self.optimizer.found_inf = self.grad_sync.found_inf
         with record_function("efg::optimizer"):
             if self.grad_clipper is not None:  # hooks.py:74-79 (disabled in the ConQueR / Voxel-DETR configs)
                 params = [p for p in self.model.parameters() if p.grad is not None]

@@ -1,7 +1,8 @@
 """Split-precision (bf16 x 3) products for the A/B arm of the bench -- csrc/gemm_bf16x3.hip through the C ABI.
 
 Never the default: `EFG_GEMM_ARM=bf16x3` swaps it in for the forward and the data-gradient product of the encoder-sized
-`nn.Linear` layers (operators/linear.py); the weight gradient and everything else stay exact fp32."""
+`nn.Linear` layers (operators/linear.py) -- forward, data gradient and (via `wgrad`) the weight gradient; everything
+else stays exact fp32."""
 import torch
 
 from .. import _lib

@@ -37,12 +37,14 @@ def _hard_voxelize_launch(points, offsets, voxel_size, coors_range, max_points, 
     batch = len(offsets) - 1
     n_total = int(offsets[-1])
     lib = L.lib()
-    ws_bytes = lib.efg_hard_voxelize_workspace_bytes(n_total, batch, max_points, max_voxels)
+    vs, cr = L.host_f32(voxel_size, 3), L.host_f32(coors_range, 6)
+    ws_bytes = lib.efg_hard_voxelize_workspace_bytes(n_total, batch, points.shape[1], max_points, max_voxels, vs, cr)
     if ws_bytes == 0:
-        raise RuntimeError("hard_voxelize: max_points and max_voxels must be >= 1")
+        raise RuntimeError("hard_voxelize: max_points and max_voxels must be >= 1, batch in [1, 64], points [N, >= 3] "
+                           "and a non-empty grid")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=points.device)
     L.check(lib.efg_hard_voxelize_f32(L.ptr(points), L.host_i64(offsets), batch, points.shape[1],
-                                      L.host_f32(voxel_size, 3), L.host_f32(coors_range, 6), max_points, max_voxels,
+                                      vs, cr, max_points, max_voxels,
                                       L.ptr(voxels), L.ptr(coors), coors.shape[1], L.ptr(npv), L.ptr(voxel_num),
                                       L.ptr(mean), L.ptr(ws), ws_bytes, L.stream()))
 

@@ -119,10 +119,14 @@ def _build_wgrad_sched(plan, m, cin, cout, kvol):
 _WGT_OK = {}
 
 
-def _wgrad_tiled(cin, cout, kvol, m_out):
+def _wgrad_tiled(cin, cout, kvol, m_out, m_in=0):
     """Does the plan-walking weight gradient take this layer?  (EFG_WGRAD_TILED=0: the table kernel everywhere.)  Cached:
-    this sits on the host path of every sparse convolution, and the training step is close to host-bound."""
+    this sits on the host path of every sparse convolution, and the training step is close to host-bound.
+    Size limits of csrc/spconv_wgt.hip (32-bit byte offsets into the feature tensors, 32-bit tile products in the
+    schedule kernel): larger layers take the table kernel instead of failing at backward time."""
     if m_out <= 0:
+        return False
+    if max(m_in, m_out) * max(cin, cout) * 4 >= (1 << 32) or m_out >= (1 << 25):
         return False
     key = (cin, cout, kvol)
     ok = _WGT_OK.get(key)
@@ -157,7 +161,50 @@ def _arm_bf16x3(cin, cout, kvol, m_in, m_out):
     return _ARM_OK[key]
 
 
-def _conv_forward(features, w, bias, rb):
+# ---- packed weights, cached across calls ------------------------------------------------------------------------------
+# The MFMA operand order of a layer's weights is a pure function of the weights: re-packing in every forward and every
+# backward was ~40 launches per ConQueR step.  The packed copy lives on the PARAMETER object (so it dies with it) and is
+# valid while (parameter._version, weight epoch) is unchanged.  The epoch is bumped by a global post-step hook on every
+# torch optimizer (the fused AdamW updates parameters without moving `_version`) and by `weights_updated()`, which code
+# that writes weights behind autograd's back (`p.data.copy_(...)`) must call.  EFG_SPCONV_PACK_CACHE=0 packs per call.
+_WEIGHT_EPOCH = [0]
+_PACK_CACHE_ON = os.environ.get("EFG_SPCONV_PACK_CACHE", "1") != "0"
+
+
+def weights_updated(*_args, **_kwargs):
+    """Invalidate every cached packed weight (called after each optimizer step; call it yourself after writing
+    convolution weights through `.data`)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+try:   # every optimizer of the process, the reference's own (efg/solver) included
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+
+    _reg_hook(weights_updated)
+except ImportError:   # pragma: no cover  (older torch: no global hooks -> no caching)
+    _PACK_CACHE_ON = False
+
+
+def _packed_weight(w, flags, owner=None):
+    """MFMA-order copy of w [cout, kvol, cin] for `flags` (bit 0: data-gradient layout, bit 1: natural channel order,
+    bit 2: split-precision arm), cached on `owner` (the layer's Parameter) when given."""
+    lib = L.lib()
+    cout, kvol, cin = w.shape
+    tag = None
+    if owner is not None and _PACK_CACHE_ON and w.is_cuda:
+        tag = (owner._version, _WEIGHT_EPOCH[0], w.data_ptr())
+        cache = owner.__dict__.setdefault("_efg_packed", {})
+        ent = cache.get(flags)
+        if ent is not None and ent[0] == tag:
+            return ent[1]
+    packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, flags & 1), dtype=torch.uint8, device=w.device)
+    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, flags, L.ptr(packed), L.stream()))
+    if tag is not None:
+        cache[flags] = (tag, packed)
+    return packed
+
+
+def _conv_forward(features, w, bias, rb, owner=None):
     """features [m_in,cin], w [cout,kvol,cin] -> [m_out,cout]"""
     lib = L.lib()
     cout, kvol, cin = w.shape
@@ -165,9 +212,7 @@ def _conv_forward(features, w, bias, rb):
     nat = _natural_order(cin) if tiled else 0
     if tiled and not nat:
         nat = _arm_bf16x3(cin, cout, kvol, rb.m_in, rb.m_out)   # (bit 2 of the same flag word)
-    packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 0), dtype=torch.uint8,
-                         device=features.device)
-    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 0 | nat, L.ptr(packed), L.stream()))
+    packed = _packed_weight(w, 0 | nat, owner)
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
     if tiled:
         plan = rb.plan_fwd()
@@ -181,16 +226,14 @@ def _conv_forward(features, w, bias, rb):
     return out
 
 
-def _conv_dgrad(grad_out, w, rb):
+def _conv_dgrad(grad_out, w, rb, owner=None):
     lib = L.lib()
     cout, kvol, cin = w.shape
     tiled = _tiled() and kvol <= 31 and rb.m_in > 0
     nat = _natural_order(cout) if tiled else 0
     if tiled and not nat:
         nat = _arm_bf16x3(cout, cin, kvol, rb.m_out, rb.m_in)
-    packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, 1), dtype=torch.uint8,
-                         device=grad_out.device)
-    L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, 1 | nat, L.ptr(packed), L.stream()))
+    packed = _packed_weight(w, 1 | nat, owner)
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     if tiled:
         plan, flip = rb.plan_dgrad()
@@ -209,7 +252,7 @@ def _conv_dgrad(grad_out, w, rb):
 def _conv_wgrad(features, grad_out, rb):
     lib = L.lib()
     cin, cout, kvol = features.shape[1], grad_out.shape[1], rb.kvol
-    if _wgrad_tiled(cin, cout, kvol, rb.m_out):
+    if _wgrad_tiled(cin, cout, kvol, rb.m_out, rb.m_in):
         # over the layer's forward tile plan: MFMA operands straight from the feature rows (csrc/spconv_wgt.hip)
         plan, sched, ws_bytes = rb.plan_fwd(), *rb.wgrad_sched(cin, cout)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
@@ -385,7 +428,7 @@ class Rulebook:
         (csrc/spconv_wgt.hip) on the geometry stream -- the forward pass of a training step calls this and does NOT wait
         for it: only the backward pass reads the schedule (wgrad_sched waits for the event recorded here)."""
         key = (cin, cout)
-        if key in self._wgrad_sched or not _wgrad_tiled(cin, cout, self.kvol, self.m_out):
+        if key in self._wgrad_sched or not _wgrad_tiled(cin, cout, self.kvol, self.m_out, self.m_in):
             return
         plan = self.plan_fwd()
         with _on_geometry_stream(wait=False) as main:
@@ -531,12 +574,16 @@ class _SparseConvFunction(Function):
     """features[M_in,Cin] x weight[Cout,kvol,Cin] (+bias) -> [M_out,Cout] through a Rulebook."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb):
+    def forward(ctx, features, weight, bias, rb, grad_on=True):
         features = features.contiguous()
         cout, cin = weight.shape[0], weight.shape[-1]
         w = weight.reshape(cout, rb.kvol, cin).contiguous()
-        out = _conv_forward(features, w, bias, rb)
-        if ctx.needs_input_grad[1] and features.is_cuda:   # (the oracle-backed CPU path of the tests patches _conv_* only)
+        # (the oracle-backed CPU path of the tests patches _conv_* with three-argument stand-ins: no `owner` there)
+        out = _conv_forward(features, w, bias, rb, weight) if features.is_cuda else _conv_forward(features, w, bias, rb)
+        ctx.owner = weight if features.is_cuda else None
+        # the weight gradient's launch schedule: only when a backward can follow (needs_input_grad is True under no_grad
+        # too, and grad mode is always off inside forward(): the caller passes what it saw)
+        if ctx.needs_input_grad[1] and features.is_cuda and grad_on:
             rb.prepare_wgrad(cin, cout)   # the weight gradient's launch schedule, on the geometry stream, ahead of the backward
         ctx.save_for_backward(features, w)
         ctx.rb = rb
@@ -552,12 +599,12 @@ class _SparseConvFunction(Function):
         grad_out = grad_out.contiguous()
         grad_in = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
-            grad_in = _conv_dgrad(grad_out, w, rb)
+            grad_in = _conv_dgrad(grad_out, w, rb, ctx.owner) if ctx.owner is not None else _conv_dgrad(grad_out, w, rb)
         if ctx.needs_input_grad[1]:
             grad_w = _conv_wgrad(features, grad_out, rb).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = grad_out.sum(0)
-        return grad_in, grad_w, grad_b, None
+        return grad_in, grad_w, grad_b, None, None
 
 
 def _downsample_geometry(x, ks, st, pad):
@@ -719,7 +766,7 @@ class SparseConvolution(SparseModule):
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
         rb, geom = self._rulebook(x)
-        feats = _SparseConvFunction.apply(x.features, self.weight, self.bias, rb)
+        feats = _SparseConvFunction.apply(x.features, self.weight, self.bias, rb, torch.is_grad_enabled())
         if self.subm:
             return x.replace_feature(feats)
         out_indices, site_index, out_shape = geom

@@ -46,7 +46,10 @@ int efg_capture_stream_destroy(void* stream);
 /* ------------------------------------------------------------------------------------------
  * Voxelization.  Replaces efg::dynamic_voxelize / efg::hard_voxelize
  * (efg/operators/src/voxelize/voxelization.h:51-83; CPU semantics voxelization_cpu.cpp:7-99).
- * Grid volume (x batch) must be < 2^32 - 1 cells.
+ * Two implementations behind efg_hard_voxelize_f32 (csrc/voxelize_bins.hip, the default: points binned into
+ * BEV supercells, per-bin tables in LDS; csrc/voxelize_hash.hip: one global hash table, taken when the
+ * environment says EFG_VOX_IMPL=hash or when the grid has far more supercells than points -- that path needs
+ * grid volume x batch < 2^32 - 1 cells).
  * ---------------------------------------------------------------------------------------- */
 
 /* coors[n,3] int32 (z,y,x); (-1,-1,-1) for points outside coors_range (CPU encoding,
@@ -54,7 +57,10 @@ int efg_capture_stream_destroy(void* stream);
 int efg_dynamic_voxelize_f32(const float* points, int64_t n, int f, const float* voxel_size_host,
                              const float* coors_range_host, int32_t* coors, void* stream);
 
-size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int max_points, int max_voxels);
+/* Bytes of scratch efg_hard_voxelize_f32 needs for this call shape (0 for invalid arguments).  The geometry
+ * matters: the binned path keeps per-supercell counters. */
+size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int f, int max_points, int max_voxels,
+                                         const float* voxel_size_host, const float* coors_range_host);
 
 /*
  * Batched hard voxelization of `batch` scenes in one call.  Scene b owns the point rows
@@ -77,6 +83,11 @@ int efg_hard_voxelize_f32(const float* points, const int64_t* point_offsets_host
                           const float* voxel_size_host, const float* coors_range_host, int max_points,
                           int max_voxels, float* voxels, int32_t* coors, int coors_cols, int32_t* npv,
                           int32_t* voxel_num, float* mean, void* ws, size_t ws_bytes, void* stream);
+
+/* Development aid (scripts/vox_timeline.py): with a device buffer of the returned number of uint64 words set, thread
+ * 0 of every workgroup of the binned voxelizer's kernels stores the 100 MHz wall clock at its phase markers
+ * ([kernel 0..3][marker 0..7][workgroup < 32768]); NULL (the default) switches it off.  Returns the word count. */
+size_t efg_hard_voxelize_debug_timeline(void* device_buf_u64);
 
 /* ------------------------------------------------------------------------------------------
  * Dynamic scatter.  Replaces efg::dynamic_point_to_voxel_forward / _backward
@@ -191,6 +202,13 @@ int efg_spconv_tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_o
 int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);
+/* Stream-K's bounded wait (a share that does not arrive within EFG_TILE_SK_POLLS polls, ~20 ms: two processes
+ * spinning on one device, a preempted queue) makes the owner RECOMPUTE the unit -- same sum, different order, twice the
+ * work.  Every such event is counted on the device; this returns the count summed over the current device's streams
+ * (it synchronises: a measurement / test call, not a step call) and optionally clears it.  A launch issued while its
+ * stream is being captured into a HIP graph never uses stream-K (the launch epoch is a kernel argument: a replay would
+ * read stale shares). */
+int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset);
 /* 1 when the split-precision arm of the tile kernel covers a (cin -> cout, kvol) convolution of these table sizes. */
 int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out);
 

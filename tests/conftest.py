@@ -103,3 +103,17 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def force_proposals(transformer, indexes):
+    """Test-side hook: make `transformer` take the given proposal tokens instead of its own top-k.  WHICH tokens make
+    the cut is ill-defined when the k-th best score is shared by many tokens (empty BEV cells all produce the same logit;
+    on a random-init model the cut often falls inside that plateau, and two devices whose logits differ in the last bit
+    then pick different members of it).  A comparison feeds both sides one set of proposals; the tests check separately
+    that the two sides' own sets differ only inside the tie.  `indexes` None restores the model's own selection."""
+    import torch
+
+    if indexes is None:
+        transformer.__dict__.pop("_select_proposals", None)
+        return
+    transformer._select_proposals = lambda probs: (torch.gather(probs, 1, indexes.to(probs.device)), indexes.to(probs.device))

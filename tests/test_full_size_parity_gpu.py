@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from conftest import ROOT
+from conftest import ROOT, force_proposals
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def _losses(make_trainer, make_batch, device, install, seed, forced_topk=None):
     seen = {}
     transformer = getattr(tr.model, "transformer", None)
     if transformer is not None and hasattr(transformer, "_get_enc_proposals"):
-        transformer.forced_topk_indexes = forced_topk
+        force_proposals(transformer, forced_topk)
         transformer.register_forward_hook(lambda mod, inp, out: seen.update(
             topk=mod.enc_outputs["topk_indexes"].detach().cpu()[..., 0], logits=mod.enc_outputs["pred_logits"].detach().cpu()[..., 0]))
     with install():

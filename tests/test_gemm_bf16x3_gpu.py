@@ -2,6 +2,7 @@
 product's own error, which is the scale that matters for the parity gate (tests/test_full_size_parity_gpu.py)."""
 import pytest
 import torch
+from conftest import force_proposals
 
 pytestmark = pytest.mark.gpu
 
@@ -81,7 +82,7 @@ def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
         tr = Trainer(device=dev, overrides={"model.transformer.num_queries": 900}, seed=0, ddp=False)
         tr.model.noise_generator = torch.Generator().manual_seed(4321)
         seen = {}
-        tr.model.transformer.forced_topk_indexes = forced
+        force_proposals(tr.model.transformer, forced)
         tr.model.transformer.register_forward_hook(lambda mod, inp, out: seen.update(
             topk=mod.enc_outputs["topk_indexes"].detach().cpu()[..., 0], logits=mod.enc_outputs["pred_logits"].detach().cpu()))
         losses, _ = tr.step(synthetic_batch(1000, 2, n_points=180000, device=dev))

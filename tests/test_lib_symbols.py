@@ -32,8 +32,10 @@ def test_version_and_error_channel(lib):
     assert lib.efg_version().decode().startswith("efg_hip")
     assert b"gfx950" in lib.efg_version()
     # host-side validation: bad arguments are rejected before any device work
-    assert lib.efg_hard_voxelize_workspace_bytes(1000, 1, 0, 10) == 0
-    assert lib.efg_hard_voxelize_workspace_bytes(180000, 2, 5, 120000) > 0
+    vs, cr = (ctypes.c_float * 3)(0.1, 0.1, 0.15), (ctypes.c_float * 6)(-75.2, -75.2, -2.0, 75.2, 75.2, 4.0)
+    assert lib.efg_hard_voxelize_workspace_bytes(1000, 1, 5, 0, 10, vs, cr) == 0
+    assert lib.efg_hard_voxelize_workspace_bytes(1000, 1, 2, 5, 10, vs, cr) == 0
+    assert lib.efg_hard_voxelize_workspace_bytes(180000, 2, 5, 5, 120000, vs, cr) > 0
     assert lib.efg_spconv_packed_weight_bytes(64, 27, 64, 0) >= 27 * 64 * 64 * 4
     assert lib.efg_spconv_wgrad_workspace_bytes(100000, 64, 64, 27) > 0
     shp = (ctypes.c_int * 3)(41, 1504, 1504)

@@ -24,8 +24,11 @@ def _port():
     return p
 
 
-def _torchrun(script_args, mode):
-    env = dict(os.environ, EFG_DIST_BACKEND="gloo", EFG_DDP_MODE=mode, OMP_NUM_THREADS="2")
+def _torchrun(script_args, mode, backend="gloo"):
+    env = dict(os.environ, EFG_DIST_BACKEND=backend, OMP_NUM_THREADS="2")
+    env.pop("EFG_DDP_MODE", None)
+    if mode is not None:
+        env["EFG_DDP_MODE"] = mode
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_port())] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -35,24 +38,34 @@ _BENCH_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "3000
                "--no-cpu-baseline", "--profile-steps", "1"]
 
 
-def _check_line(r):
+def _check_line(r, mode="bucket", backend="gloo"):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
-    assert line["rccl_ranks"] == 2 and line["dist_backend"] == "gloo"
+    assert line["rccl_ranks"] == 2 and line["dist_backend"] == backend
+    # what an 8-GPU run needs to be read: the exchange that ran, every rank's step time and input size, the host's issue
+    # time, and the stream-K recompute counter (two processes on ONE device may legitimately trip its bounded wait)
+    assert line["ddp_mode"] == mode
+    assert len(line["rank_ms_per_step"]["all"]) == 2 and line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    assert 0 < line["host_issue_ms_per_step"] <= line["ms_per_step"] * 1.001
+    assert len(line["rank_input_voxels"]) == 2 and min(line["rank_input_voxels"]) > 1000
+    assert len(line["streamk_fallbacks"]) == 2 and min(line["streamk_fallbacks"]) >= 0
+    return line
 
 
-def test_bench_two_ranks_one_gpu(dev):
-    """launched exactly as the driver launches N > 1: under torch.distributed.run"""
-    _check_line(_torchrun(["bench.py"] + _BENCH_ARGS, "flat"))
+@pytest.mark.parametrize("mode", [None, "flat"])
+def test_bench_two_ranks_one_gpu(dev, mode):
+    """launched exactly as the driver launches N > 1: under torch.distributed.run; default exchange = bucket (overlapped)"""
+    args = ["bench.py"] + _BENCH_ARGS + (["--ddp-mode", mode] if mode else [])
+    _check_line(_torchrun(args, None), mode or "bucket")
 
 
 def test_bench_bare_command_starts_its_own_ranks(dev):
     """`python bench.py --gpus 2` with no launcher in front: bench.py spawns the ranks itself"""
-    env = dict(os.environ, EFG_DIST_BACKEND="gloo", EFG_DDP_MODE="flat", OMP_NUM_THREADS="2")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env = dict(os.environ, EFG_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EFG_DDP_MODE"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py"] + _BENCH_ARGS, capture_output=True, text=True, timeout=900, env=env,
                        cwd=ROOT)
@@ -60,12 +73,27 @@ def test_bench_bare_command_starts_its_own_ranks(dev):
     _check_line(r)
 
 
+def test_rccl_two_ranks_when_the_node_has_two_devices():
+    """The first box with >= 2 GPUs exercises RCCL itself (backend "nccl"), both exchanges, through the driver's command;
+    on the 1-GPU boxes of this pool it skips (the gloo tests above cover the logic)."""
+    import torch
+
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices: RCCL cannot place two ranks on one GPU")
+    for mode in ("bucket", "flat"):
+        line = _check_line(_torchrun(["bench.py"] + _BENCH_ARGS + ["--ddp-mode", mode], None, backend="nccl"), mode, "rccl")
+        assert line["streamk_fallbacks"] == [0, 0]     # one process per device: a share is never late
+    r = _torchrun(["tests/ddp_gpu_worker.py"], "bucket", backend="nccl")
+    assert "DDP_GPU_OK" in r.stdout and "nan_step_skipped_on_all_ranks=1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_two_rank_gradients_and_parameters_agree(dev):
     res = {}
     for mode in ("flat", "bucket"):
         r = _torchrun(["tests/ddp_gpu_worker.py"], mode)
-        m = re.search(r"DDP_GPU_(\w+) mode=(\w+) grad_norm=(\S+) loss=(\S+)", r.stdout)
+        m = re.search(r"DDP_GPU_(\w+) mode=(\w+) grad_norm=(\S+) loss=(\S+) nan_step_skipped_on_all_ranks=(\d)", r.stdout)
         assert m and m.group(1) == "OK", r.stdout[-2000:] + r.stderr[-3000:]
+        assert m.group(5) == "1", "a non-finite loss on one rank must make every rank skip the update (%s)" % mode
         res[mode] = (m.group(2), float(m.group(3)), float(m.group(4)))
     assert res["flat"][0] == "FlatGradientAllReduce" and res["bucket"][0] == "BucketedGradientAllReduce"
     # the same averaged gradient either way (two separate 3-step runs: fp32 atomics in the attention / scatter

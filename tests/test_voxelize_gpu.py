@@ -116,3 +116,98 @@ def test_batched_matches_per_scene(dev, oracle_mod):
                                    atol=1e-6)
         base += m
     assert out["voxels"].shape[0] == base
+
+
+@pytest.fixture(params=["bins", "hash"])
+def impl(request, monkeypatch):
+    """Both hard voxelizers behind the one entry point (csrc/voxelize_bins.hip default, voxelize_hash.hip)."""
+    monkeypatch.setenv("EFG_VOX_IMPL", request.param)
+    return request.param
+
+
+def _check_vs_oracle(dev, oracle_mod, pts, vs, cr, mp, mv):
+    ev, ec, en = oracle_mod.hard_voxelize(pts, vs, cr, mp, mv)
+    v, c, k = _run_hard(dev, pts, vs, cr, mp, mv)
+    assert v.shape == ev.shape
+    assert np.array_equal(c, ec) and np.array_equal(k, en) and np.array_equal(v, ev)
+
+
+@pytest.mark.parametrize("order", ["shuffled", "scan", "sorted_x"])
+def test_both_implementations_any_point_order(dev, oracle_mod, impl, order):
+    """The binned voxelizer aggregates a tile's points per supercell: a cloud in scan order (long runs inside one
+    supercell) and a shuffled one (every point a different supercell) take different paths through it."""
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+
+    pts, _, _ = make_scene(77, n_points=60000)
+    if order == "scan":
+        pts = pts[np.lexsort((pts[:, 0], np.round(np.arctan2(pts[:, 1], pts[:, 0]), 2)))]
+    elif order == "sorted_x":
+        pts = pts[np.argsort(pts[:, 0], kind="stable")]
+    for mp, mv in [(5, 120000), (5, 9000), (1, 500), (35, 20000)]:
+        _check_vs_oracle(dev, oracle_mod, np.ascontiguousarray(pts), VOXEL_SIZE, PC_RANGE, mp, mv)
+
+
+@pytest.mark.parametrize("f", [3, 4, 6, 8, 9, 13])
+def test_feature_widths_and_unaligned_rows(dev, oracle_mod, impl, f):
+    """Rows are staged through LDS with 16-byte loads when F <= 8 (any alignment of the first row), read in place
+    otherwise; the buffer itself may start 4 bytes off a 16-byte boundary."""
+    from efg_amd.operators import voxelization
+
+    rng = np.random.default_rng(f)
+    n = 30011
+    pts = rng.uniform(-1, 1, (n, f)).astype(np.float32)
+    pts[:, :3] = rng.uniform(-12.5, 12.5, (n, 3))          # ~4 % of the points fall outside the range
+    vs, cr = [0.25, 0.25, 0.5], [-12.0, -12.0, -12.0, 12.0, 12.0, 12.0]
+    ev, ec, en = oracle_mod.hard_voxelize(pts, vs, cr, 4, 7000)
+    for shift in (0, 1, 3):
+        buf = torch.empty(n * f + 4, device=dev)
+        t = buf[shift:shift + n * f].view(n, f)
+        t.copy_(torch.from_numpy(pts))
+        assert t.data_ptr() % 16 == (buf.data_ptr() + 4 * shift) % 16
+        v, c, k = voxelization(t, vs, cr, 4, 7000)
+        assert np.array_equal(c.cpu().numpy(), ec) and np.array_equal(k.cpu().numpy(), en)
+        assert np.array_equal(v.cpu().numpy(), ev)
+
+
+def test_crowded_supercells(dev, oracle_mod, impl):
+    """Bins far beyond the one-wave limit (256 points) and beyond any LDS list: 70k points inside two supercells, many
+    of them in a handful of voxels; plus a grid taller than one supercell (two z-slabs)."""
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0.0, 1.6, (50000, 3))            # one 16 x 16 column of 0.1 m cells
+    b = rng.uniform(3.2, 3.3, (20000, 3))            # one voxel column, ~1 cell wide
+    pts = np.concatenate([a, b, rng.uniform(0, 6.4, (3000, 3))]).astype(np.float32)
+    pts = np.concatenate([pts, rng.uniform(0, 1, (len(pts), 2)).astype(np.float32)], 1)
+    rng.shuffle(pts)
+    vs, cr = [0.1, 0.1, 0.1], [0.0, 0.0, 0.0, 6.4, 6.4, 6.4]   # grid 64 x 64 x 64: nsz = 2
+    for mp, mv in [(5, 50000), (3, 700), (40, 50000)]:
+        _check_vs_oracle(dev, oracle_mod, pts, vs, cr, mp, mv)
+
+
+def test_batched_cap_and_break_per_scene(dev, oracle_mod, impl):
+    """The `break` (voxelization_cpu.cpp:78-79) is per scene: one scene of the batch hits max_voxels, the others do
+    not; scenes of very different sizes share the launches."""
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators import voxelize_batch
+
+    sizes = [50000, 700, 90000, 1, 12000]
+    scenes = [make_scene(900 + i, n_points=n)[0][:n] for i, n in enumerate(sizes)]
+    mv = 15000
+    out = voxelize_batch([torch.from_numpy(s).to(dev) for s in scenes], VOXEL_SIZE, PC_RANGE, 5, mv)
+    base = 0
+    for b, s in enumerate(scenes):
+        ev, ec, en = oracle_mod.hard_voxelize(s, VOXEL_SIZE, PC_RANGE, 5, mv)
+        m = out["num_voxels"][b]
+        assert m == ev.shape[0]
+        sl = slice(base, base + m)
+        assert np.array_equal(out["voxels"][sl].cpu().numpy(), ev)
+        assert np.array_equal(out["coordinates"][sl].cpu().numpy()[:, 1:], ec)
+        assert np.array_equal(out["num_points_per_voxel"][sl].cpu().numpy(), en)
+        base += m
+    assert out["num_voxels"][0] == mv and out["num_voxels"][2] == mv and out["num_voxels"][1] < mv
+
+
+def test_full_size_both_implementations_agree(dev, impl, oracle_mod):
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+
+    pts, _, _ = make_scene(2024, n_points=720000, n_sweeps=4)
+    _check_vs_oracle(dev, oracle_mod, pts, VOXEL_SIZE, PC_RANGE, 5, 200000)
