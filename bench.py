@@ -76,6 +76,18 @@ def _pmc_traffic(kernel):
         return None, None
 
 
+def _pmc_prefix(prefix):
+    """(sum of HBM bytes per launch, names) over the kernels of profiles/pmc_latest.json whose name starts with `prefix`
+    (one launch of each per call), or (None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            kernels = json.load(f)["kernels"]
+        hit = {k: v["hbm_bytes_per_launch"] for k, v in kernels.items() if k.startswith(prefix)}
+        return (sum(hit.values()), sorted(hit)) if hit else (None, None)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(args):
     """Host-core baseline on the GPU box (bounded: ~20-30 s), same scene size as the GPU workload:
       * value: the whole train step (fwd + bwd + AdamW) on ONE `--points`-point scene with the ORACLE standing in for
@@ -403,13 +415,13 @@ def main():
                                              "standalone_frac_of_8TBps": round(nbytes / us / 1e3 / 8000.0, 4)})
             except Exception as exc:  # accounting only
                 line["voxelize_hbm"]["standalone_error"] = str(exc)
-            # counter traffic of the call's five kernels (profiles/pmc_latest.json, same PMC passes as roofline.traffic)
-            vk = ("vox_insert_kernel", "vox_count_kernel", "vox_assign_kernel", "vox_cascade_kernel", "vox_gather_kernel")
-            tr_b = [_pmc_traffic(k)[0] for k in vk]
-            if all(t is not None for t in tr_b):
+            # counter traffic of the call's kernels (every `vox_*` kernel of profiles/pmc_latest.json: the same PMC passes as
+            # roofline.traffic; the one memset of the call -- ~1 MB of counters -- is not an efg kernel and is left out)
+            tr_b, names = _pmc_prefix("vox_")
+            if tr_b is not None:
                 alg = sum(v["bytes"] for v in vox.values()) / max(sum(v["launches"] for v in vox.values()), 1)
-                line["voxelize_hbm"].update({"traffic_bytes_per_call": round(sum(tr_b)), "alg_bytes_per_call": round(alg),
-                                             "traffic_ratio": round(sum(tr_b) / max(alg, 1.0), 2)})
+                line["voxelize_hbm"].update({"traffic_bytes_per_call": round(tr_b), "alg_bytes_per_call": round(alg),
+                                             "traffic_ratio": round(tr_b / max(alg, 1.0), 2), "traffic_kernels": names})
         try:
             line["geometry"] = _geometry_report(trainer, pool[0])
         except Exception as exc:  # accounting only

@@ -239,6 +239,30 @@ box_loss_grad_kernel(const float* __restrict__ boxes, const float* __restrict__ 
   for (int k = 0; k < 7; ++k) gboxes[row + k] = g[k];
 }
 
+
+// ---- iterative box refinement of the detection heads ($CQ/heads.py:76-79, $CQ/transformer.py:60-81) -----------------
+//   out = sigmoid(delta + inverse_sigmoid(anchor)),  inverse_sigmoid(x) = log(max(clamp(x, 0, 1), eps) / max(1 - clamp(x, 0, 1), eps))
+// ($CQ/modules/utils.py:83-87, eps = 1e-5).  The anchors are detached reference windows: only `delta` has a gradient,
+// d out / d delta = out (1 - out).  PyTorch runs this as clamp, clamp, rsub, clamp, div, log, add, sigmoid (8 launches
+// forward, 3 backward) on a few thousand numbers, seven times per step.
+__global__ void __launch_bounds__(256) box_refine_fwd_kernel(const float* __restrict__ delta, const float* __restrict__ anchor,
+                                                              long long n, float eps, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = fminf(fmaxf(anchor[i], 0.0f), 1.0f);
+  const float x1 = fmaxf(x, eps), x2 = fmaxf(__fsub_rn(1.0f, x), eps);
+  const float s = __fadd_rn(delta[i], logf(__fdiv_rn(x1, x2)));
+  out[i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-s)));
+}
+
+__global__ void __launch_bounds__(256) box_refine_bwd_kernel(const float* __restrict__ grad, const float* __restrict__ out,
+                                                              long long n, float* __restrict__ gdelta) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float y = out[i];
+  gdelta[i] = __fmul_rn(__fmul_rn(grad[i], __fsub_rn(1.0f, y)), y);   // sigmoid_backward: grad * (1 - y) * y
+}
+
 }  // namespace
 }  // namespace efg
 
@@ -306,6 +330,25 @@ extern "C" int efg_box_loss_backward_f32(const float* boxes, const float* tgt_bo
   hipLaunchKernelGGL(box_loss_grad_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, boxes,
                      tgt_boxes, (const long long*)l_idx, (const long long*)b_idx, (const long long*)q_idx,
                      (const long long*)g_idx, (long long)n, b, q, g, denom, grad_out, grad_boxes);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_box_refine_forward_f32(const float* delta, const float* anchor, int64_t n, float eps, float* out,
+                                          void* stream) {
+  EFG_CHECK_ARG(n >= 0 && (n == 0 || (delta && anchor && out)), "box_refine: bad arguments");
+  if (n == 0) return EFG_OK;
+  hipLaunchKernelGGL(box_refine_fwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, delta, anchor,
+                     (long long)n, eps, out);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_box_refine_backward_f32(const float* grad, const float* out, int64_t n, float* grad_delta, void* stream) {
+  EFG_CHECK_ARG(n >= 0 && (n == 0 || (grad && out && grad_delta)), "box_refine backward: bad arguments");
+  if (n == 0) return EFG_OK;
+  hipLaunchKernelGGL(box_refine_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad, out,
+                     (long long)n, grad_delta);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

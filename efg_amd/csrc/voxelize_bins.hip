@@ -11,10 +11,10 @@
 //   K1 bin_count   a workgroup stages a 1024-point tile in LDS with 16-byte coalesced loads, computes each point's
 //                  supercell (8 x 8 x <=40 cells), aggregates the tile's points per supercell in an LDS hash table and
 //                  reserves their places with ONE returning atomic per (tile, supercell) -- on a counter PRIVATE TO
-//                  THE XCD the workgroup runs on (count[supercell][xcd]), so the atomic is executed in that XCD's L2.
+//                  THE XCD the workgroup runs on (count[xcd][supercell]), so the atomic is executed in that XCD's L2.
 //                  (A device-scope atomic is executed past the L2s, at the memory side: the ~90k group atomics of a
 //                  2 x 180k-point call took 35 us of a 44 us kernel, `scripts/vox_timeline.py`.)
-//   K2 bin_scan    exclusive scan over the count[supercell][xcd] array (8192 counters per workgroup, chunk totals
+//   K2 bin_scan    exclusive scan over the count[xcd][supercell] array (1024 supercells per workgroup, chunk totals
 //                  chained by decoupled look-back): the place of every (supercell, xcd) group -- a supercell's eight
 //                  groups are adjacent, so a bin is one contiguous range -- plus the two work lists of K4 / K5
 //                  (bins of <= 256 points, bins above).
@@ -46,7 +46,7 @@ constexpr int kSmall = 256;            // bins up to this many points are handle
 constexpr int kSmallT = 512;           // hash slots of a wave's bin
 constexpr int kAggSlots = 2048;        // LDS hash slots of the per-tile aggregation in K1
 constexpr int kXcd = 8;                // XCDs of an MI355X: one private counter per supercell and XCD
-constexpr int kScanChunk = 8192;       // counters per workgroup of K2 (256 threads x 32 = 4 supercells per thread)
+constexpr int kScanChunk = 1024;       // supercells per workgroup of K2 (256 threads x 4, eight counters each)
 constexpr int kItemGrid = 1024;        // workgroups of K4 / K5 over all scenes (each loops over the bins)
 constexpr unsigned kNone = 0xffffffffu;
 
@@ -132,7 +132,8 @@ vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords 
   const long long row0 = beg + (long long)blockIdx.x * kTile;
   const int nrows = (int)max(0ll, min((long long)kTile, end - row0));
   const unsigned xcd = xcd_id();
-  unsigned* cnt_x = count + (size_t)scene * bg.s_stride * kXcd + xcd;  // [supercell][xcd]
+  // [xcd][supercell]: an XCD's counters are its own contiguous range -- no cache line is shared between two XCDs' L2s
+  unsigned* cnt_x = count + ((size_t)scene * kXcd + xcd) * bg.s_stride;
   if (tid < kTile / 32) {  // this tile's words of the first-point bitmap start empty
     const int w = sw.wb[scene] + blockIdx.x * (kTile / 32) + tid;
     if (w < sw.wb[scene + 1]) bits[w] = 0u;
@@ -179,7 +180,7 @@ vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords 
 #pragma unroll
     for (int i = 0; i < kAggSlots / 256; ++i) {
       const int sl = tid + 256 * i;
-      r[i] = hkey[sl] != kNone ? __hip_atomic_fetch_add(cnt_x + (size_t)hkey[sl] * kXcd, hcnt[sl], __ATOMIC_RELAXED,
+      r[i] = hkey[sl] != kNone ? __hip_atomic_fetch_add(cnt_x + hkey[sl], hcnt[sl], __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_WORKGROUP)
                                : 0u;
     }
@@ -207,25 +208,31 @@ vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ co
   mark(dbg, 1, 0);
   const int scene = blockIdx.y, tid = threadIdx.x, chunk = blockIdx.x;
   const size_t xbase = (size_t)scene * bg.s_stride * kXcd;
-  const int e0 = chunk * kScanChunk + tid * 32;          // first counter of this thread: supercells e0 / 8 .. + 3
-  const int ne = bg.s_stride * kXcd;
-  uint4 v[8];
+  const int sc0 = chunk * kScanChunk + tid * 4;           // this thread's four supercells
+  uint4 v[kXcd];                                          // v[x] = counters of XCD x for supercells sc0 .. sc0 + 3
   int sum = 0, ns = 0, nb = 0;
   unsigned tot[4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
-    v[q] = e0 + q * 4 < ne ? *reinterpret_cast<const uint4*>(count + xbase + e0 + q * 4) : make_uint4(0, 0, 0, 0);
+  for (int x = 0; x < kXcd; ++x)
+    v[x] = sc0 < bg.s_stride ? *reinterpret_cast<const uint4*>(count + xbase + (size_t)x * bg.s_stride + sc0)
+                             : make_uint4(0, 0, 0, 0);
+  tot[0] = tot[1] = tot[2] = tot[3] = 0u;
+#pragma unroll
+  for (int x = 0; x < kXcd; ++x) {
+    tot[0] += v[x].x;
+    tot[1] += v[x].y;
+    tot[2] += v[x].z;
+    tot[3] += v[x].w;
+  }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    tot[b] = v[2 * b].x + v[2 * b].y + v[2 * b].z + v[2 * b].w + v[2 * b + 1].x + v[2 * b + 1].y + v[2 * b + 1].z +
-             v[2 * b + 1].w;
     sum += (int)tot[b];
     ns += (tot[b] > 0u && tot[b] <= (unsigned)kSmall) ? 1 : 0;
     nb += (tot[b] > (unsigned)kSmall) ? 1 : 0;
   }
   int csum, clist;
   const int psum = block_exclusive_scan(sum, smem, &csum);
-  const int plist = block_exclusive_scan(ns | (nb << 15), smem, &clist);   // <= 1024 supercells per chunk: 15 bits each
+  const int plist = block_exclusive_scan(ns | (nb << 15), smem, &clist);   // 1024 supercells per chunk: 15 bits each
   unsigned long long* part_s = part + (size_t)scene * nchunks;
   if (tid == 0)  // publish this chunk's totals at once; nothing has been waited for
     __hip_atomic_store(part_s + chunk, (1ull << 63) | ((unsigned long long)(unsigned)csum << 30) | (unsigned)clist,
@@ -269,9 +276,11 @@ vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ co
   int pb = (int)(unsigned)(prl >> 32) + (plist >> 15);
   uint4* small_s = small_list + (size_t)scene * bg.s_stride;
   uint4* big_s = big_list + (size_t)scene * bg.s_stride;
+  unsigned start[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    const int sc = e0 / kXcd + b;
+    const int sc = sc0 + b;
+    start[b] = run;
     if (sc < bg.s_scene) {
       // one 16-byte record per bin {supercell, first place, points}: K4 / K5 read everything they need in ONE load
       if (tot[b] > (unsigned)kSmall)
@@ -279,19 +288,16 @@ vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ co
       else if (tot[b] > 0u)
         small_s[ps++] = make_uint4((unsigned)sc, run, tot[b], 0u);
     }
-    uint4 o0, o1;
-    o0.x = run;
-    o0.y = o0.x + v[2 * b].x;
-    o0.z = o0.y + v[2 * b].y;
-    o0.w = o0.z + v[2 * b].z;
-    o1.x = o0.w + v[2 * b].w;
-    o1.y = o1.x + v[2 * b + 1].x;
-    o1.z = o1.y + v[2 * b + 1].y;
-    o1.w = o1.z + v[2 * b + 1].z;
-    run = o1.w + v[2 * b + 1].w;
-    if (e0 + b * 8 < ne) {
-      *reinterpret_cast<uint4*>(basex + xbase + e0 + b * 8) = o0;
-      *reinterpret_cast<uint4*>(basex + xbase + e0 + b * 8 + 4) = o1;
+    run += tot[b];
+  }
+  if (sc0 < bg.s_stride) {   // the place of every (supercell, xcd) group: a bin's eight groups are adjacent
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) {
+      *reinterpret_cast<uint4*>(basex + xbase + (size_t)x * bg.s_stride + sc0) = make_uint4(start[0], start[1], start[2], start[3]);
+      start[0] += v[x].x;
+      start[1] += v[x].y;
+      start[2] += v[x].z;
+      start[3] += v[x].w;
     }
   }
   if (chunk == nchunks - 1 && tid == 255) {  // (the last thread's running list positions are the scene's totals)
@@ -338,7 +344,7 @@ vox_bin_scatter_kernel(const float* __restrict__ pts, SceneOffsets so, int f, Vo
       cell_of(r[0], r[1], r[2], g, cx, cy, cz);  // same arithmetic as K1: same bin
       unsigned sc;
       bin_of(cx, cy, cz, bg, sc, lcs[j]);
-      dst[j] = (size_t)basex_s[(size_t)sc * kXcd + (pv[j] >> 28)] + (pv[j] & 0x0fffffffu);
+      dst[j] = (size_t)basex_s[(size_t)(pv[j] >> 28) * bg.s_stride + sc] + (pv[j] & 0x0fffffffu);
     }
   }
 #pragma unroll
@@ -405,30 +411,52 @@ vox_first_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, const uint4* __rest
       const unsigned p = rec.z, b = rec.y;
       for (int c = tid; c < bg.cells; c += 256) tab[c] = kNone;
       __syncthreads();
-      // (four loads in flight per thread: one at a time the loop is a chain of L2 round trips, P / 256 of them)
-      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
-        uint2 m[4];
+      if (p <= 8 * 256) {
+        // the bin's points stay in registers between the two passes (8 loads in flight, one round trip)
+        uint2 m[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+        for (int j = 0; j < 8; ++j) m[j] = tid + 256 * j < p ? meta[b + tid + 256 * j] : make_uint2(kNone, 0u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 8; ++j)
           if (m[j].x != kNone) atomicMin(&tab[m[j].y], m[j].x);
-      }
-      __syncthreads();
-      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
-        uint2 m[4];
+        __syncthreads();
+        unsigned old[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
-        unsigned old[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           old[j] = 0u;
           if (m[j].x != kNone && tab[m[j].y] == m[j].x) {
             const unsigned jj = m[j].x - beg;
             old[j] = atomicOr(&bits_s[jj >> 5], 1u << (jj & 31));
           }
         }
-        sink |= old[0] | old[1] | old[2] | old[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sink |= old[j];
+      } else {
+        // (four loads in flight per thread: one at a time the loop is a chain of L2 round trips, P / 256 of them)
+        for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+          uint2 m[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (m[j].x != kNone) atomicMin(&tab[m[j].y], m[j].x);
+        }
+        __syncthreads();
+        for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+          uint2 m[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+          unsigned old[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            old[j] = 0u;
+            if (m[j].x != kNone && tab[m[j].y] == m[j].x) {
+              const unsigned jj = m[j].x - beg;
+              old[j] = atomicOr(&bits_s[jj >> 5], 1u << (jj & 31));
+            }
+          }
+          sink |= old[0] | old[1] | old[2] | old[3];
+        }
       }
       __syncthreads();
     } else {
@@ -711,13 +739,23 @@ vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, cons
       const unsigned sc = rec.x, p = rec.z, b = rec.y;
       for (int c = tid; c < bg.cells; c += 256) tab[c] = 0u;
       __syncthreads();
-      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
-        uint2 m[4];
+      const bool in_reg = p <= 4 * 256;   // the bin's points stay in registers between the count and the scatter pass
+      uint2 mr[4];
+      if (in_reg) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+        for (int j = 0; j < 4; ++j) mr[j] = tid + 256 * j < p ? meta[b + tid + 256 * j] : make_uint2(kNone, 0u);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (m[j].x < ib) atomicAdd(&tab[m[j].y], 1u);   // (kNone >= ib always)
+          if (mr[j].x < ib) atomicAdd(&tab[mr[j].y], 1u);   // (kNone >= ib always)
+      } else {
+        for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+          uint2 m[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (m[j].x < ib) atomicAdd(&tab[m[j].y], 1u);
+        }
       }
       __syncthreads();
       int nvox;
@@ -744,16 +782,27 @@ vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, cons
       const bool in_lds = p <= (unsigned)kSegLds;
       unsigned* si = in_lds ? seg_lds : seg_idx_g + b;
       unsigned* se = in_lds ? seg_lds + kSegLds : seg_e_g + b;
-      for (unsigned e0 = tid; e0 < p; e0 += 1024) {
-        uint2 m[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+      if (in_reg) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (m[j].x < ib) {
-            const unsigned q = atomicAdd(&tab[m[j].y], 1u);  // afterwards tab[c] = END of cell c = start of cell c + 1
-            si[q] = m[j].x;
-            se[q] = e0 + 256 * j;
+          if (mr[j].x < ib) {
+            const unsigned q = atomicAdd(&tab[mr[j].y], 1u);  // afterwards tab[c] = END of cell c = start of cell c + 1
+            si[q] = mr[j].x;
+            se[q] = tid + 256 * j;
+          }
+        }
+      } else {
+        for (unsigned e0 = tid; e0 < p; e0 += 1024) {
+          uint2 m[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = e0 + 256 * j < p ? meta[b + e0 + 256 * j] : make_uint2(kNone, 0u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (m[j].x < ib) {
+              const unsigned q = atomicAdd(&tab[m[j].y], 1u);
+              si[q] = m[j].x;
+              se[q] = e0 + 256 * j;
+            }
           }
         }
       }
@@ -857,7 +906,7 @@ bool bins_layout(int64_t n_total, int batch, int f, const VoxGeom& g, BinsLayout
   if (L->s_total > (size_t)std::max<int64_t>(1 << 18, 8 * n_total) || L->s_total > (1u << 22)) return false;
   if (n_total >= (1ll << 28)) return false;
   L->rs = (f + 3) / 4 * 4;
-  L->nchunks = (int)ceil_div((int64_t)L->bg.s_stride * kXcd, kScanChunk);
+  L->nchunks = (int)ceil_div((int64_t)L->bg.s_stride, kScanChunk);
   L->n = std::max<int64_t>(n_total, 1);
   return true;
 }
@@ -950,7 +999,9 @@ int bins_hard_voxelize(const HardArgs& a) {
   const int64_t items_ub = std::min<int64_t>(L.bg.s_scene, std::max<int64_t>(a.max_scene, 1));
   // as many workgroups as are resident at once (4 per CU x 256 CUs), shared by the scenes of the batch
   const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(items_ub, std::max(256, kItemGrid / batch)));
-  hipLaunchKernelGGL(vox_first_kernel, dim3(gx, batch), blk, 0, stream, so, sw, L.bg, small_list, big_list,
+  // (K4 is light -- 16 KB of LDS, 53 VGPRs, 8 workgroups per CU: every bin gets its own workgroup up to 2048 of them)
+  const int gx4 = (int)std::max<int64_t>(1, std::min<int64_t>(items_ub, std::max(256, 2 * kItemGrid / batch)));
+  hipLaunchKernelGGL(vox_first_kernel, dim3(gx4, batch), blk, 0, stream, so, sw, L.bg, small_list, big_list,
                      nlist, meta, bits, prefix, ticket, a.voxel_num, i_break, a.max_voxels, g_dbg);
   EFG_LAUNCH_CHECK();
   if (a.n_total > 0) {

@@ -6,7 +6,8 @@ from torch import nn
 
 from .losses import Det3DLoss
 from .matcher import HungarianMatcher3d
-from .utils import MLP, get_clones, inverse_sigmoid
+from ..operators.det_loss import box_refine
+from .utils import MLP, get_clones
 
 
 def accuracy(output, target):
@@ -45,14 +46,13 @@ class Det3DHead(nn.Module):
 
     def forward(self, embed, anchors, layer_idx=0):
         cls_logits = self.class_embed[layer_idx](embed)
-        box_coords = (self.bbox_embed[layer_idx](embed) + inverse_sigmoid(anchors)).sigmoid()
+        box_coords = box_refine(self.bbox_embed[layer_idx](embed), anchors)   # (delta + inverse_sigmoid(anchors)).sigmoid()
         return cls_logits, box_coords
 
     def compute_losses(self, outputs, targets, dn_meta=None):
-        loss_dict = self.losses(outputs, targets, dn_meta=dn_meta)
-        for k, v in loss_dict.items():
-            if k in self.losses.weight_dict:  # note: *_dn / *_dn_i keys are not in the dict -> weight 1 (reference)
-                loss_dict[k] = v * self.losses.weight_dict[k]
+        # weighted in the loss module, all terms in one multiply (*_dn / *_dn_i keys are not in the dict -> weight 1, as in
+        # the reference's loop over weight_dict)
+        loss_dict = self.losses(outputs, targets, dn_meta=dn_meta, weights=self.losses.weight_dict)
         if self.with_metrics:
             with torch.no_grad():
                 loss_dict["accuracy"] = accuracy(*self.losses.get_target_classes())

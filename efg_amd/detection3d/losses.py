@@ -22,6 +22,38 @@ def get_world_size():
                                                   and torch.distributed.is_initialized()) else 1
 
 
+class LossDict(dict):
+    """The model's loss dictionary (same keys and values as the reference's: one scalar tensor per term) plus the
+    VECTORS the scalars are views of.  `total()` sums the vectors: a backward that starts from it never touches the
+    ~32 select nodes of the scalar entries (each a zero-fill + copy launch pair in backward), which a
+    `sum(loss_dict.values())` as in efg/engine/trainer.py:296-297 would.  Both give the same value up to fp32
+    summation order; a trainer that does not know `total()` keeps working."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.vectors = []          # 1-D tensors covering every differentiable entry exactly once
+
+    def add_vector(self, keys, vec):
+        """Register `vec` [len(keys)] and expose vec[i] under keys[i]."""
+        self.vectors.append(vec)
+        for i, k in enumerate(keys):
+            self[k] = vec[i]
+
+    def merge(self, other, suffix=""):
+        for k, v in other.items():
+            self[k + suffix] = v
+        self.vectors.extend(getattr(other, "vectors", []))
+        return self
+
+    def total(self):
+        vs = [v for v in self.vectors if v.requires_grad]
+        covered = sum(v.numel() for v in vs)
+        n_diff = sum(1 for v in self.values() if torch.is_tensor(v) and v.requires_grad)
+        if not vs or covered != n_diff:   # entries added outside add_vector: fall back to the generic sum
+            return torch.stack([v for v in self.values() if torch.is_tensor(v) and v.requires_grad]).sum()
+        return (vs[0] if len(vs) == 1 else torch.cat(vs)).sum()
+
+
 class PaddedTargets(list):
     """The per-scene target dicts (a plain list, as the reference passes them) that also carries the padded batch
     form built once on the host: labels [B,G] (0 padded), boxes [B,G,7], counts (host list).  Every dict's
@@ -104,7 +136,8 @@ class Det3DLoss(nn.Module):
             out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
         return out, cls
 
-    def forward(self, outputs, targets, dn_meta=None):
+    def forward(self, outputs, targets, dn_meta=None, weights=None):
+        """`weights`: {key: coefficient} applied to the terms in one multiply (None: unweighted terms)."""
         dev = outputs["pred_logits"].device
         n_gt = sum(len(t["labels"]) for t in targets)
         if get_world_size() > 1:
@@ -157,12 +190,12 @@ class Det3DLoss(nn.Module):
             cls = cls[-n_gt:] if n_gt else cls[:0]
         self._metric_classes = cls
 
-        losses = {}
+        # every family is an [L] vector (aux layers first, the final layer last): the scalar entries are views of it
+        fam_keys, fam_vecs = [], []
         n_aux = len(layers) - 1
         for k, v in per_layer.items():
-            for i in range(n_aux):
-                losses[k + f"_{i}"] = v[i]
-            losses[k] = v[n_aux]
+            fam_keys.append([k + f"_{i}" for i in range(n_aux)] + [k])
+            fam_vecs.append(v)
 
         if dn_meta is not None:
             known = dn_meta["output_known_lbs_bboxes"]
@@ -190,7 +223,22 @@ class Det3DLoss(nn.Module):
             dn_per_layer, _ = self._layer_losses(dn_logits, dn_boxes, tuple(sel_dn), tgt_labels, tgt_boxes,
                                                  num_boxes * scalar)
             for k, v in dn_per_layer.items():
-                for i in range(nl - 1):
-                    losses[k + f"_dn_{i}"] = v[i]
-                losses[k + "_dn"] = v[nl - 1]
-        return losses
+                fam_keys.append([k + f"_dn_{i}" for i in range(nl - 1)] + [k + "_dn"])
+                fam_vecs.append(v)
+        # ONE weighted vector for all terms of this head: weight_dict per key, 1 for keys it does not name (the *_dn terms,
+        # as in the reference: heads.py compute_losses only scales keys found in the dict)
+        keys = [k for ks in fam_keys for k in ks]
+        vec = torch.cat(fam_vecs) if len(fam_vecs) > 1 else fam_vecs[0]
+        if weights is not None:
+            w = self._weight_vector(tuple(keys), weights, vec.device)
+            vec = vec * w
+        out = LossDict()
+        out.add_vector(keys, vec)
+        return out
+
+    def _weight_vector(self, keys, weights, device):
+        cache = self.__dict__.setdefault("_wvec", {})
+        ent = cache.get((keys, device))
+        if ent is None:
+            ent = cache[(keys, device)] = torch.tensor([float(weights.get(k, 1.0)) for k in keys], dtype=torch.float32).to(device)
+        return ent

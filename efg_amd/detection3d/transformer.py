@@ -11,6 +11,7 @@ from torch.autograd.profiler import record_function
 from torch.nn import functional as F
 
 from ..operators import attention
+from ..operators.det_loss import box_refine
 from ..operators.layernorm import add_layer_norm
 from ..operators.linear import Linear, linear
 from .box_attention import Box3dAttention
@@ -188,7 +189,7 @@ class Transformer(nn.Module):
         topk_probs, indexes = topk_probs.unsqueeze(-1), indexes.unsqueeze(-1)
         emb_k = torch.gather(enc_embed, 1, indexes.expand(-1, -1, enc_embed.shape[-1]))
         ref_k = torch.gather(ref_windows, 1, indexes.expand(-1, -1, ref_windows.shape[-1]))
-        boxes_k = (head.bbox_embed[0](emb_k) + inverse_sigmoid(ref_k)).sigmoid()
+        boxes_k = box_refine(head.bbox_embed[0](emb_k), ref_k)   # (delta + inverse_sigmoid(ref_k)).sigmoid()
         self.enc_outputs = {"pred_logits": out_logits, "topk_boxes": boxes_k, "topk_indexes": indexes}
         out_ref_windows = torch.cat((boxes_k.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
         return None, None, out_ref_windows, indexes

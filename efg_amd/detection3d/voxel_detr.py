@@ -35,7 +35,7 @@ from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
 from .heads import Det3DHead
-from .losses import PaddedTargets
+from .losses import LossDict, PaddedTargets
 from .position_encoding import build_position_encoding
 from .transformer import Transformer
 
@@ -265,7 +265,7 @@ class VoxelDETR(nn.Module):
 
     def _losses(self, outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes):
         head = self.transformer.decoder.detection_head
-        losses = {}
+        losses = LossDict()
         # encoder proposal losses (class-agnostic), voxel_detr.py:198-209
         bin_targets = targets.class_agnostic() if isinstance(targets, PaddedTargets) else copy.deepcopy(targets)
         if not isinstance(targets, PaddedTargets):
@@ -273,16 +273,16 @@ class VoxelDETR(nn.Module):
                 tgt["labels"].fill_(0)
         enc_outputs = dict(self.transformer.enc_outputs)  # class logits of all tokens + boxes of the top-k (one evaluation)
         enc_losses = self.transformer.proposal_head.compute_losses(enc_outputs, bin_targets)
-        losses.update({k + "_enc": v for k, v in enc_losses.items()})
+        losses.merge(enc_losses, "_enc")
         nq = self.num_queries
         outputs = {"pred_logits": outputs_class[-1][:, :nq], "pred_boxes": outputs_coord[-1][:, :nq],
                    "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
         with record_function("efg::losses.decoder"):
-            losses.update(head.compute_losses(outputs, targets, dn_meta))
+            losses.merge(head.compute_losses(outputs, targets, dn_meta))
         if self.is_conquer:
             with record_function("efg::losses.contrastive"):
-                losses.update(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
-                                                       targets, dn_meta))
+                losses.merge(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
+                                                      targets, dn_meta))
         return losses
 
     def _contrastive_losses(self, outputs_class, outputs_coord, query_of_gt, targets, dn_meta):
@@ -291,7 +291,7 @@ class VoxelDETR(nn.Module):
         log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau.  All layers and
         scenes are evaluated together (the reference runs a Python loop per layer, scene and pair).
         query_of_gt: int64 [B, G] on the device, the last layer's assignment (matcher.match_layers)."""
-        out = {}
+        out = LossDict()
         per_gt = [t["gt_boxes"].shape[0] for t in targets]
         max_gt, num_gts = max(per_gt), sum(per_gt)
         if num_gts == 0 or dn_meta is None:
@@ -323,8 +323,8 @@ class VoxelDETR(nn.Module):
         pos = sim.gather(3, q_idx[None, :, None, None].expand(n_layers, n, groups, 1))
         neg = (torch.exp(sim) * neg_mask[b_idx][None, :, None, :]).sum(dim=-1, keepdim=True)
         per_layer = (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(2, 3)).sum(dim=1)      # [L]
-        for li in range(n_layers):
-            out[f"loss_contrastive_dec_{li}"] = self.contras_loss_coeff * per_layer[li] / num_gts
+        out.add_vector([f"loss_contrastive_dec_{li}" for li in range(n_layers)],
+                       per_layer * (self.contras_loss_coeff / num_gts))
         return out
 
     def _inference(self, outputs_class, outputs_coord):

@@ -518,8 +518,13 @@ class Trainer:
             self.grad_sync.begin_step()
         with record_function("efg::forward"):
             loss_dict = self.wrapped(batch)
-            # one stack + sum instead of 31 chained scalar adds (and as many backward nodes)
-            losses = torch.stack([v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad]).sum()
+            if hasattr(loss_dict, "total"):
+                # detection3d.losses.LossDict: the terms are views of a few vectors; summing the vectors keeps the
+                # ~32 select nodes of the scalar entries (a zero-fill + copy each in backward) out of the graph
+                losses = loss_dict.total()
+            else:
+                # one stack + sum instead of 31 chained scalar adds (and as many backward nodes)
+                losses = torch.stack([v for v in loss_dict.values() if torch.is_tensor(v) and v.requires_grad]).sum()
         if losses.device.type == "cpu":
             if not bool(torch.isfinite(losses)):   # the reference's check (trainer.py:307-311); free on the host
                 raise FloatingPointError("Loss became infinite or NaN at iteration=%d!" % self._steps)

@@ -1,5 +1,7 @@
 """Fused detection-loss ops over libefg_hip.so (csrc/det_loss.hip): the matching cost and the per-layer focal /
 box losses of $CQ/modules/matcher.py:40-80 and $CQ/losses.py:26-108, one kernel per family and direction."""
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -81,3 +83,35 @@ class BoxLossLayers(Function):
                                                   L.ptr(g_idx), l_idx.numel(), n_layers, b, q, tb.shape[1], L.ptr(denom),
                                                   L.ptr(grad_out.contiguous()), L.ptr(grad), L.stream()))
         return grad, None, None, None, None, None, None
+
+
+class BoxRefineFunction(Function):
+    """sigmoid(delta + inverse_sigmoid(anchor)) in one launch each way (csrc/det_loss.hip); `anchor` carries no gradient
+    (the reference detaches the reference windows between layers, $CQ/transformer.py:331-336)."""
+
+    @staticmethod
+    def forward(ctx, delta, anchor, eps):
+        d, a = delta.contiguous(), anchor.contiguous()
+        out = torch.empty_like(d)
+        L.check(L.lib().efg_box_refine_forward_f32(L.ptr(d), L.ptr(a), d.numel(), float(eps), L.ptr(out), L.stream()))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        (out,) = ctx.saved_tensors
+        g = grad.contiguous()
+        gd = torch.empty_like(out)
+        L.check(L.lib().efg_box_refine_backward_f32(L.ptr(g), L.ptr(out), out.numel(), L.ptr(gd), L.stream()))
+        return gd, None, None
+
+
+def box_refine(delta, anchor, eps=1e-5):
+    """(delta + inverse_sigmoid(anchor)).sigmoid() -- $CQ/heads.py:78.  GPU fp32 tensors of equal shape whose anchor needs
+    no gradient take the fused kernel; anything else the PyTorch formulation (same math)."""
+    if (delta.is_cuda and delta.dtype == torch.float32 and anchor.dtype == torch.float32 and delta.shape == anchor.shape
+            and not anchor.requires_grad and os.environ.get("EFG_FUSED_LOSS", "1") != "0"):
+        return BoxRefineFunction.apply(delta, anchor, eps)
+    x = anchor.clamp(min=0, max=1)
+    return (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()

@@ -463,6 +463,12 @@ int efg_box_loss_backward_f32(const float* boxes, const float* tgt_boxes, const 
                               const int64_t* q_idx, const int64_t* g_idx, int64_t n, int layers, int b, int q, int g,
                               const float* denom, const float* grad_out, float* grad_boxes, void* stream);
 
+/* Iterative box refinement of the detection heads ($CQ/heads.py:76-79, $CQ/transformer.py:60-81):
+ *   out = sigmoid(delta + inverse_sigmoid(anchor)), inverse_sigmoid as $CQ/modules/utils.py:83-87 (eps 1e-5);
+ * n elements, any shape.  Backward: grad_delta = grad * out * (1 - out) (the anchors are detached reference windows). */
+int efg_box_refine_forward_f32(const float* delta, const float* anchor, int64_t n, float eps, float* out, void* stream);
+int efg_box_refine_backward_f32(const float* grad, const float* out, int64_t n, float* grad_delta, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d (training statistics) + optional residual + optional ReLU over sparse features [m, c]
  * (the norm / activation steps of efg/modeling/backbones/sparse_net.py:85-95,120-165, which the reference runs as

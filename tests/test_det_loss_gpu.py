@@ -100,3 +100,27 @@ def test_box_loss_layers():
     (ref * w).sum().backward()
     torch.testing.assert_close(out, ref, rtol=2e-5, atol=1e-6)
     _close(g_fused, boxes.grad, "grad boxes")
+
+
+def test_box_refine_matches_the_reference_formulation():
+    dev = torch.device("cuda:0")
+    """sigmoid(delta + inverse_sigmoid(anchor)) ($CQ/heads.py:78, $CQ/modules/utils.py:83-87) in one launch each way,
+    incl. anchors outside [0, 1] and at the eps clamps."""
+    from efg_amd.operators.det_loss import box_refine
+
+    g = torch.Generator().manual_seed(3)
+    delta = (torch.randn(2, 1240, 7, generator=g) * 3).to(dev).requires_grad_(True)
+    anchor = torch.rand(2, 1240, 7, generator=g)
+    anchor[0, :7, 0] = torch.tensor([0.0, 1.0, -0.3, 1.7, 1e-6, 1 - 1e-6, 0.5])
+    anchor = anchor.to(dev)
+    out = box_refine(delta, anchor)
+    x = anchor.clamp(min=0, max=1)
+    d2 = delta.detach().clone().requires_grad_(True)
+    ref = (d2 + torch.log(x.clamp(min=1e-5) / (1 - x).clamp(min=1e-5))).sigmoid()
+    torch.testing.assert_close(out, ref, rtol=2e-6, atol=2e-7)
+    w = torch.randn(out.shape, generator=g).to(dev)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(delta.grad, d2.grad, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():   # the momentum decoder's (graph-captured) use
+        torch.testing.assert_close(box_refine(delta, anchor), ref.detach(), rtol=2e-6, atol=2e-7)
