@@ -36,20 +36,19 @@ torch.cuda.synchronize()
 words = _lib.lib().efg_hard_voxelize_debug_timeline(None)
 buf = torch.zeros(words, dtype=torch.int64, device=dev)
 _lib.lib().efg_hard_voxelize_debug_timeline(_lib.ptr(buf))
-NAMES = {0: "bin_count", 1: "bin_scan", 2: "bin_scatter", 3: "first", 4: "write"}
+NAMES = {0: "bin_count", 1: "bin_scan", 2: "bin_scatter", 3: "first", 5: "rank", 4: "write"}
 MARK = {(0, 0): "start", (0, 1): "tile staged", (0, 2): "LDS aggregation", (0, 3): "group atomics + places",
         (1, 0): "start", (1, 1): "chunk published", (1, 2): "look-back", (1, 3): "end",
-        (2, 0): "start", (2, 1): "end", (3, 0): "start", (3, 1): "bin work", (3, 2): "ticket",
-        (3, 3): "last-WG tail", (4, 0): "start", (4, 1): "big: sorted", (4, 2): "big: written", (4, 3): "small: sorted",
+        (2, 0): "start", (2, 1): "end", (3, 0): "start", (3, 1): "bin work", (5, 0): "start", (5, 1): "end", (4, 0): "start", (4, 1): "big: sorted", (4, 2): "big: written", (4, 3): "small: sorted",
         (4, 4): "small: written"}
 for rep in range(3):
     buf.zero_()
     run()
     torch.cuda.synchronize()
-    t = buf.cpu().numpy().reshape(5, 8, -1)
+    t = buf.cpu().numpy().reshape(6, 8, -1)
     t0 = t[t > 0].min()
     print("--- call %d: %d scenes x %d points, %d voxels" % (rep, nb, n, int(num.sum())))
-    for k in range(5):
+    for k in (0, 1, 2, 3, 5, 4):
         for m in range(8):
             v = t[k, m]
             v = v[v > 0]
