@@ -45,6 +45,7 @@ _SIGS = {
     "efg_spconv_build_rnbr": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "efg_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "efg_spconv_pack_weight_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "efg_spconv_pack_weights_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "efg_spconv_forward_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
                                        c_void_p, c_void_p]),
     "efg_spconv_dgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p,

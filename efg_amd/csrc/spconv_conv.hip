@@ -38,8 +38,8 @@ __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 // packed[((k*R16 + r16)*NP + n)*16 + kk*4 + j] = W(red = r16*16 + 4*j + kk, n) for offset k,
 // where (red, n) = (ci, co) forward, (co, ci) dgrad; zero padded to multiples of 16.
 // for_dgrad bit 1 ("natural order", the 16-byte-gather tile kernel): red = r16*16 + 4*kk + j instead.
-__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin,
-                                                           int for_dgrad, float* __restrict__ packed) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, int cout, int kvol, int cin, int for_dgrad,
+                                                 float* __restrict__ packed, unsigned bid, unsigned nblk) {
   const int natural = for_dgrad & 2, bf3 = for_dgrad & 4;
   for_dgrad &= 1;
   const int red = for_dgrad ? cout : cin, nn = for_dgrad ? cin : cout;
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     bf16_t* out = reinterpret_cast<bf16_t*>(packed);
     const int c32n = red / 32, nt16 = nn / 16;
     const long long total = (long long)kvol * red * nn;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = (long long)bid * blockDim.x + threadIdx.x; e < total; e += (long long)nblk * blockDim.x) {
       const int n = (int)(e % nn);
       long long q = e / nn;
       const int r = (int)(q % red), k = (int)(q / red);
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
   const int r16n = round16(red) / 16, np = round16(nn);
   const long long total = (long long)kvol * r16n * np * 16;
   // (+ the slack row kernels with NT > tiles read past the last n-tile: written as zeros here, no separate memset)
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total + 16 * 256;
-       e += (long long)gridDim.x * blockDim.x) {
+  for (long long e = (long long)bid * blockDim.x + threadIdx.x; e < total + 16 * 256;
+       e += (long long)nblk * blockDim.x) {
     if (e >= total) {
       packed[e] = 0.0f;
       continue;
@@ -88,6 +88,23 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restric
     }
     packed[e] = v;
   }
+}
+
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ w, int cout, int kvol, int cin,
+                                                           int for_dgrad, float* __restrict__ packed) {
+  pack_weight_body(w, cout, kvol, cin, for_dgrad, packed, blockIdx.x, gridDim.x);
+}
+
+// Every packed copy a model needs, in ONE launch (blockIdx.y = item): the layers' weights change together -- at the
+// optimizer step -- so their MFMA-order copies are refreshed together instead of by two launches per convolution.
+struct PackItem {
+  const float* w;
+  float* packed;
+  int cout, kvol, cin, flags;
+};
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  pack_weight_body(it.w, it.cout, it.kvol, it.cin, it.flags, it.packed, blockIdx.x, gridDim.x);
 }
 
 // ---- forward / dgrad ------------------------------------------------------------------------
@@ -728,6 +745,16 @@ extern "C" int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvo
   const long long total = (long long)(bytes / sizeof(float));
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 4096)), dim3(256),
                      0, stream, weight, cout, kvol, cin, for_dgrad, packed);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+extern "C" int efg_spconv_pack_weights_multi(const void* items_dev, int n, void* stream) {
+  EFG_CHECK_ARG(n >= 0 && (n == 0 || items_dev), "pack_weights_multi: bad arguments");
+  static_assert(sizeof(PackItem) == 32, "PackItem is 2 pointers + 4 ints (the Python side writes it as 4 int64)");
+  if (n == 0) return EFG_OK;
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const PackItem*>(items_dev));
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

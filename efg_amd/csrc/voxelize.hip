@@ -39,10 +39,16 @@ int make_geom(const float* vs, const float* cr, VoxGeom* g, unsigned long long* 
   return EFG_OK;
 }
 
-// 0: binned (default), 1: hash.  Read per call (a getenv is nothing next to four launches): tests flip it in-process.
-int forced_impl() {
+// 1: hash, 0: binned.  EFG_VOX_IMPL=hash|bins forces one (read per call -- a getenv is nothing next to six launches --
+// so tests flip it in-process); otherwise by size: the binned path has a fixed cost (seven launches, a scan over every
+// supercell of the grid) that a small cloud does not amortise -- 16k points: 44 us against 31 us for the hash path,
+// 2 x 180k: 80 against 94, 8 x 180k: 181 against 288 (profiles/r04_vox_times.txt).
+constexpr int64_t kBinsMinPoints = 65536;
+int pick_impl(int64_t n_total) {
   const char* e = getenv("EFG_VOX_IMPL");
-  return (e && !strcmp(e, "hash")) ? 1 : 0;
+  if (e && !strcmp(e, "hash")) return 1;
+  if (e && !strcmp(e, "bins")) return 0;
+  return n_total < kBinsMinPoints ? 1 : 0;
 }
 
 }  // namespace
@@ -113,7 +119,7 @@ extern "C" int efg_hard_voxelize_f32(const float* points, const int64_t* offs, i
   a.mean = mean;
   a.ws = ws;
   a.ws_bytes = ws_bytes;
-  if (forced_impl() == 1 || bins_workspace_bytes(a.n_total, batch, f, a.g) == 0) return hash_hard_voxelize(a);
+  if (pick_impl(a.n_total) == 1 || bins_workspace_bytes(a.n_total, batch, f, a.g) == 0) return hash_hard_voxelize(a);
   return bins_hard_voxelize(a);
 }
 

@@ -185,22 +185,72 @@ except ImportError:   # pragma: no cover  (older torch: no global hooks -> no ca
     _PACK_CACHE_ON = False
 
 
+class _PackRegistry:
+    """Per device: every (parameter, layout) pair that has a cached packed copy, and the device table of 32-byte
+    {weight ptr, packed ptr, cout, kvol, cin, flags} records efg_spconv_pack_weights_multi reads.  When the first
+    convolution after an optimizer step finds its copy stale, ALL registered copies are refreshed by ONE launch (two
+    launches per convolution and step before: ~40 of the step's launches)."""
+
+    def __init__(self):
+        self.entries = {}      # (id(owner), flags) -> [weakref(owner), packed tensor, (cout, kvol, cin), data_ptr]
+        self.table = None      # int64 [n, 4] on the device, rebuilt when the membership changes
+        self.keys = None
+
+    def _live(self):
+        # gone parameters, and parameters whose storage moved (module.to(...), load_state_dict(assign=True)): their
+        # recorded pointer must never be read again; the next use of such a layer packs and registers it afresh
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[3]]
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        return self.entries
+
+    def refresh_all(self, device):
+        """One launch for every registered copy; tags of all owners move to the current (version, epoch)."""
+        ent = self._live()
+        if self.table is None:
+            self.keys = list(ent)
+            rows = []
+            for k in self.keys:
+                _, packed, (cout, kvol, cin), wptr = ent[k]
+                rows.append([wptr, packed.data_ptr(), cout | (kvol << 32), cin | (k[1] << 32)])
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        L.check(L.lib().efg_spconv_pack_weights_multi(L.ptr(self.table), len(self.keys), L.stream()))
+        for k in self.keys:
+            owner = ent[k][0]()
+            owner.__dict__["_efg_packed"][k[1]][0] = (owner._version, _WEIGHT_EPOCH[0], ent[k][3])
+
+
+_PACK_REGISTRY = {}
+
+
 def _packed_weight(w, flags, owner=None):
     """MFMA-order copy of w [cout, kvol, cin] for `flags` (bit 0: data-gradient layout, bit 1: natural channel order,
     bit 2: split-precision arm), cached on `owner` (the layer's Parameter) when given."""
     lib = L.lib()
     cout, kvol, cin = w.shape
-    tag = None
-    if owner is not None and _PACK_CACHE_ON and w.is_cuda:
+    cached = owner is not None and _PACK_CACHE_ON and w.is_cuda
+    if cached:
         tag = (owner._version, _WEIGHT_EPOCH[0], w.data_ptr())
         cache = owner.__dict__.setdefault("_efg_packed", {})
         ent = cache.get(flags)
         if ent is not None and ent[0] == tag:
             return ent[1]
+        reg = _PACK_REGISTRY.setdefault(w.device.index, _PackRegistry())
+        key = (id(owner), flags)
+        known = reg.entries.get(key)
+        if ent is not None and known is not None and known[3] == w.data_ptr() and known[0]() is owner:
+            # stale (an optimizer step happened): refresh EVERY registered copy of the device now, in one launch
+            reg.refresh_all(w.device)
+            return ent[1]
     packed = torch.empty(lib.efg_spconv_packed_weight_bytes(cout, kvol, cin, flags & 1), dtype=torch.uint8, device=w.device)
     L.check(lib.efg_spconv_pack_weight_f32(L.ptr(w), cout, kvol, cin, flags, L.ptr(packed), L.stream()))
-    if tag is not None:
-        cache[flags] = (tag, packed)
+    if cached:
+        import weakref
+
+        cache[flags] = [tag, packed]
+        reg.entries[key] = [weakref.ref(owner), packed, (cout, kvol, cin), w.data_ptr()]
+        reg.table = None
     return packed
 
 

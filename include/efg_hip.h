@@ -163,6 +163,10 @@ int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m
 size_t efg_spconv_packed_weight_bytes(int cout, int kvol, int cin, int for_dgrad);
 int efg_spconv_pack_weight_f32(const float* weight, int cout, int kvol, int cin, int for_dgrad, float* packed,
                                void* stream);
+/* The same for n weights in ONE launch.  items_dev: device array of n 32-byte records
+ *   { const float* weight; float* packed; int32 cout, kvol, cin, for_dgrad; }
+ * (the model's layers change together at the optimizer step: their packed copies are refreshed together). */
+int efg_spconv_pack_weights_multi(const void* items_dev, int n, void* stream);
 
 /* out[o][:] = bias + sum_k W[:,k,:] . in[nbr[k][o]][:]   (bias may be NULL; packed: for_dgrad = 0) */
 int efg_spconv_forward_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,

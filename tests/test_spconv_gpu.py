@@ -159,3 +159,61 @@ def test_dense_bev_matches_dense_view(dev):
     (g1,) = torch.autograd.grad(bev, x.features, g, retain_graph=True)
     (g2,) = torch.autograd.grad(ref, x.features, g)
     assert torch.equal(g1, g2)
+
+
+def test_packed_weight_cache_follows_every_weight_update(dev, monkeypatch):
+    """The MFMA-order copies of the weights are cached on the parameters and refreshed in ONE launch after an optimizer
+    step (spconv/core.py `_PackRegistry`).  Whatever changes the weights -- the fused AdamW (which does not move
+    `_version`), an in-place autograd op, a write through `.data` followed by `weights_updated()` -- the next forward and
+    backward must equal the uncached path bit for bit."""
+    import efg_amd.spconv as spconv
+    from efg_amd.spconv import core
+
+    rng = np.random.default_rng(11)
+    batch, shape = 2, (7, 24, 24)
+    idx, feat = random_sparse(rng, batch, shape, 3000, 16)
+    c1 = spconv.SubMConv3d(16, 64, 3, padding=1, bias=False, indice_key="k").to(dev)
+    c2 = spconv.SparseConv3d(64, 64, 3, stride=2, padding=1, bias=False).to(dev)
+    opt = torch.optim.AdamW(list(c1.parameters()) + list(c2.parameters()), lr=0.05, fused=True)
+    refreshes = []
+    real = core._PackRegistry.refresh_all
+    mine = {id(c1.weight), id(c2.weight)}
+
+    def counted(self, d):
+        real(self, d)
+        refreshes.append(sum(1 for k in self.keys if k[0] in mine))   # (other tests' layers may still be alive)
+
+    monkeypatch.setattr(core._PackRegistry, "refresh_all", counted)
+
+    def run():
+        x = _tensor(dev, idx, feat, batch, shape)
+        x.features.requires_grad_(True)
+        y = c2(c1(x)).features
+        (y * y).sum().backward()
+        out = (y.detach().clone(), x.features.grad.clone(), c1.weight.grad.clone(), c2.weight.grad.clone())
+        c1.weight.grad = c2.weight.grad = None
+        return out
+
+    def check(what):
+        got = run()
+        monkeypatch.setattr(core, "_PACK_CACHE_ON", False)
+        ref = run()
+        monkeypatch.setattr(core, "_PACK_CACHE_ON", True)
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r), what
+
+    check("first use")
+    for step in range(2):
+        out = run()
+        c1.weight.grad, c2.weight.grad = out[2], out[3]
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        n = len(refreshes)
+        check("after optimizer step %d" % step)
+        assert len(refreshes) == n + 1 and refreshes[-1] == 4, "one refresh launch for all four packed copies"
+    with torch.no_grad():
+        c1.weight.mul_(1.5)                      # in-place autograd op: `_version` moves
+    check("after an in-place update")
+    c2.weight.data.mul_(0.5)                     # behind autograd's back: the documented contract is to say so
+    spconv.weights_updated()
+    check("after a write through .data + weights_updated()")
