@@ -28,8 +28,9 @@ _SIGS = {
     "efg_scatter_workspace_bytes": (c_size_t, [c_int64, c_int, c_void_p]),
     "efg_scatter_index": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p]),
+    "efg_scatter_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "efg_scatter_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_void_p,
-                                       c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_scatter_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_index_bytes": (c_size_t, [c_int, c_void_p]),

@@ -83,6 +83,77 @@ scatter_reduce_kernel(const float* __restrict__ feats, const int* __restrict__ c
   }
 }
 
+// ---- deterministic sum / mean: exact integer accumulation ------------------------------------------------------
+// Float atomics make the sum depend on the order the points arrive in (the reference's reduceAdd,
+// scatter_points_cuda.cu:101-133, has the same property).  Here every addend is converted to a 64-bit fixed-point
+// integer x * 2^s, with s chosen from the largest |x| of the call and the point count so that NO sum can overflow
+// (n * max|x| * 2^s < 2^62); integer addition is associative, so the voxel sums are the same bits run to run,
+// whatever the arrival order -- and they are the correctly rounded true sums, not a chain of fp32 roundings.
+// x * 2^s is exact in double (24-bit mantissa times a power of two); bits of x below 2^-s are rounded to nearest.
+// Non-finite addends (never produced by the pipeline) go through float atomics into the output itself: Inf / NaN
+// results do not depend on the order either.
+__global__ void __launch_bounds__(256) scatter_absmax_kernel(const float* __restrict__ feats, const int* __restrict__ p2v,
+                                                              long long n, int c, unsigned* __restrict__ absmax_bits) {
+  unsigned best = 0u;
+  const long long total = n * c;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    if (p2v[e / c] < 0) continue;
+    const float a = fabsf(feats[e]);
+    if (a < INFINITY) best = max(best, __float_as_uint(a));   // (NaN fails the comparison; finite floats order like their bits)
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, d, 64));
+  if (lane_id() == 0 && best) atomicMax(absmax_bits, best);
+}
+
+__device__ __forceinline__ int fixed_shift(unsigned absmax_bits, long long n) {
+  int e = 0;
+  frexpf(__uint_as_float(absmax_bits), &e);            // max|x| < 2^e (e = 0 for an all-zero call)
+  int ln = 0;
+  while ((1ll << ln) < n + 1) ++ln;                      // n + 1 <= 2^ln
+  return min(61 - ln - e, 1000);
+}
+
+__global__ void __launch_bounds__(256)
+scatter_sum_fixed_kernel(const float* __restrict__ feats, const int* __restrict__ coors, const int* __restrict__ p2v,
+                         long long n, int c, int ndim, int reduce, const unsigned* __restrict__ absmax_bits,
+                         unsigned long long* __restrict__ acc, float* __restrict__ vf, int* __restrict__ vc,
+                         int* __restrict__ count) {
+  const int s = fixed_shift(*absmax_bits, n);
+  const long long total = n * c;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / c;
+    const int k = (int)(e - i * c);
+    const int v = p2v[i];
+    if (v < 0) continue;
+    const float x = feats[e];
+    if (fabsf(x) < INFINITY)
+      atomicAdd(acc + (long long)v * c + k, (unsigned long long)__double2ll_rn(ldexp((double)x, s)));   // two's complement
+    else
+      unsafeAtomicAdd(vf + (long long)v * c + k, x);
+    if (k == 0) {
+      if (reduce == 1) atomicAdd(count + v, 1);
+      for (int j = 0; j < ndim; ++j) vc[(long long)v * ndim + j] = coors[i * ndim + j];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+scatter_fixed_finish_kernel(const unsigned long long* __restrict__ acc, const unsigned* __restrict__ absmax_bits,
+                            long long n, const int* __restrict__ count, long long m, int c, int reduce,
+                            float* __restrict__ vf) {
+  const int s = fixed_shift(*absmax_bits, n);
+  const long long total = m * c;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    // the exact sum, rounded ONCE to fp32 (+ the non-finite part, 0 in every sane call)
+    float v = __fadd_rn(vf[e], (float)ldexp((double)(long long)acc[e], -s));
+    if (reduce == 1) v = __fdiv_rn(v, (float)count[e / c]);
+    vf[e] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) scatter_mean_kernel(float* __restrict__ vf, const int* __restrict__ count,
                                                             long long m, int c) {
   const long long total = m * c;
@@ -196,9 +267,14 @@ extern "C" int efg_scatter_index(const int32_t* coors, int64_t n, int ndim, cons
   return EFG_OK;
 }
 
+extern "C" size_t efg_scatter_reduce_workspace_bytes(int64_t m, int c) {
+  if (m < 0 || c < 1) return 0;
+  return align_up((size_t)std::max<int64_t>(m, 1) * c * 8, 256) + 256;   // int64 accumulators + the |x| maximum
+}
+
 extern "C" int efg_scatter_reduce_f32(const float* feats, const int32_t* coors, const int32_t* p2v, int64_t n, int c,
                                       int ndim, int reduce, int64_t m, float* vf, int32_t* vc, int32_t* count,
-                                      void* stream_) {
+                                      void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EFG_CHECK_ARG(reduce >= 0 && reduce <= 2, "scatter: reduce must be 0 (sum), 1 (mean) or 2 (max)");
   EFG_CHECK_ARG(c >= 1 && ndim >= 1 && ndim <= kMaxDim && n >= 0 && m >= 0, "scatter: bad sizes");
@@ -207,15 +283,33 @@ extern "C" int efg_scatter_reduce_f32(const float* feats, const int32_t* coors, 
                      reduce == 2 ? -INFINITY : 0.0f);
   EFG_LAUNCH_CHECK();
   EFG_HIP_TRY(hipMemsetAsync(count, 0, (size_t)m * 4, stream));
+  if (reduce == 2) {   // max: order-independent as it is
+    if (n > 0) {
+      hipLaunchKernelGGL(scatter_reduce_kernel, dim3(grid_for((long long)n * c)), dim3(256), 0, stream, feats, coors,
+                         p2v, (long long)n, c, ndim, reduce, vf, vc, count);
+      EFG_LAUNCH_CHECK();
+    }
+    return EFG_OK;
+  }
+  // sum / mean: exact integer accumulation (deterministic; see scatter_sum_fixed_kernel)
+  Workspace w(ws, ws_bytes);
+  unsigned long long* acc = w.take<unsigned long long>((size_t)m * c);
+  unsigned* absmax = w.take<unsigned>(1);
+  if (!w.ok) {
+    set_error("scatter reduce workspace too small: need %zu bytes, got %zu", efg_scatter_reduce_workspace_bytes(m, c), ws_bytes);
+    return EFG_E_WORKSPACE;
+  }
+  EFG_HIP_TRY(hipMemsetAsync(acc, 0, reinterpret_cast<char*>(absmax + 1) - reinterpret_cast<char*>(acc), stream));
   if (n > 0) {
-    hipLaunchKernelGGL(scatter_reduce_kernel, dim3(grid_for((long long)n * c)), dim3(256), 0, stream, feats, coors,
-                       p2v, (long long)n, c, ndim, reduce, vf, vc, count);
+    hipLaunchKernelGGL(scatter_absmax_kernel, dim3(grid_for((long long)n * c)), dim3(256), 0, stream, feats, p2v, (long long)n,
+                       c, absmax);
+    hipLaunchKernelGGL(scatter_sum_fixed_kernel, dim3(grid_for((long long)n * c)), dim3(256), 0, stream, feats, coors, p2v,
+                       (long long)n, c, ndim, reduce, absmax, acc, vf, vc, count);
     EFG_LAUNCH_CHECK();
   }
-  if (reduce == 1) {
-    hipLaunchKernelGGL(scatter_mean_kernel, dim3(grid_for(m * c)), dim3(256), 0, stream, vf, count, (long long)m, c);
-    EFG_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(scatter_fixed_finish_kernel, dim3(grid_for(m * c)), dim3(256), 0, stream, acc, absmax, (long long)n, count,
+                     (long long)m, c, reduce, vf);
+  EFG_LAUNCH_CHECK();
   return EFG_OK;
 }
 

@@ -46,8 +46,10 @@ def dynamic_point_to_voxel_forward(feats, coors, reduce_type):
     vf = torch.empty((m, c), dtype=torch.float32, device=dev)
     vc = torch.empty((m, ndim), dtype=torch.int32, device=dev)
     cnt = torch.empty((m,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.efg_scatter_reduce_workspace_bytes(m, c)   # sum / mean: exact integer accumulators (deterministic)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     L.check(lib.efg_scatter_reduce_f32(L.ptr(feats), L.ptr(coors), L.ptr(p2v), n, c, ndim, red, m, L.ptr(vf),
-                                       L.ptr(vc), L.ptr(cnt), L.stream()))
+                                       L.ptr(vc), L.ptr(cnt), L.ptr(ws), ws_bytes, L.stream()))
     return [vf, vc, p2v, cnt]
 
 

@@ -102,9 +102,13 @@ size_t efg_scatter_workspace_bytes(int64_t n, int ndim, const int32_t* dims_host
  * does at scatter_points_cuda.cu:220). */
 int efg_scatter_index(const int32_t* coors, int64_t n, int ndim, const int32_t* dims_host,
                       int32_t* point2voxel, int32_t* m_dev, void* ws, size_t ws_bytes, void* stream);
+/* Sum / mean are accumulated as exact 64-bit fixed-point integers (scale from the call's largest |x| and n): the
+ * result is the correctly rounded true sum and bit-identical run to run -- the reference's float atomics
+ * (scatter_points_cuda.cu:101-133) depend on arrival order.  ws: efg_scatter_reduce_workspace_bytes(m, c). */
+size_t efg_scatter_reduce_workspace_bytes(int64_t m, int c);
 int efg_scatter_reduce_f32(const float* feats, const int32_t* coors, const int32_t* point2voxel, int64_t n,
                            int c, int ndim, int reduce, int64_t m, float* voxel_feats, int32_t* voxel_coors,
-                           int32_t* count, void* stream);
+                           int32_t* count, void* ws, size_t ws_bytes, void* stream);
 /* grad_feats[n,c] is fully written.  ws: m*c int32 (max only). */
 int efg_scatter_backward_f32(float* grad_feats, const float* grad_voxel_feats, const float* feats,
                              const float* voxel_feats, const int32_t* point2voxel, const int32_t* count,

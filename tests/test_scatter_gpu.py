@@ -171,3 +171,37 @@ def test_reduce_pinned_to_reference_cpu_grouping(dev, oracle_mod, reduce):
         if reduce == "mean":
             exp = exp / npv[:, None]
         np.testing.assert_allclose(vf.cpu().numpy(), exp, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_sum_and_mean_do_not_depend_on_the_point_order(dev, reduce):
+    """Sums are accumulated as exact 64-bit fixed-point integers (csrc/scatter.hip): the SAME points in any order --
+    a different arrival order of the atomics -- give the same bits, and the result is the correctly rounded fp64 sum.
+    (With float atomics two runs of one call already differ in the last bits.)"""
+    from efg_amd.operators.scatter_points import dynamic_scatter
+
+    rng = np.random.default_rng(3)
+    n, c = 60000, 7
+    coors = rng.integers(0, [4, 12, 12], size=(n, 3)).astype(np.int32)     # ~100 points per voxel: long sums
+    feats = (rng.standard_normal((n, c)) * np.exp(rng.uniform(-12, 6, (n, 1)))).astype(np.float32)   # 8 decades of magnitude
+    outs = []
+    for trial in range(3):
+        perm = rng.permutation(n) if trial else np.arange(n)
+        vf, vc = dynamic_scatter(torch.from_numpy(feats[perm]).to(dev), torch.from_numpy(coors[perm]).to(dev), reduce)
+        outs.append((vf.cpu().numpy(), vc.cpu().numpy()))
+    for vf, vc in outs[1:]:
+        assert np.array_equal(vc, outs[0][1])
+        assert np.array_equal(vf, outs[0][0]), "voxel %s of a permuted cloud differs in its bits" % reduce
+    # against the exact sum: key -> float64 accumulation
+    key = (coors[:, 0].astype(np.int64) * 12 + coors[:, 1]) * 12 + coors[:, 2]
+    uniq, inv = np.unique(key, return_inverse=True)
+    ref = np.zeros((len(uniq), c))
+    np.add.at(ref, inv, feats.astype(np.float64))
+    if reduce == "mean":
+        cnt = np.bincount(inv).astype(np.float32)
+        ref = ref.astype(np.float32) / cnt[:, None]
+    else:
+        ref = ref.astype(np.float32)
+    got = outs[0][0]
+    ulp = np.abs(np.spacing(ref))
+    assert np.all(np.abs(got - ref) <= 1.5 * ulp), "not the correctly rounded sum"
