@@ -508,7 +508,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
                     const float* __restrict__ kidx, const float* __restrict__ grad_out, BoxDims dm,
                     float* __restrict__ grad_value, float* __restrict__ grad_off, float* __restrict__ grad_logits,
                     int* __restrict__ cursor, int2* __restrict__ entries, const int* __restrict__ bin_end,
-                    int* __restrict__ overflow) {
+                    int* __restrict__ overflow, int color) {
   using B = BT<TQY>;
   constexpr int TQX = B::TQX, R = B::R, WINY = B::WINY, WINX = B::WINX, NQ = B::NQ, NC = B::NC, D = B::D, VS = B::VS, GS = B::GS,
                 WS = B::WS, kThreads = B::kThreads, kGW = B::kGW, PMAX = bt::PMAX;
@@ -527,7 +527,17 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   const int m = blockIdx.y, bi = blockIdx.z;
   const int np = dm.p;  // single level
   const int tiles_x = (Wm + TQX - 1) / TQX;
-  const int ntiles = ((Hm + TQY - 1) / TQY) * tiles_x;
+  const int tiles_y = (Hm + TQY - 1) / TQY;
+  // color >= 0: this launch works on the tiles (ty, tx) with (ty % NCY, tx % NCX) == (color / NCX, color % NCX) only.  The
+  // windows of two such tiles never overlap (a window is the tile + R cells all around: NCY x NCX tiles), so the window
+  // flush is a plain read-modify-write and the NCY * NCX launches apply the overlapping windows' contributions to a cell
+  // in a FIXED order: grad_value is reproducible bit for bit.  color < 0: one launch over all tiles, float atomics.
+  constexpr int NCY = (WINY + TQY - 1) / TQY, NCX = (WINX + TQX - 1) / TQX;
+  const int cy0 = color >= 0 ? color / NCX : 0, cx0 = color >= 0 ? color % NCX : 0;
+  const int sy = color >= 0 ? NCY : 1, sx = color >= 0 ? NCX : 1;
+  const int ctx = (tiles_x - cx0 + sx - 1) / sx, cty = (tiles_y - cy0 + sy - 1) / sy;   // tiles of this launch
+  const int ntiles = max(ctx, 0) * max(cty, 0);
+  auto tile_of = [&](int j) { return (cy0 + sy * (j / ctx)) * tiles_x + cx0 + sx * (j % ctx); };
   const long long S = dm.s;
   constexpr int VPT = NC * (D / 4) / kThreads;  // float4 of the value window per thread (4)
   constexpr int EPT = PMAX / 2;                 // points per lane (one half of the lattice)
@@ -539,7 +549,8 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     float4 go;
     float lg[4], rf[5], of[5];
   } pre;
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int j) {
+    const int tile = tile_of(j);
     const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
 #pragma unroll
     for (int it = 0; it < VPT; ++it) {
@@ -564,7 +575,8 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   };
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tj = blockIdx.x; tj < ntiles; tj += gridDim.x) {
+    const int tile = tile_of(tj);
     const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
     const int wy0 = ty0 - R, wx0 = tx0 - R;
     __syncthreads();  // previous item's GEMM-2 is done with GOs / W
@@ -602,7 +614,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     const float inv = 1.0f / den;
     const BoxGeo g = make_box_v(pre.rf, pre.of, dm.v);
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight during the phases below
+    if (tj + (int)gridDim.x < ntiles) fetch(tj + gridDim.x);  // in flight during the phases below
 
     // ---- S1: G = GO . V^T ----------------------------------------------------------------------------------
     {
@@ -772,6 +784,21 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
       f32x4 acc[CBW][2];
 #pragma unroll
       for (int i = 0; i < CBW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // coloured launch: the window's current contents, requested BEFORE the product so that the read half of the
+      // read-modify-write flush is hidden behind the MFMAs
+      float cur[CBW][2][4];
+      if (color >= 0) {
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cell = 16 * (CBW * wave + i) + 4 * kk + r;
+            const int cy = min(max(wy0 + cell / WINX, 0), Hm - 1), cx = min(max(wx0 + cell % WINX, 0), Wm - 1);
+            const float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
+            cur[i][0][r] = gv[0];
+            cur[i][1][r] = gv[16];
+          }
+      }
       const float* ap = GW + (16 * (CBW * wave) + r16) * WS + kk;
       const float* bp = GOs + kk * VS + r16;
 #pragma unroll
@@ -792,8 +819,13 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
           const int cy = wy0 + cell / WINX, cx = wx0 + cell % WINX;
           if (cy >= 0 && cy < Hm && cx >= 0 && cx < Wm) {
             float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
-            if (acc[i][0][r] != 0.0f) unsafeAtomicAdd(gv, acc[i][0][r]);
-            if (acc[i][1][r] != 0.0f) unsafeAtomicAdd(gv + 16, acc[i][1][r]);
+            if (color >= 0) {   // nobody else touches this window during this launch
+              if (acc[i][0][r] != 0.0f) gv[0] = __fadd_rn(cur[i][0][r], acc[i][0][r]);
+              if (acc[i][1][r] != 0.0f) gv[16] = __fadd_rn(cur[i][1][r], acc[i][1][r]);
+            } else {
+              if (acc[i][0][r] != 0.0f) unsafeAtomicAdd(gv, acc[i][0][r]);
+              if (acc[i][1][r] != 0.0f) unsafeAtomicAdd(gv + 16, acc[i][1][r]);
+            }
           }
         }
     }
@@ -914,6 +946,12 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int* __restrict__ offse
 
 // grad_value row `bin` += sum over its entries of weight * grad_out[row]; 8 lanes x float4 per bin.  After the
 // main kernel cursor[bin] is the END of the bin, offsets[bin] its start.
+// The entries of a bin sit in the order their atomics arrived, which differs run to run; a float accumulation in list
+// order would make grad_value (and every gradient upstream of it) differ in the last bits between two identical steps.
+// The sum is therefore taken as EXACT 64-bit fixed-point integers: pass 1 finds the largest |weight * grad_out| of the
+// lane's four channels over the bin, which fixes a scale 2^sh at which no sum of the bin's n products can overflow;
+// pass 2 adds round(weight * grad_out * 2^sh) -- the product is exact in double (24 x 24 bits), integer addition is
+// associative -- and the row receives the correctly rounded total.  Entries are read twice (the second time from L1 / L2).
 __global__ void __launch_bounds__(256)
 box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ cursor, const int2* __restrict__ entries,
                       const float* __restrict__ grad_out, long long nbins, float* __restrict__ grad_value) {
@@ -921,8 +959,9 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
   for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
     const int s = offsets[bin], e = min(cursor[bin], offsets[bin + 1]);  // offsets has nbins + 1 entries
     if (s == e) continue;
-    float4 acc = ld4(grad_value + bin * 32 + c4);
-    for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight, accumulated in list order
+    float mx = 0.0f;
+    bool finite = true;
+    for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight
       int2 en[4];
       float4 g[4];
 #pragma unroll
@@ -930,14 +969,51 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
 #pragma unroll
       for (int u = 0; u < 4; ++u) g[u] = ld4(grad_out + (long long)en[u].x * 32 + c4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i0 + u < e) {
-          const float w = __int_as_float(en[u].y);
-          acc.x = fmaf(w, g[u].x, acc.x);
-          acc.y = fmaf(w, g[u].y, acc.y);
-          acc.z = fmaf(w, g[u].z, acc.z);
-          acc.w = fmaf(w, g[u].w, acc.w);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const float w = fabsf(__int_as_float(en[u].y));
+        const float m4 = fmaxf(fmaxf(fabsf(g[u].x), fabsf(g[u].y)), fmaxf(fabsf(g[u].z), fabsf(g[u].w))) * w;
+        finite = finite && (m4 < INFINITY);   // (false for NaN too)
+        mx = fmaxf(mx, m4);
+      }
+    }
+    float4 acc = ld4(grad_value + bin * 32 + c4);
+    if (finite) {
+      int ex = 0, ln = 0;
+      frexpf(mx * 1.0000002f, &ex);          // every |product| < 2^ex (the float product above may round down by one ulp)
+      while ((1 << ln) < e - s + 1) ++ln;    // n + 1 <= 2^ln
+      const int sh = 61 - ln - ex;
+      long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      for (int i0 = s; i0 < e; i0 += 4) {
+        int2 en[4];
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = entries[min(i0 + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = ld4(grad_out + (long long)en[u].x * 32 + c4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u < e) {
+            const double w = (double)__int_as_float(en[u].y);
+            a0 += __double2ll_rn(ldexp(w * (double)g[u].x, sh));
+            a1 += __double2ll_rn(ldexp(w * (double)g[u].y, sh));
+            a2 += __double2ll_rn(ldexp(w * (double)g[u].z, sh));
+            a3 += __double2ll_rn(ldexp(w * (double)g[u].w, sh));
+          }
+      }
+      acc.x = __fadd_rn(acc.x, (float)ldexp((double)a0, -sh));
+      acc.y = __fadd_rn(acc.y, (float)ldexp((double)a1, -sh));
+      acc.z = __fadd_rn(acc.z, (float)ldexp((double)a2, -sh));
+      acc.w = __fadd_rn(acc.w, (float)ldexp((double)a3, -sh));
+    } else {   // Inf / NaN among the addends: so is the sum, in any order
+      for (int i = s; i < e; ++i) {
+        const int2 en = entries[i];
+        const float4 g = ld4(grad_out + (long long)en.x * 32 + c4);
+        const float w = __int_as_float(en.y);
+        acc.x = fmaf(w, g.x, acc.x);
+        acc.y = fmaf(w, g.y, acc.y);
+        acc.z = fmaf(w, g.z, acc.z);
+        acc.w = fmaf(w, g.w, acc.w);
+      }
     }
     *reinterpret_cast<float4*>(grad_value + bin * 32 + c4) = acc;
   }
@@ -1073,16 +1149,30 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
                                  kernel_indices, dm, 1, tqy, st, &offs, &cursor, &entries, &overflow))
           return rc;
       }
-      if (tqy == 8) {
-        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
-        hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(tile_gx, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
-                           (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
-                           grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
-      } else {
-        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<4>, bt::lds_bytes<4>());
-        hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(tile_gx, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,
-                           (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
-                           grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow);
+      // EFG_BOX_DETERMINISTIC (default 1): the tiles in NCY x NCX colour classes whose windows never overlap, one launch
+      // per class with a plain read-modify-write flush -- grad_value is the same bits run to run (with the binned
+      // out-of-window corners, whose reduction is order-independent).  0: one launch, float atomics.
+      static const int det_env = getenv("EFG_BOX_DETERMINISTIC") ? atoi(getenv("EFG_BOX_DETERMINISTIC")) : 1;
+      const bool colored = det_env != 0 && binned;
+      const int ncolors = colored ? (tqy == 8 ? ((BT<8>::WINY + 7) / 8) * ((BT<8>::WINX + BT<8>::TQX - 1) / BT<8>::TQX)
+                                              : ((BT<4>::WINY + 3) / 4) * ((BT<4>::WINX + BT<4>::TQX - 1) / BT<4>::TQX))
+                                  : 1;
+      // (workgroups along x of a colour launch; measured 16: +1.1 ms, 32: +0.35 ms, 64: +0.1 ms per step against the atomic launch)
+      static const int cgx_env = getenv("EFG_BOX_COLOR_GRIDX") ? atoi(getenv("EFG_BOX_COLOR_GRIDX")) : 64;
+      const unsigned gx_launch = colored ? std::min<unsigned>(tile_gx, (unsigned)std::max(cgx_env, 1)) : tile_gx;
+      for (int col = 0; col < ncolors; ++col) {
+        const int color = colored ? col : -1;
+        if (tqy == 8) {
+          EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
+          hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(gx_launch, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
+                             (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                             grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow, color);
+        } else {
+          EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<4>, bt::lds_bytes<4>());
+          hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(gx_launch, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,
+                             (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                             grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow, color);
+        }
       }
       if (binned) {
         EFG_LAUNCH_CHECK();

@@ -406,6 +406,10 @@ class Trainer:
             # instead of taking the immediate-mode pick: fwd 1.24 -> 0.66 ms, bwd-data 0.85 -> 0.66 ms per step
             if os.environ.get("EFG_MIOPEN_FIND", "1") == "1":
                 torch.backends.cudnn.benchmark = True
+            # EFG_MIOPEN_DETERMINISTIC=1: only MIOpen solvers without atomics (the weight gradient of the one dense 3 x 3
+            # BEV convolution is the last run-to-run difference of a training step, scripts/ubench/determinism_probe.py)
+            if os.environ.get("EFG_MIOPEN_DETERMINISTIC", "0") == "1":
+                torch.backends.cudnn.deterministic = True
         torch.manual_seed(seed)
         self.cfg = cfg
         self.model = (model_cls or VoxelDETR)(cfg)
