@@ -80,6 +80,7 @@ _SIGS = {
     "efg_box_attn_fused_backward_f32": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "efg_boxes_bev_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "efg_nms_workspace_bytes": (c_size_t, [c_int]),
+    "efg_topk_unsorted_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_box_refine_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "efg_box_refine_backward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "efg_add_layernorm_forward_f32": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int] + [c_void_p] * 5),

@@ -9,7 +9,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libefg_hip.so")
 
-SOURCES = ["lib.cpp", "voxelize.hip", "voxelize_bins.hip", "voxelize_hash.hip", "scatter.hip", "spconv_index.hip", "spconv_conv.hip", "spconv_tiles.hip", "spconv_wgt.hip", "msda.hip", "box_fused.hip", "iou3d_nms.hip", "matcher.hip", "layernorm.hip", "augment.hip", "det_loss.hip", "batchnorm.hip", "colsum.hip", "crop.hip", "attention.hip", "gemm_bf16x3.hip"]
+SOURCES = ["lib.cpp", "voxelize.hip", "voxelize_bins.hip", "voxelize_hash.hip", "scatter.hip", "spconv_index.hip", "spconv_conv.hip", "spconv_tiles.hip", "spconv_wgt.hip", "msda.hip", "box_fused.hip", "iou3d_nms.hip", "matcher.hip", "layernorm.hip", "augment.hip", "det_loss.hip", "batchnorm.hip", "colsum.hip", "crop.hip", "attention.hip", "gemm_bf16x3.hip", "topk.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
 

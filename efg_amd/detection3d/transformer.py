@@ -173,6 +173,11 @@ class Transformer(nn.Module):
 
     def _select_proposals(self, probs):
         """(scores, token indexes) of the num_queries best proposals per scene, unsorted ($CQ/transformer.py:65)."""
+        if probs.is_cuda and probs.dtype == torch.float32 and probs.dim() == 2 and os.environ.get("EFG_TOPK", "1") != "0":
+            # one launch and a FIXED tie rule (lowest indices of the values equal to the k-th): csrc/topk.hip
+            from ..operators.det_loss import topk_unsorted
+
+            return topk_unsorted(probs, self.num_queries)
         return torch.topk(probs, self.num_queries, dim=1, sorted=False)
 
     def _get_enc_proposals(self, enc_embed, ref_windows):

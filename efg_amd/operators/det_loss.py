@@ -115,3 +115,15 @@ def box_refine(delta, anchor, eps=1e-5):
         return BoxRefineFunction.apply(delta, anchor, eps)
     x = anchor.clamp(min=0, max=1)
     return (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()
+
+
+def topk_unsorted(x, k):
+    """(values, indices) of the k largest entries of every row of x [rows, n] (GPU fp32), ascending index order; ties at the
+    cut go to the lowest indices.  == torch.topk(x, k, dim=1, sorted=False) as a set."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    rows, n = x.shape
+    values = torch.empty((rows, k), dtype=torch.float32, device=x.device)
+    indices = torch.empty((rows, k), dtype=torch.int64, device=x.device)
+    L.check(L.lib().efg_topk_unsorted_f32(L.ptr(x), rows, n, k, L.ptr(values), L.ptr(indices), L.stream()))
+    return values, indices

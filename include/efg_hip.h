@@ -471,6 +471,11 @@ int efg_box_loss_backward_f32(const float* boxes, const float* tgt_boxes, const 
                               const int64_t* q_idx, const int64_t* g_idx, int64_t n, int layers, int b, int q, int g,
                               const float* denom, const float* grad_out, float* grad_boxes, void* stream);
 
+/* Unsorted top-k per row of x [rows, n] (the proposal selection, $CQ/transformer.py:65: torch.topk(sorted=False)):
+ * values [rows, k], indices int64 [rows, k], in ascending index order; of the elements equal to the k-th largest value
+ * the lowest indices are taken (a fixed rule: two runs pick the same proposals).  One launch, one workgroup per row. */
+int efg_topk_unsorted_f32(const float* x, int64_t rows, int n, int k, float* values, int64_t* indices, void* stream);
+
 /* Iterative box refinement of the detection heads ($CQ/heads.py:76-79, $CQ/transformer.py:60-81):
  *   out = sigmoid(delta + inverse_sigmoid(anchor)), inverse_sigmoid as $CQ/modules/utils.py:83-87 (eps 1e-5);
  * n elements, any shape.  Backward: grad_delta = grad * out * (1 - out) (the anchors are detached reference windows). */

@@ -124,3 +124,30 @@ def test_box_refine_matches_the_reference_formulation():
     torch.testing.assert_close(delta.grad, d2.grad, rtol=1e-5, atol=1e-7)
     with torch.no_grad():   # the momentum decoder's (graph-captured) use
         torch.testing.assert_close(box_refine(delta, anchor), ref.detach(), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("n,k", [(35344, 1000), (35344, 900), (5000, 5000), (1500, 1), (70000, 300)])
+def test_topk_unsorted_is_exact_and_breaks_ties_by_index(n, k):
+    """csrc/topk.hip against torch.topk: the same VALUES (multiset), indices in ascending order; with a plateau of equal
+    scores at the cut (every empty BEV cell of a fresh model) the lowest indices of the plateau are taken, every time."""
+    from efg_amd.operators.det_loss import topk_unsorted
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.rand(3, n, generator=g)
+    x[1, torch.randperm(n, generator=g)[: n // 2]] = 0.25        # half the row on one plateau: the cut falls inside it
+    x[2] = torch.randn(n, generator=g)                           # negative values too
+    x[2, :7] = float("-inf")
+    x = x.to(dev)
+    v, i = topk_unsorted(x, k)
+    tv, ti = torch.topk(x, k, dim=1, sorted=True)
+    assert torch.equal(torch.sort(v, dim=1, descending=True)[0], tv)          # the same values, exactly
+    assert torch.equal(torch.gather(x, 1, i), v)
+    assert bool((i[:, 1:] > i[:, :-1]).all()) or k == 1                       # ascending, no duplicates
+    for r in range(3):                                                         # tie rule: lowest indices of the cut value
+        cut = tv[r, -1]
+        eq = torch.nonzero(x[r] == cut).flatten()
+        taken = i[r][torch.gather(x[r], 0, i[r]) == cut]
+        assert torch.equal(taken, eq[: taken.numel()])
+    v2, i2 = topk_unsorted(x, k)
+    assert torch.equal(i2, i) and torch.equal(v2, v)

@@ -181,3 +181,30 @@ def test_linear_refuses_nothing_on_cpu():
     x = torch.randn(3, 8, requires_grad=True)
     m(x).sum().backward()
     assert m.bias.grad is not None
+
+
+def test_conv3x3_fixed_order_weight_gradient(dev):
+    """EFG_DETERMINISTIC=1: the dense 3 x 3 convolution's weight gradient as nine fixed-order GEMMs over the padded
+    channels-last maps (operators/conv2d.py) -- equal to MIOpen's to fp32 rounding, and the same bits every time."""
+    from efg_amd.operators.conv2d import conv3x3
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 45, 52, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(96, 64, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = torch.randn(96, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(2, 96, 45, 52, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref.backward(gy.double())
+    rx, rw, rb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+    outs = []
+    for trial in range(3):
+        x.grad = w.grad = b.grad = None
+        y = conv3x3(x, w, b)
+        y.backward(gy)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
+    y, gx, gw, gb = outs[0]
+    for got, exp, name in ((y, ref.detach(), "out"), (gx, rx, "grad x"), (gw, rw, "grad w"), (gb, rb, "grad b")):
+        scale = float(exp.abs().max())
+        assert float((got.double() - exp.double()).abs().max()) < 2e-5 * scale, name
+    for o in outs[1:]:
+        assert torch.equal(o[2], gw), "weight gradient differs between two identical backward passes"
