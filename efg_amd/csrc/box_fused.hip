@@ -1188,7 +1188,10 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
   } else {
     const BinPlan pl = bin_plan(b, s, h, l, lq, p);
     hipStream_t st = (hipStream_t)stream;
-    const bool binned = ws != nullptr && pl.nentries >= kBinMinEntries && pl.nentries < (1ll << 31) &&
+    // small problems (below kBinMinEntries corners the extra launches cost more than the float atomics) are binned too
+    // unless EFG_BOX_DETERMINISTIC=0: the atomics' arrival order would make grad_value differ run to run
+    static const int det_dec = getenv("EFG_BOX_DETERMINISTIC") ? atoi(getenv("EFG_BOX_DETERMINISTIC")) : 1;
+    const bool binned = ws != nullptr && (det_dec != 0 || pl.nentries >= kBinMinEntries) && pl.nentries < (1ll << 31) &&
                         pl.nbins + 1 < (1ll << 31);
     int *cursor = nullptr, *offs = nullptr, *overflow = nullptr;
     int2* entries = nullptr;

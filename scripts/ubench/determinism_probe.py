@@ -21,7 +21,9 @@ runs = []
 seen = []
 per_step = []
 for r in range(2):
-    tr = Trainer(device=dev, seed=0)
+    small = "--small" in sys.argv   # the configuration of tests/ddp_gpu_worker.py
+    ov = {"model.transformer.num_queries": 60, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2} if small else None
+    tr = Trainer(device=dev, seed=0, overrides=ov, max_iters=50 if small else None)
     tr.model.noise_generator = torch.Generator().manual_seed(4321)
     # torch.topk returns ANY members of a tie at the cut (radix select with atomics), and on a random-init model the
     # proposal scores have a plateau of equal values there: the second run takes the first run's proposals, so that what
@@ -37,7 +39,9 @@ for r in range(2):
         tf._select_proposals = lambda probs, it=it: (lambda idx: (torch.gather(probs, 1, idx), idx))(next(it))
     trace = []
     for s in range(steps):
-        losses, total = tr.step(synthetic_batch(2000 + 10 * s, 2, device=dev))
+        batch = (synthetic_batch(700 + 10 * s, 1, n_points=30000, n_boxes=12, device=dev) if small else
+                 synthetic_batch(2000 + 10 * s, 2, device=dev))
+        losses, total = tr.step(batch)
         torch.cuda.synchronize()
         trace.append((float(total.detach()), float(sum(p.grad.double().abs().sum() for p in tr.model.parameters() if p.grad is not None))))
     per_step.append(trace)
