@@ -1,16 +1,19 @@
-"""3 x 3 dense convolution whose WEIGHT GRADIENT is nine fixed-order GEMMs instead of MIOpen's `wrw` kernel.
+"""3 x 3 dense convolution as fixed-order GEMMs over the zero-padded channels-last map (EFG_DETERMINISTIC=1).
 
-MIOpen's fp32 weight-gradient solver for the one dense 3 x 3 convolution of the path (FPN `fpn_output3`, 256 -> 256 at
-188 x 188, efg/modeling/backbones/fpn.py:47) splits its reduction with float atomics: that tensor's gradient is the
-LAST thing that differs between two identical training steps (`scripts/ubench/determinism_probe.py`; MIOpen's own
-deterministic mode picks a naive solver: 10x the whole step).  With `EFG_DETERMINISTIC=1` the convolution keeps MIOpen
-for the forward and the data gradient and computes
+The one dense 3 x 3 convolution of the path (FPN `fpn_output3`, 256 -> 256 at 188 x 188, efg/modeling/backbones/fpn.py:47)
+normally runs on MIOpen, whose solver is picked by TIMING (`cudnn.benchmark`, engine.py): its fp32 weight-gradient solver
+splits the reduction with float atomics on every box, and on a box whose host is loaded while the find runs the forward /
+data-gradient pick can be an atomic one too -- then two identical steps differ from this layer's OUTPUT on
+(`scripts/ubench/determinism_probe.py --trace`; MIOpen's own deterministic mode picks a naive solver: 10x the whole step).
+With `EFG_DETERMINISTIC=1` the convolution does not touch MIOpen.  A shifted window of a zero-padded row-major map is a
+CONTIGUOUS row range, so with off(ky, kx) = (ky - 1) (W + 2) + (kx - 1) over the rows r of the padded maps
 
-    dW[:, :, ky, kx] = sum_r  G_pad[r]^T  X_pad[r + (ky - 1) (W + 2) + (kx - 1)]
+    Y[r]             = b + sum_k  X_pad[r + off_k]  W_k^T          nine `addmm_` into one buffer, in tap order
+    dX[r]            =     sum_k  G_pad[r - off_k]  W_k            the same, on the padded gradient
+    dW[:, :, ky, kx] =     sum_r  G_pad[r]^T  X_pad[r + off_k]     nine `operators.linear.weight_grad` (16 fixed row chunks)
 
-over the rows of the zero-padded channels-last maps -- a shifted window of a padded row-major map is a CONTIGUOUS row
-range, and the padding rows of G are zero, so every out-of-image pair drops out -- as nine products of
-`operators.linear.weight_grad` (16 fixed row chunks, summed in order).  +0.2 ms per step, hence opt-in."""
+(the border rows of Y and dX are computed and dropped; the padding rows of G are zero, so every out-of-image pair drops out
+of dW).  hipBLASLt does not split K = 256, so each product has one summation order.  +0.5 ms per step, hence opt-in."""
 import os
 
 import torch
@@ -25,43 +28,75 @@ def deterministic_mode():
     return os.environ.get("EFG_DETERMINISTIC", "0") == "1"
 
 
-def wgrad_3x3(x, gy):
+def _pad_rows(t, front):
+    """[B, C, H, W] -> zero-padded channels-last rows [front + rows + front, C]; returns (buffer, r, rows)."""
+    b, c, h, w = t.shape
+    r = b * (h + 2) * (w + 2)
+    rows = (r + 15) // 16 * 16
+    buf = torch.zeros((front + rows + front, c), dtype=t.dtype, device=t.device)
+    buf[front:front + r].view(b, h + 2, w + 2, c)[:, 1:-1, 1:-1].copy_(t.permute(0, 2, 3, 1))
+    return buf, r, rows
+
+
+def _unpad_rows(flat, b, h, w):
+    """rows of the padded map -> [B, C, H, W] (a channels-last view of the interior)."""
+    return flat[:b * (h + 2) * (w + 2)].view(b, h + 2, w + 2, -1)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
+
+
+_TAPS = [(ky, kx) for ky in range(3) for kx in range(3)]
+
+
+def _taps_gemm(buf, rows, front, wp, mats, sign, bias=None):
+    """sum_k buf[front + sign * off_k :][:rows] @ mats[k], accumulated in tap order into one [rows, N] buffer."""
+    out = (bias.expand(rows, -1).contiguous() if bias is not None else
+           torch.zeros((rows, mats[0].shape[1]), dtype=buf.dtype, device=buf.device))
+    for (ky, kx), m in zip(_TAPS, mats):
+        s = front + sign * ((ky - 1) * wp + (kx - 1))
+        out.addmm_(buf[s:s + rows], m)
+    return out
+
+
+def wgrad_3x3(x, gy, xb=None):
     """x [B, Ci, H, W], gy [B, Co, H, W] (stride 1, padding 1) -> dW [Co, Ci, 3, 3], fixed summation order."""
-    b, ci, h, w = x.shape
+    b, ci, h, w = gy.shape[0], (x.shape[1] if xb is None else xb.shape[1]), gy.shape[2], gy.shape[3]
     co = gy.shape[1]
     wp = w + 2
-    r = b * (h + 2) * wp
-    rows = (r + 15) // 16 * 16
     front = wp + 1
-    xb = torch.zeros((front + rows + front, ci), dtype=x.dtype, device=x.device)
-    gb = torch.zeros((rows, co), dtype=gy.dtype, device=gy.device)
-    xb[front:front + r].view(b, h + 2, wp, ci)[:, 1:-1, 1:-1].copy_(x.permute(0, 2, 3, 1))
-    gb[:r].view(b, h + 2, wp, co)[:, 1:-1, 1:-1].copy_(gy.permute(0, 2, 3, 1))
+    if xb is None:
+        xb, _, _ = _pad_rows(x, front)
+    gb, _, rows = _pad_rows(gy, 0)
     parts = []
-    for ky in range(3):
-        for kx in range(3):
-            s = front + (ky - 1) * wp + (kx - 1)
-            parts.append(weight_grad(xb[s:s + rows], gb))     # [Co, Ci]
+    for ky, kx in _TAPS:
+        s = front + (ky - 1) * wp + (kx - 1)
+        parts.append(weight_grad(xb[s:s + rows], gb))     # [Co, Ci]
     return torch.stack(parts, dim=-1).view(co, ci, 3, 3)
 
 
 class Conv3x3Function(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        b, _, h, w = x.shape
+        front = w + 3
+        xb, _, rows = _pad_rows(x, front)
+        ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
-        return F.conv2d(x, weight, bias, stride=1, padding=1)
+        ctx.geom = (b, h, w)
+        mats = [weight[:, :, ky, kx].t() for ky, kx in _TAPS]              # [Ci, Co] each
+        return _unpad_rows(_taps_gemm(xb, rows, front, w + 2, mats, +1, bias), b, h, w)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        xb, weight = ctx.saved_tensors
+        b, h, w = ctx.geom
+        front = w + 3
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            gbuf, _, rows = _pad_rows(gy, front)
+            mats = [weight[:, :, ky, kx] for ky, kx in _TAPS]              # [Co, Ci] each
+            gx = _unpad_rows(_taps_gemm(gbuf, rows, front, w + 2, mats, -1), b, h, w)
         if ctx.needs_input_grad[1]:
-            gw = wgrad_3x3(x, gy).contiguous(memory_format=torch.channels_last if weight.is_contiguous(
+            gw = wgrad_3x3(None, gy, xb=xb).contiguous(memory_format=torch.channels_last if weight.is_contiguous(
                 memory_format=torch.channels_last) and not weight.is_contiguous() else torch.contiguous_format)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))

@@ -37,6 +37,35 @@ for r in range(2):
     else:
         it = iter(seen)
         tf._select_proposals = lambda probs, it=it: (lambda idx: (torch.gather(probs, 1, idx), idx))(next(it))
+    events = []   # (phase, module, checksum tensor): the first entry that differs between the runs names the op
+    if "--trace" in sys.argv:
+        def digest(x):
+            ts = []
+            def walk(o):
+                if torch.is_tensor(o):
+                    ts.append(o)
+                elif hasattr(o, "features") and torch.is_tensor(getattr(o, "features")):
+                    ts.append(o.features)
+                elif isinstance(o, (list, tuple)):
+                    [walk(i) for i in o]
+                elif isinstance(o, dict):
+                    [walk(i) for i in o.values()]
+            walk(x)
+            ts = [t.detach() for t in ts if t.is_cuda and t.numel()]
+            if not ts:
+                return None
+            out = []
+            for t in ts:
+                w = t.contiguous().view(-1).view(torch.uint8).to(torch.int64)
+                out.append((w * (torch.arange(w.numel(), device=w.device) % 251 + 1)).sum())
+            return torch.stack(out).sum()
+        def on_forward(m, i, o, name):
+            events.append(("fwd", name, digest(o)))
+            t = o if torch.is_tensor(o) else getattr(o, "features", None)
+            if torch.is_tensor(t) and t.requires_grad:
+                t.register_hook(lambda g, name=name: events.append(("bwd", name, digest(g))))
+        for name, mod in tr.model.named_modules():
+            mod.register_forward_hook(lambda m, i, o, name=name: on_forward(m, i, o, name))
     trace = []
     for s in range(steps):
         batch = (synthetic_batch(700 + 10 * s, 1, n_points=30000, n_boxes=12, device=dev) if small else
@@ -47,13 +76,14 @@ for r in range(2):
     per_step.append(trace)
     runs.append(({k: float(v.detach()) for k, v in losses.items()},
                  {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None},
-                 {n: p.detach().clone() for n, p in tr.model.named_parameters()}))
+                 {n: p.detach().clone() for n, p in tr.model.named_parameters()},
+                 [(ph, n, None if d is None else int(d)) for ph, n, d in events]))
     tr.close()
     del tr
 for s, (a, b) in enumerate(zip(*per_step)):
     print("step %d: total loss %s, sum |grad| %s" % (s, "same" if a[0] == b[0] else "%.9g vs %.9g" % (a[0], b[0]),
                                                      "same" if a[1] == b[1] else "%.12g vs %.12g" % (a[1], b[1])))
-(l0, g0, p0), (l1, g1, p1) = runs
+(l0, g0, p0, e0), (l1, g1, p1, e1) = runs
 bad_l = [k for k in l0 if l0[k] != l1[k]]
 print("loss terms that differ: %d of %d %s" % (len(bad_l), len(l0), bad_l[:6]))
 bad = []
@@ -70,5 +100,21 @@ for d, n in bad:
     groups[key][1] = max(groups[key][1], d)
 for k, (c, d) in sorted(groups.items()):
     print("  %-60s %3d tensors, max rel diff %.2e" % (k, c, d))
+import ctypes  # noqa: E402
+
+from efg_amd import _lib  # noqa: E402
+
+nfb = ctypes.c_int64(0)
+_lib.check(_lib.lib().efg_spconv_streamk_fallbacks(ctypes.byref(nfb), 0))
+print("stream-K units recomputed after a missed share (both runs): %d" % nfb.value)
 same = [n for n in g0 if torch.equal(g0[n], g1[n])]
 print("identical gradients: %d, e.g. %s" % (len(same), same[:5]))
+if e0:
+    print("traced events: %d vs %d" % (len(e0), len(e1)))
+    shown = 0
+    for i, (a, b) in enumerate(zip(e0, e1)):
+        if a != b:
+            print("  event %4d differs: %s %s" % (i, a[0], a[1] if a[1] == b[1] else "%s / %s" % (a[1], b[1])))
+            shown += 1
+            if shown >= 25:
+                break

@@ -2,8 +2,9 @@
 
 Since round 4 nothing on the path accumulates in arrival order: the encoder's box-attention backward runs its query
 tiles in colour classes with a plain read-modify-write flush, binned corners are summed as exact fixed-point integers,
-the proposal top-k breaks ties by index (csrc/box_fused.hip, csrc/topk.hip); EFG_DETERMINISTIC=1 additionally replaces
-MIOpen's atomic weight gradient of the one dense 3 x 3 convolution by nine fixed-order GEMMs (operators/conv2d.py).
+the proposal top-k breaks ties by index (csrc/box_fused.hip, csrc/topk.hip); EFG_DETERMINISTIC=1 additionally takes the
+one dense 3 x 3 convolution off MIOpen -- whose solver is picked by timing, so on a loaded box even its forward could be
+an atomic one -- and runs it as fixed-order GEMMs over the padded channels-last map (operators/conv2d.py).
 Two trainers with one seed then agree in EVERY loss term and EVERY gradient over consecutive optimizer steps."""
 import os
 import subprocess
