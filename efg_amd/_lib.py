@@ -82,7 +82,7 @@ _SIGS = {
     "efg_nms_workspace_bytes": (c_size_t, [c_int]),
     "efg_topk_unsorted_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_box_refine_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
-    "efg_box_refine_backward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "efg_box_refine_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "efg_add_layernorm_forward_f32": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int] + [c_void_p] * 5),
     "efg_add_layernorm_backward_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "efg_add_layernorm_backward_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int] + [c_void_p] * 4 + [c_size_t, c_void_p]),
@@ -167,7 +167,13 @@ def lib():
                 "efg_amd: %s is missing. Build it with `python -m efg_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback on the product path." % _LIB_PATH)
         _warn_if_stale()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        # EFG_HIP_LIB_AB=<file in efg_amd/lib/>: an A/B build of the same sources (scripts/build_ab.sh compiles one
+        # translation unit with other -D switches) -- same C ABI, for same-box kernel comparisons only
+        ab = os.environ.get("EFG_HIP_LIB_AB")
+        path = os.path.join(os.path.dirname(_LIB_PATH), os.path.basename(ab)) if ab else _LIB_PATH
+        if ab and not os.path.exists(path):
+            raise RuntimeError("efg_amd: EFG_HIP_LIB_AB=%s not found in %s" % (ab, os.path.dirname(_LIB_PATH)))
+        _lib = ctypes.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = res

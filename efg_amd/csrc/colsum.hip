@@ -10,10 +10,15 @@
 //               matrices, a wave covers several rows per step (64 / pow2ceil(columns/4)); row loop unrolled so
 //               that each wave keeps several KB in flight; rows -> waves -> LDS, fixed order;
 //   K2 final    partial[blocks][C] -> out[C], lanes over columns (coalesced), waves over blocks, fixed order.
-// Deterministic (no atomics).  HBM-bound: one pass over the matrix.
+// Up to kFusedBlocks row blocks (the decoder's few thousand rows) K2 runs INSIDE K1: every block publishes its partial row
+// and takes a ticket; the block that draws the last one sums the partial rows in block order (the ticket decides WHO sums,
+// not the order) -- one launch instead of two for ~70 reductions of a step.  The tickets live in a ring of self-resetting
+// device counters (a call takes the next slots; the summing block stores 0 back).
+// Deterministic (no float atomics).  HBM-bound: one pass over the matrix.
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace efg {
 namespace {
@@ -52,11 +57,46 @@ struct Acc<false> {
   __device__ void store(float* p) const { *p = v; }
 };
 
+constexpr int kFusedBlocks = 128;   // row blocks up to which the final sum runs inside the partial kernel
+
+// Called by every thread of a block after its partial row is stored (by lanes of wave 0): true in the one block that has
+// to sum.  Release/acquire at agent scope: the partial rows were written through other XCDs' L2s.
+__device__ __forceinline__ bool draw_last_ticket(unsigned* counter, unsigned nblocks) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == nblocks - 1;
+    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for its next call
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// out[c] = sum_b partial[b][c] for the columns [c0, c0 + ncols) of this block's column group, blocks in index order
+// (four interleaved chains, combined in a fixed order).
+__device__ __forceinline__ void sum_partials_in_block(const float* __restrict__ partial, int nblocks, int cols, int c0,
+                                                      int ncols, float* __restrict__ out) {
+  for (int t = threadIdx.x; t < ncols; t += blockDim.x) {
+    const int c = c0 + t;
+    if (c >= cols) break;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] += partial[(long long)(b + i) * cols + c];
+    }
+    for (; b < nblocks; ++b) s[0] += partial[(long long)b * cols + c];
+    out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+  }
+}
+
 // slots = number of column slots (C / 4 float4 or C scalars); slot_log2 = log2(pow2ceil(min(slots, 64))).
 template <bool kVec>
 __global__ void __launch_bounds__(256)
 colsum_partial_kernel(const float* __restrict__ x, long long rows, int slots, long long row_stride,
-                      int rows_per_block, int slot_log2, int cols, float* __restrict__ partial) {
+                      int rows_per_block, int slot_log2, int cols, float* __restrict__ partial,
+                      unsigned* __restrict__ tickets, float* __restrict__ out) {
   constexpr int kW = kVec ? 4 : 1;
   __shared__ Acc<kVec> sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,6 +136,8 @@ colsum_partial_kernel(const float* __restrict__ x, long long rows, int slots, lo
     s.add(sm[3][lane]);
     s.store(partial + (long long)blockIdx.x * cols + (long long)slot * kW);
   }
+  if (tickets && draw_last_ticket(tickets + blockIdx.y, gridDim.x))
+    sum_partials_in_block(partial, gridDim.x, cols, blockIdx.y * 64 * kW, 64 * kW, out);
 }
 
 // The same pass with the ReLU backward folded in: g_out = g where y > 0 else 0 (what autograd's threshold_backward
@@ -104,7 +146,7 @@ colsum_partial_kernel(const float* __restrict__ x, long long rows, int slots, lo
 __global__ void __launch_bounds__(256)
 relu_bwd_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ y, long long rows, int slots,
                                long long row_stride, int rows_per_block, int slot_log2, int cols, float* __restrict__ g_out,
-                               float* __restrict__ partial) {
+                               float* __restrict__ partial, unsigned* __restrict__ tickets, float* __restrict__ out) {
   __shared__ Acc<true> sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int width = 1 << slot_log2;
@@ -153,6 +195,8 @@ relu_bwd_colsum_partial_kernel(const float* __restrict__ g, const float* __restr
     s.add(sm[3][lane]);
     s.store(partial + (long long)blockIdx.x * cols + (long long)slot * 4);
   }
+  if (tickets && draw_last_ticket(tickets + blockIdx.y, gridDim.x))
+    sum_partials_in_block(partial, gridDim.x, cols, blockIdx.y * 256, 256, out);
 }
 
 // kWaves = 16 for long partial lists (the 70 688-row matrices), 4 for the decoder-sized ones.
@@ -202,6 +246,36 @@ ColsumPlan colsum_plan(int64_t rows, int cols, int64_t row_stride, const void* x
   return p;
 }
 
+// Ticket counters of the fused final: a ring of zero-initialised device words per device; a call takes `n` consecutive ones
+// (one per column group).  A slot comes round again after kRing / n calls -- far beyond what a stream keeps in flight --
+// and each counter is back at 0 when its kernel ends.  nullptr (=> two launches) while the stream is being captured
+// before the ring exists (hipMalloc is not capturable).
+constexpr unsigned kRing = 8192;
+std::mutex g_ring_mu;
+unsigned* g_ring[64] = {};
+unsigned g_ring_next[64] = {};
+
+unsigned* ticket_slots(int n, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || n < 1 || (unsigned)n > kRing / 4) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ring_mu);
+  if (!g_ring[dev]) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned) * kRing) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned) * kRing) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_ring[dev] = p;
+  }
+  if (g_ring_next[dev] + (unsigned)n > kRing) g_ring_next[dev] = 0;
+  unsigned* out = g_ring[dev] + g_ring_next[dev];
+  g_ring_next[dev] += (unsigned)n;
+  return out;
+}
+
 }  // namespace
 }  // namespace efg
 
@@ -228,14 +302,16 @@ extern "C" int efg_colsum_f32(const float* x, int64_t rows, int cols, int64_t ro
   const ColsumPlan p = colsum_plan(rows, cols, row_stride, x);
   EFG_CHECK_ARG(ws_bytes >= sizeof(float) * (size_t)cols * (size_t)p.nblocks, "colsum: workspace too small");
   float* partial = p.nblocks == 1 ? out : static_cast<float*>(ws);
+  unsigned* tickets = p.nblocks > 1 && p.nblocks <= kFusedBlocks ? ticket_slots(p.ygroups, st) : nullptr;
   const dim3 grid(p.nblocks, p.ygroups);
   if (p.vec)
     hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, (long long)rows, p.slots,
-                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial);
+                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial, tickets, out);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, (long long)rows, p.slots,
-                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial);
+                       (long long)row_stride, p.rows_per_block, p.slot_log2, cols, partial, tickets, out);
   EFG_LAUNCH_CHECK();
+  if (tickets) return EFG_OK;
   if (p.nblocks > 64) {
     hipLaunchKernelGGL(colsum_final_kernel<16>, dim3((unsigned)ceil_div(cols, 64)), dim3(1024), 0, st, partial,
                        p.nblocks, cols, out);
@@ -265,9 +341,11 @@ extern "C" int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t r
   const ColsumPlan p = colsum_plan(rows, cols, cols, g);
   EFG_CHECK_ARG(ws_bytes >= sizeof(float) * (size_t)cols * (size_t)p.nblocks, "relu_bwd_colsum: workspace too small");
   float* partial = p.nblocks == 1 ? out : static_cast<float*>(ws);
+  unsigned* tickets = p.nblocks > 1 && p.nblocks <= kFusedBlocks ? ticket_slots(p.ygroups, st) : nullptr;
   hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(p.nblocks, p.ygroups), dim3(256), 0, st, g, y, (long long)rows, p.slots,
-                     (long long)cols, p.rows_per_block, p.slot_log2, cols, g_out, partial);
+                     (long long)cols, p.rows_per_block, p.slot_log2, cols, g_out, partial, tickets, out);
   EFG_LAUNCH_CHECK();
+  if (tickets) return EFG_OK;
   if (p.nblocks > 64) {
     hipLaunchKernelGGL(colsum_final_kernel<16>, dim3((unsigned)ceil_div(cols, 64)), dim3(1024), 0, st, partial, p.nblocks, cols,
                        out);

@@ -255,12 +255,22 @@ __global__ void __launch_bounds__(256) box_refine_fwd_kernel(const float* __rest
   out[i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-s)));
 }
 
+// ganchor (optional): the chain through inverse_sigmoid as autograd differentiates its clamps -- clamp(a, 0, 1) passes the
+// gradient for 0 <= a <= 1, clamp(., min = eps) for values >= eps: ds/da = [0 <= a <= 1] ([x >= eps] / x1 + [1 - x >= eps] / x2)
 __global__ void __launch_bounds__(256) box_refine_bwd_kernel(const float* __restrict__ grad, const float* __restrict__ out,
-                                                              long long n, float* __restrict__ gdelta) {
+                                                              const float* __restrict__ anchor, long long n, float eps,
+                                                              float* __restrict__ gdelta, float* __restrict__ ganchor) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float y = out[i];
-  gdelta[i] = __fmul_rn(__fmul_rn(grad[i], __fsub_rn(1.0f, y)), y);   // sigmoid_backward: grad * (1 - y) * y
+  const float gs = __fmul_rn(__fmul_rn(grad[i], __fsub_rn(1.0f, y)), y);   // sigmoid_backward: grad * (1 - y) * y
+  gdelta[i] = gs;
+  if (ganchor) {
+    const float a = anchor[i];
+    const float x = fminf(fmaxf(a, 0.0f), 1.0f), r = __fsub_rn(1.0f, x);
+    const float d = (x >= eps ? __fdiv_rn(1.0f, fmaxf(x, eps)) : 0.0f) + (r >= eps ? __fdiv_rn(1.0f, fmaxf(r, eps)) : 0.0f);
+    ganchor[i] = (a >= 0.0f && a <= 1.0f) ? __fmul_rn(gs, d) : 0.0f;
+  }
 }
 
 }  // namespace
@@ -344,11 +354,13 @@ extern "C" int efg_box_refine_forward_f32(const float* delta, const float* ancho
   return EFG_OK;
 }
 
-extern "C" int efg_box_refine_backward_f32(const float* grad, const float* out, int64_t n, float* grad_delta, void* stream) {
+extern "C" int efg_box_refine_backward_f32(const float* grad, const float* out, const float* anchor, int64_t n, float eps,
+                                           float* grad_delta, float* grad_anchor, void* stream) {
   EFG_CHECK_ARG(n >= 0 && (n == 0 || (grad && out && grad_delta)), "box_refine backward: bad arguments");
+  EFG_CHECK_ARG(!grad_anchor || anchor, "box_refine backward: the anchor gradient needs the anchors");
   if (n == 0) return EFG_OK;
   hipLaunchKernelGGL(box_refine_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, grad, out,
-                     (long long)n, grad_delta);
+                     anchor, (long long)n, eps, grad_delta, grad_anchor);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

@@ -3,6 +3,7 @@ tokens, top-k proposal selection, iterative-refinement decoder, momentum GT deco
 
 Module and parameter names follow the reference (encoder.layers.N.self_attn..., decoder.layers.N...,
 decoder.detection_head, proposal_head, decoder_gt) so state dicts are interchangeable."""
+import contextlib
 import os
 
 import torch
@@ -13,7 +14,7 @@ from torch.nn import functional as F
 from ..operators import attention
 from ..operators.det_loss import box_refine
 from ..operators.layernorm import add_layer_norm
-from ..operators.linear import Linear, linear
+from ..operators.linear import Linear, linear, self_attention_in_proj
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
 from .utils import MLP, flatten_with_shape, get_clones, inverse_sigmoid
@@ -89,8 +90,7 @@ class TransformerDecoderLayer(nn.Module):
                 and mha.in_proj_weight is not None):
             # csrc/attention.hip (long / 32-wide-head kernels): q | k from ONE projection of the shared input, the boolean
             # mask as bit rows, one gradient tensor for that projection
-            qk = F.linear(qk_in, mha.in_proj_weight[:2 * c], mha.in_proj_bias[:2 * c])
-            v = F.linear(v_in, mha.in_proj_weight[2 * c:], mha.in_proj_bias[2 * c:])
+            qk, v = self_attention_in_proj(qk_in, v_in, mha.in_proj_weight, mha.in_proj_bias)
             return F.linear(attention.long_self_attention(qk, v, attn_bits, h), mha.out_proj.weight, mha.out_proj.bias)
         q, v = qk_in.transpose(0, 1), v_in.transpose(0, 1)
         # need_weights=False: same output, skips materialising the head-averaged attention map the reference
@@ -110,7 +110,8 @@ class TransformerDecoderLayer(nn.Module):
         query2 = self.multihead_attn(_with_pos(query, query_pos), memory, memory_shape, None, memory_start_idx, None,
                                      ref_windows[..., :7])[0]
         query = add_layer_norm(query, self.dropout2(query2), self.norm2)
-        query2 = self.linear2(self.dropout(self.activation(self.linear1(query))))
+        hidden = linear(query, self.linear1.weight, self.linear1.bias, relu=True)   # activation(linear1(query))
+        query2 = self.linear2(self.dropout(hidden))
         return add_layer_norm(query, self.dropout3(query2), self.norm3)
 
 
@@ -199,6 +200,67 @@ class Transformer(nn.Module):
         out_ref_windows = torch.cat((boxes_k.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
         return None, None, out_ref_windows, indexes
 
+    def _gt_stream(self, device):
+        """Side stream of the momentum decoder (one per process and device, efg_amd/streams.py); None on the CPU or with
+        EFG_GT_STREAM=0."""
+        if device.type != "cuda" or os.environ.get("EFG_GT_STREAM", "1") == "0":
+            return None
+        from ..streams import side_stream
+
+        return side_stream(device, "gt_decoder")
+
+    def _launch_gt_decoder(self, memory, src_shape, src_start_index, targets, noised_gt_proposals):
+        """EMA update + momentum decoder over the GT boxes (and their positive-noised copies), $CQ/transformer.py:146-200.
+
+        The pass needs the encoder memory and the targets only, and nothing before the contrastive loss needs its result:
+        it is issued right after the encoder on its OWN stream, so that its ~160 launches (one graph replay) run beside
+        the proposal head and the decoder -- both are chains of small kernels that leave the device mostly idle -- instead
+        of after them.  Returns what _join_gt_decoder needs."""
+        main = torch.cuda.current_stream(memory.device) if memory.is_cuda else None
+        side = self._gt_stream(memory.device)
+        if side is not None:
+            side.wait_stream(main)   # the memory, the noised proposals, last step's optimizer update of the decoder
+        batch_size = len(targets)
+        per_gt_num = [tgt["gt_boxes"].shape[0] for tgt in targets]
+        max_gt_num = max(per_gt_num)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            if isinstance(targets, PaddedTargets):  # batched: padded rows are zeroed by the validity mask
+                valid = (torch.arange(max_gt_num)[None, :] < torch.tensor(per_gt_num)[:, None]).to(
+                    memory.device, non_blocking=True)
+                gt_with_score = torch.cat((targets.boxes[:, :max_gt_num],
+                                           F.one_hot(targets.labels[:, :max_gt_num], num_classes=self.num_classes)
+                                           .to(memory.dtype)), dim=-1) * valid[..., None]
+            else:
+                gt_with_score = memory.new_zeros(batch_size, max_gt_num, 10)
+                for bi in range(batch_size):
+                    gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
+                    gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
+                                                                        num_classes=self.num_classes)
+            with torch.no_grad(), record_function("efg::gt_decoder"):
+                self._momentum_update_gt_decoder()
+                if noised_gt_proposals is not None:
+                    dn_group_num = noised_gt_proposals.shape[1] // (max_gt_num * 2)
+                    pos_noised = torch.cat([noised_gt_proposals[:, pi * max_gt_num:(pi + 1) * max_gt_num]
+                                            for pi in range(0, dn_group_num * 2, 2)], dim=1)
+                    gt_proposals = torch.cat((gt_with_score, pos_noised), dim=1)
+                    n = (dn_group_num + 1) * max_gt_num
+                    grp = torch.arange(n, device=memory.device) // max_gt_num
+                    gt_attn_mask = grp[:, None] != grp[None, :]  # groups see only themselves
+                else:
+                    gt_proposals, gt_attn_mask = gt_with_score, None
+                hs_gt, inter_references_gt = self._run_gt_decoder(memory, src_shape, src_start_index,
+                                                                  gt_proposals, gt_attn_mask)
+        return hs_gt, inter_references_gt, gt_proposals, side, main
+
+    @staticmethod
+    def _join_gt_decoder(run):
+        hs_gt, inter_references_gt, gt_proposals, side, main = run
+        if side is not None:
+            main.wait_stream(side)
+            for t in (hs_gt, inter_references_gt, gt_proposals):   # allocated on the side stream, read on the main one
+                t.record_stream(main)
+        return hs_gt, inter_references_gt, gt_proposals
+
     def _run_gt_decoder(self, memory, src_shape, src_start_index, gt_proposals, gt_attn_mask):
         """The momentum decoder is a no-grad pass of ~160 small kernels over a few hundred queries: 2.5-3.8 ms of
         host launch work for 1.2 ms of device time, on a step whose host side is within 10 % of its device side.
@@ -275,39 +337,15 @@ class Transformer(nn.Module):
             noised_gt_proposals = torch.cat((noised_gt_box, noised_gt_onehot), dim=-1)
             topk_proposals = torch.cat((noised_gt_proposals, topk_proposals), dim=1)
         init_reference_out = topk_proposals[..., :7]
+        gt_run = None
+        if targets is not None:  # momentum GT decoder pass (:146-200): issued BEFORE the decoder, beside it (see _launch_gt_decoder)
+            gt_run = self._launch_gt_decoder(memory, src_shape, src_start_index, targets,
+                                             noised_gt_proposals if noised_gt_box is not None else None)
         with record_function("efg::decoder"):
             hs, inter_references = self.decoder(query_embed, query_pos, memory, src_shape, src_start_index,
                                                 topk_proposals, attn_mask)
-        if targets is not None:  # momentum GT decoder pass (:146-200)
-            batch_size = len(targets)
-            per_gt_num = [tgt["gt_boxes"].shape[0] for tgt in targets]
-            max_gt_num = max(per_gt_num)
-            if isinstance(targets, PaddedTargets):  # batched: padded rows are zeroed by the validity mask
-                valid = (torch.arange(max_gt_num)[None, :] < torch.tensor(per_gt_num)[:, None]).to(
-                    memory.device, non_blocking=True)
-                gt_with_score = torch.cat((targets.boxes[:, :max_gt_num],
-                                           F.one_hot(targets.labels[:, :max_gt_num], num_classes=self.num_classes)
-                                           .to(memory.dtype)), dim=-1) * valid[..., None]
-            else:
-                gt_with_score = memory.new_zeros(batch_size, max_gt_num, 10)
-                for bi in range(batch_size):
-                    gt_with_score[bi, : per_gt_num[bi], :7] = targets[bi]["gt_boxes"]
-                    gt_with_score[bi, : per_gt_num[bi], 7:] = F.one_hot(targets[bi]["labels"],
-                                                                        num_classes=self.num_classes)
-            with torch.no_grad(), record_function("efg::gt_decoder"):
-                self._momentum_update_gt_decoder()
-                if noised_gt_box is not None:
-                    dn_group_num = noised_gt_proposals.shape[1] // (max_gt_num * 2)
-                    pos_noised = torch.cat([noised_gt_proposals[:, pi * max_gt_num:(pi + 1) * max_gt_num]
-                                            for pi in range(0, dn_group_num * 2, 2)], dim=1)
-                    gt_proposals = torch.cat((gt_with_score, pos_noised), dim=1)
-                    n = (dn_group_num + 1) * max_gt_num
-                    grp = torch.arange(n, device=memory.device) // max_gt_num
-                    gt_attn_mask = grp[:, None] != grp[None, :]  # groups see only themselves
-                else:
-                    gt_proposals, gt_attn_mask = gt_with_score, None
-                hs_gt, inter_references_gt = self._run_gt_decoder(memory, src_shape, src_start_index,
-                                                                  gt_proposals, gt_attn_mask)
+        if gt_run is not None:
+            hs_gt, inter_references_gt, gt_proposals = self._join_gt_decoder(gt_run)
             init_reference_out = torch.cat((init_reference_out, gt_proposals[..., :7]), dim=1)
             hs = torch.cat((hs, hs_gt), dim=2)
             inter_references = torch.cat((inter_references, inter_references_gt), dim=2)

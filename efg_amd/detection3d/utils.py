@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..operators.linear import Linear
+from ..operators.linear import Linear, linear
 
 
 class MLP(nn.Module):
@@ -19,7 +19,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            # hidden layers: Linear + ReLU as one product with a fused epilogue / one-launch backward (operators/linear.py)
+            x = linear(x, layer.weight, layer.bias, relu=True) if i < self.num_layers - 1 else layer(x)
         return x
 
 

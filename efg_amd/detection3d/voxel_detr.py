@@ -73,6 +73,7 @@ def collate(samples, device):
 class VoxelDETR(nn.Module):
     # set by engine.Trainer for the bucketed (overlapped) gradient exchange: callable(key, activation); see forward()
     grad_watch = None
+    plain_loss_dict = False   # True: forward returns a plain dict of the scalar loss terms (torch DDP's output traversal)
 
     def __init__(self, config):
         super().__init__()
@@ -261,7 +262,8 @@ class VoxelDETR(nn.Module):
         if not self.training:
             return self._inference(outputs_class, outputs_coord)
         with record_function("efg::losses"):
-            return self._losses(outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes)
+            losses = self._losses(outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes)
+            return dict(losses) if self.plain_loss_dict else losses   # (torch DDP wrappers: engine.Trainer)
 
     def _losses(self, outputs_class, outputs_coord, targets, dn_meta, src_embed, src_ref_windows, src_indexes):
         head = self.transformer.decoder.detection_head

@@ -456,6 +456,11 @@ class Trainer:
                 elif mode != "plain":
                     raise ValueError("EFG_DDP_MODE must be flat, bucket, static, find_unused or plain, got %r" % mode)
                 dev_ids = [torch.cuda.current_device()] if self.model.device.type == "cuda" else None
+                # torch DDP looks for the tensors of the forward output with pytree, which knows `dict` but treats a dict
+                # SUBCLASS as an opaque leaf: with the model's LossDict it would see no output at all (static_graph: the
+                # delayed all-reduce is never triggered; find_unused: every parameter counts as unused).  These modes get
+                # the plain dict of scalar terms -- and the trainer sums its values, as the reference does.
+                self.model.plain_loss_dict = True
                 self.wrapped = torch.nn.parallel.DistributedDataParallel(
                     self.model, device_ids=dev_ids, broadcast_buffers=False,
                     bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),

@@ -86,32 +86,38 @@ class BoxLossLayers(Function):
 
 
 class BoxRefineFunction(Function):
-    """sigmoid(delta + inverse_sigmoid(anchor)) in one launch each way (csrc/det_loss.hip); `anchor` carries no gradient
-    (the reference detaches the reference windows between layers, $CQ/transformer.py:331-336)."""
+    """sigmoid(delta + inverse_sigmoid(anchor)) in one launch each way (csrc/det_loss.hip).  The decoder's reference windows
+    are detached between layers ($CQ/transformer.py:331-336) -- no anchor gradient; the model's per-layer heads refine the
+    previous layer's UNdetached boxes ($CQ/voxel_detr.py:171-180) -- the same launch also returns the anchor gradient."""
 
     @staticmethod
     def forward(ctx, delta, anchor, eps):
         d, a = delta.contiguous(), anchor.contiguous()
         out = torch.empty_like(d)
         L.check(L.lib().efg_box_refine_forward_f32(L.ptr(d), L.ptr(a), d.numel(), float(eps), L.ptr(out), L.stream()))
-        ctx.save_for_backward(out)
+        ctx.eps = float(eps)
+        ctx.save_for_backward(out, a if anchor.requires_grad else None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad):
-        (out,) = ctx.saved_tensors
+        out, anchor = ctx.saved_tensors
         g = grad.contiguous()
         gd = torch.empty_like(out)
-        L.check(L.lib().efg_box_refine_backward_f32(L.ptr(g), L.ptr(out), out.numel(), L.ptr(gd), L.stream()))
-        return gd, None, None
+        ga = torch.empty_like(out) if anchor is not None and ctx.needs_input_grad[1] else None
+        L.check(L.lib().efg_box_refine_backward_f32(L.ptr(g), L.ptr(out), L.ptr(anchor) if ga is not None else None,
+                                                    out.numel(), ctx.eps, L.ptr(gd), L.ptr(ga) if ga is not None else None,
+                                                    L.stream()))
+        return gd, ga, None
 
 
 def box_refine(delta, anchor, eps=1e-5):
-    """(delta + inverse_sigmoid(anchor)).sigmoid() -- $CQ/heads.py:78.  GPU fp32 tensors of equal shape whose anchor needs
-    no gradient take the fused kernel; anything else the PyTorch formulation (same math)."""
+    """(delta + inverse_sigmoid(anchor)).sigmoid() -- $CQ/heads.py:78.  GPU fp32 tensors of equal shape take the fused
+    kernel; anything else the PyTorch formulation (same math)."""
     if (delta.is_cuda and delta.dtype == torch.float32 and anchor.dtype == torch.float32 and delta.shape == anchor.shape
-            and not anchor.requires_grad and os.environ.get("EFG_FUSED_LOSS", "1") != "0"):
+            and (not anchor.requires_grad or os.environ.get("EFG_SMALL_FUSED", "1") != "0")
+            and os.environ.get("EFG_FUSED_LOSS", "1") != "0"):
         return BoxRefineFunction.apply(delta, anchor, eps)
     x = anchor.clamp(min=0, max=1)
     return (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()

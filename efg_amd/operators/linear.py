@@ -18,13 +18,15 @@ from torch.autograd.function import once_differentiable
 from .. import _lib as L
 
 
-def column_sum(x2):
-    """x2 [rows, cols] fp32 on the GPU (rows may be strided) -> [cols], deterministic."""
+def column_sum(x2, out=None):
+    """x2 [rows, cols] fp32 on the GPU (rows may be strided) -> [cols] (into `out`, a contiguous [cols] view, if given),
+    deterministic."""
     L.require_gpu(x2)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
     rows, cols = x2.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x2.device)
     ws_bytes = L.lib().efg_colsum_workspace_bytes(rows, cols)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x2.device)
     L.check(L.lib().efg_colsum_f32(x2.data_ptr(), rows, cols, x2.stride(0) if rows > 1 else cols, L.ptr(out), L.ptr(ws),
@@ -48,6 +50,8 @@ def relu_backward_column_sum(g2, y):
 _SPLIT_MIN_ROWS = 32768
 _FUSED_MIN_ROWS = int(os.environ.get("EFG_LINEAR_MIN_ROWS", "16384"))  # linear(): rows from which the custom backward is used
 _SPLITS = 16
+# EFG_SMALL_FUSED=0: the decoder-sized Linear + ReLU layers and the self-attention in-projection as plain PyTorch ops (A/B)
+_SMALL_FUSED = os.environ.get("EFG_SMALL_FUSED", "1") != "0"
 
 
 # The A/B arm of the bench (EFG_GEMM_ARM=bf16x3, never the default): forward and data-gradient products of the long
@@ -60,10 +64,11 @@ _ARM_BF16X3 = os.environ.get("EFG_GEMM_ARM", "") == "bf16x3"
 
 
 def _arm_ok(a2, min_cols=64):
-    """a2: the [rows, K] operand of a product.  Below K = 64 the split product loses to fp32 (op bench: 32 -> 256 29.6 vs
+    """a2: the [rows, K] operand of a product: the long matrices only (the decoder-sized Linear + ReLU layers also come
+    through LinearFunction since round 4 and stay exact fp32).  Below K = 64 the split product loses to fp32 (op bench: 32 -> 256 29.6 vs
     26.2 us; the 32-row weight gradient 44.5 vs 28.5 us)."""
     return (_ARM_BF16X3 and a2.dim() == 2 and a2.stride(1) == 1 and a2.shape[1] % 4 == 0 and a2.stride(0) % 4 == 0
-            and a2.data_ptr() % 16 == 0 and a2.shape[0] > 0 and a2.shape[1] >= min_cols)
+            and a2.data_ptr() % 16 == 0 and a2.shape[0] >= _FUSED_MIN_ROWS and a2.shape[1] >= min_cols)
 
 
 def weight_grad(x2, g2):
@@ -94,10 +99,13 @@ class LinearFunction(Function):
 
             packed_fwd, ctx.packed_dgrad = G.pack_linear_both(weight.detach())
             y = G.gemm(x2, packed_fwd, weight.shape[0], bias=bias, relu=relu)
-        elif relu and bias is not None:
-            # bias + ReLU in the GEMM epilogue (hipBLASLt): bit-identical to relu(addmm(...)), and the 290 MB
-            # activation of the encoder FFN is written once instead of written, read and written again
-            # (scripts/ubench/addmm_relu.py: 294 us against 304 + 103 us)
+        elif relu and bias is not None and x2.shape[0] >= _FUSED_MIN_ROWS:
+            # bias + ReLU in the GEMM epilogue (hipBLASLt): bit-identical to relu(addmm(...)) on finite values, and the
+            # 290 MB activation of the encoder FFN is written once instead of written, read and written again
+            # (scripts/ubench/addmm_relu.py: 294 us against 304 + 103 us).  Long matrices only: on the decoder's few
+            # thousand rows the epilogue product is no faster than addmm + relu_ (16.5 against 12.9 + 5.5 us, an
+            # untuned solution), and its max(x, 0) turns a NaN into 0 where torch.relu keeps it -- the non-finite
+            # checks of the engine (tests/test_engine.py) rely on a NaN reaching the loss.
             y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
         else:
             y = torch.addmm(bias, x2, weight.t()) if bias is not None else x2.mm(weight.t())
@@ -133,6 +141,56 @@ class LinearFunction(Function):
         return gx, gw, gb, None
 
 
+class SelfAttentionInProjFunction(Function):
+    """(qk, v) = (qk_in W[:2c]^T + b[:2c], v_in W[2c:]^T + b[2c:]) for nn.MultiheadAttention's packed in_proj parameters
+    ($CQ/transformer.py:291-295 calls the module with query = key != value).  Slicing the parameters in Python makes autograd
+    build each slice's gradient as a zero-filled [3c, c] tensor plus a copy and add the pieces (17 launches per layer);
+    here the backward writes both products and both bias sums straight into ONE [3c, c] / [3c] gradient (6 launches)."""
+
+    @staticmethod
+    def forward(ctx, qk_in, v_in, weight, bias):
+        c = weight.shape[1]
+        q2, v2 = qk_in.reshape(-1, c), v_in.reshape(-1, c)
+        qk = torch.addmm(bias[:2 * c], q2, weight[:2 * c].t())
+        v = torch.addmm(bias[2 * c:], v2, weight[2 * c:].t())
+        ctx.save_for_backward(q2, v2, weight)
+        ctx.shapes = (qk_in.shape, v_in.shape)
+        return qk.view(*qk_in.shape[:-1], 2 * c), v.view(*v_in.shape[:-1], c)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gqk, gv):
+        q2, v2, weight = ctx.saved_tensors
+        c = weight.shape[1]
+        gqk2, gv2 = gqk.reshape(-1, 2 * c), gv.reshape(-1, c)
+        if not gqk2.is_contiguous():
+            gqk2 = gqk2.contiguous()
+        if not gv2.is_contiguous():
+            gv2 = gv2.contiguous()
+        g_qk_in = gqk2.mm(weight[:2 * c]).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        g_v_in = gv2.mm(weight[2 * c:]).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        gw = gb = None
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty_like(weight)
+            torch.mm(gqk2.t(), q2, out=gw[:2 * c])
+            torch.mm(gv2.t(), v2, out=gw[2 * c:])
+        if ctx.needs_input_grad[3]:
+            gb = torch.empty(3 * c, dtype=torch.float32, device=weight.device)
+            column_sum(gqk2, out=gb[:2 * c])
+            column_sum(gv2, out=gb[2 * c:])
+        return g_qk_in, g_v_in, gw, gb
+
+
+def self_attention_in_proj(qk_in, v_in, weight, bias):
+    """q | k from one projection of `qk_in`, v from `v_in`, with nn.MultiheadAttention's in_proj_weight [3c, c] / in_proj_bias."""
+    c = weight.shape[1]
+    if (_SMALL_FUSED and qk_in.is_cuda and qk_in.dtype == torch.float32 and torch.is_grad_enabled() and bias is not None
+            and (weight.requires_grad or qk_in.requires_grad or v_in.requires_grad)
+            and os.environ.get("EFG_FUSED_LINEAR", "1") != "0"):
+        return SelfAttentionInProjFunction.apply(qk_in, v_in, weight, bias)
+    return F.linear(qk_in, weight[:2 * c], bias[:2 * c]), F.linear(v_in, weight[2 * c:], bias[2 * c:])
+
+
 def linear(x, weight, bias=None, relu=False):
     """F.linear (followed by ReLU when `relu`); on the GPU, in training, on long matrices with the backward of
     this module."""
@@ -140,8 +198,10 @@ def linear(x, weight, bias=None, relu=False):
     # backward: there it saves 50-70 us of device time per layer.  On the decoder's few thousand rows the saving is
     # ~5 us per layer while a Python autograd.Function costs ~30 us more host time than F.linear, and the step is
     # close enough to host-bound (~31 ms of launch work against ~36 ms of kernels) for that to matter.
+    # Linear + ReLU takes it at every size: bias + ReLU ride in the GEMM epilogue, and the backward's threshold + bias
+    # gradient are ONE launch (csrc/colsum.hip) where autograd runs relu, threshold_backward and a two-launch sum.
     if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-            and x.numel() >= _FUSED_MIN_ROWS * x.shape[-1]
+            and (x.numel() >= _FUSED_MIN_ROWS * x.shape[-1] or (_SMALL_FUSED and relu and bias is not None and weight.shape[0] % 4 == 0))
             and (weight.requires_grad or (bias is not None and bias.requires_grad))
             and os.environ.get("EFG_FUSED_LINEAR", "1") != "0"):
         return LinearFunction.apply(x, weight, bias, relu)

@@ -478,9 +478,12 @@ int efg_topk_unsorted_f32(const float* x, int64_t rows, int n, int k, float* val
 
 /* Iterative box refinement of the detection heads ($CQ/heads.py:76-79, $CQ/transformer.py:60-81):
  *   out = sigmoid(delta + inverse_sigmoid(anchor)), inverse_sigmoid as $CQ/modules/utils.py:83-87 (eps 1e-5);
- * n elements, any shape.  Backward: grad_delta = grad * out * (1 - out) (the anchors are detached reference windows). */
+ * n elements, any shape.  Backward: grad_delta = grad * out * (1 - out); with `grad_anchor` (NULL where the anchors are
+ * detached reference windows; the heads' aux outputs of layers >= 1 pass anchors with a graph, $CQ/voxel_detr.py:171-180)
+ * also grad_anchor = grad_delta * d inverse_sigmoid(anchor), the clamps differentiated as autograd does. */
 int efg_box_refine_forward_f32(const float* delta, const float* anchor, int64_t n, float eps, float* out, void* stream);
-int efg_box_refine_backward_f32(const float* grad, const float* out, int64_t n, float* grad_delta, void* stream);
+int efg_box_refine_backward_f32(const float* grad, const float* out, const float* anchor, int64_t n, float eps,
+                                float* grad_delta, float* grad_anchor, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d (training statistics) + optional residual + optional ReLU over sparse features [m, c]

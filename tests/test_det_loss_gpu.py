@@ -126,6 +126,31 @@ def test_box_refine_matches_the_reference_formulation():
         torch.testing.assert_close(box_refine(delta, anchor), ref.detach(), rtol=2e-6, atol=2e-7)
 
 
+def test_box_refine_returns_the_anchor_gradient_of_undetached_boxes():
+    """The model's per-layer heads refine the previous layer's boxes WITH their graph ($CQ/voxel_detr.py:171-180): the
+    anchor gradient comes out of the same backward launch, the clamps of inverse_sigmoid differentiated as autograd
+    differentiates them (zero outside [0, 1] and below the eps clamps)."""
+    from efg_amd.operators.det_loss import box_refine
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    delta = (torch.randn(2, 1240, 7, generator=g) * 2).to(dev).requires_grad_(True)
+    a0 = torch.rand(2, 1240, 7, generator=g)
+    a0[0, :9, 0] = torch.tensor([0.0, 1.0, -0.3, 1.7, 1e-6, 1 - 1e-6, 0.5, 2e-5, 1 - 2e-5])
+    anchor = a0.to(dev).requires_grad_(True)
+    out = box_refine(delta, anchor)
+    assert type(out.grad_fn).__name__ == "BoxRefineFunctionBackward"
+    d2, a2 = delta.detach().clone().requires_grad_(True), anchor.detach().clone().requires_grad_(True)
+    x = a2.clamp(min=0, max=1)
+    ref = (d2 + torch.log(x.clamp(min=1e-5) / (1 - x).clamp(min=1e-5))).sigmoid()
+    w = torch.randn(out.shape, generator=g).to(dev)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(out, ref, rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(delta.grad, d2.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(anchor.grad, a2.grad, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("n,k", [(35344, 1000), (35344, 900), (5000, 5000), (1500, 1), (70000, 300)])
 def test_topk_unsorted_is_exact_and_breaks_ties_by_index(n, k):
     """csrc/topk.hip against torch.topk: the same VALUES (multiset), indices in ascending order; with a plateau of equal

@@ -52,6 +52,30 @@ def test_column_sum_exact_on_integers():
         assert torch.equal(column_sum(x), x.double().sum(0).float())
 
 
+def test_column_sum_single_launch_tickets_wrap_and_reset():
+    """Up to 128 row blocks the final sum runs inside the partial kernel, the block that draws the last ticket of a ring of
+    self-resetting counters doing it: ~10 000 back-to-back calls (the ring has 8192 slots; the wide matrix takes 4 per
+    call) on two streams keep giving the first call's bits."""
+    from efg_amd.operators.linear import column_sum, relu_backward_column_sum
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(2480, 256, device="cuda", generator=g)
+    b = torch.randn(2800, 1024, device="cuda", generator=g)
+    y = torch.relu(torch.randn(2800, 1024, device="cuda", generator=g))
+    ra, rb = column_sum(a), relu_backward_column_sum(b, y)[1]
+    assert torch.equal(rb, column_sum(torch.ops.aten.threshold_backward(b, y, 0)))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    bad_side = torch.zeros((), dtype=torch.int64, device="cuda")
+    for i in range(2500):
+        bad += (column_sum(a) != ra).sum()
+        with torch.cuda.stream(side):
+            bad_side += (relu_backward_column_sum(b, y)[1] != rb).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0 and int(bad_side) == 0
+
+
 @pytest.mark.parametrize("shape,fin,fout", [((2, 1240, 256), 256, 256), ((1240, 2, 256), 256, 1024),
                                              ((2, 35344, 256), 256, 200), ((2, 300, 10), 10, 256), ((77, 256), 256, 3)])
 def test_linear_matches_nn_linear(shape, fin, fout):
@@ -171,6 +195,36 @@ def test_relu_backward_column_sum(rows, cols):
     assert torch.equal(sums, column_sum(want))
     ref = want.double().sum(0)
     assert float((sums.double() - ref).abs().max()) <= 1e-5 * float(want.abs().double().sum(0).max()) + 1e-12
+
+
+@pytest.mark.parametrize("same_input", [False, True])
+def test_self_attention_in_proj_matches_sliced_linears(same_input):
+    """operators/linear.py:self_attention_in_proj against F.linear on slices of the packed parameters (what
+    nn.MultiheadAttention computes): same values, one [3c, c] / [3c] gradient without slice-backward nodes."""
+    import torch.nn.functional as F
+
+    from efg_amd.operators.linear import self_attention_in_proj
+
+    torch.manual_seed(4)
+    c = 256
+    w = (torch.randn(3 * c, c, device="cuda") * 0.05).requires_grad_(True)
+    b = torch.randn(3 * c, device="cuda").requires_grad_(True)
+    v_in = torch.randn(2, 1240, c, device="cuda", requires_grad=True)
+    qk_in = v_in if same_input else torch.randn(2, 1240, c, device="cuda", requires_grad=True)
+    qk, v = self_attention_in_proj(qk_in, v_in, w, b)
+    assert type(qk.grad_fn).__name__ == "SelfAttentionInProjFunctionBackward"
+    wr, br, vr = (t.detach().clone().requires_grad_(True) for t in (w, b, v_in))
+    qr = vr if same_input else qk_in.detach().clone().requires_grad_(True)
+    qk_ref, v_ref = F.linear(qr, wr[:2 * c], br[:2 * c]), F.linear(vr, wr[2 * c:], br[2 * c:])
+    assert torch.equal(qk, qk_ref) and torch.equal(v, v_ref)
+    u1, u2 = torch.randn_like(qk), torch.randn_like(v)
+    ((qk * u1).sum() + (v * u2).sum()).backward()
+    ((qk_ref * u1).sum() + (v_ref * u2).sum()).backward()
+    assert torch.allclose(w.grad, wr.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(b.grad, br.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(v_in.grad, vr.grad, rtol=1e-5, atol=1e-5)
+    if not same_input:
+        assert torch.allclose(qk_in.grad, qr.grad, rtol=1e-5, atol=1e-5)
 
 
 def test_linear_refuses_nothing_on_cpu():
