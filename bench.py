@@ -52,9 +52,10 @@ def parse():
     ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")
     ap.add_argument("--full-graph", action="store_true", help="make the full reference graph the headline run")
     ap.add_argument("--ddp-mode", default=None, choices=["bucket", "flat", "static", "find_unused", "plain"],
-                    help="N > 1 gradient exchange (engine.Trainer): bucket = three flat buckets all-reduced on a communication "
-                         "stream while backward still runs (default, what the reference's DDP does); flat = one all-reduce "
-                         "after backward; static / find_unused / plain = torch DistributedDataParallel variants")
+                    help="N > 1 gradient exchange (engine.Trainer): flat = one all-reduce after backward (default); bucket = "
+                         "three flat buckets all-reduced on a communication stream while backward still runs (what the "
+                         "reference's DDP does; not the default, see engine.py); static / find_unused / plain = torch "
+                         "DistributedDataParallel variants")
     return ap.parse_args()
 
 

@@ -430,15 +430,19 @@ class Trainer:
         self.grad_sync = None
         self.ddp_mode = None
         if use_ddp:
-            # "bucket" (default): three flat buckets, each all-reduced on a communication stream as soon as backward has
-            # produced it -- the exchange OVERLAPS backward, as the reference's DDP reducer does
-            # (efg/engine/trainer.py:191-198) and BASELINE.json's north_star asks (BucketedGradientAllReduce).
-            # "flat": one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
+            # "flat" (default): one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
+            # "bucket": three flat buckets, each all-reduced on a communication stream as soon as backward has produced it --
+            # the exchange OVERLAPS backward, as the reference's DDP reducer does (efg/engine/trainer.py:191-198) and
+            # BASELINE.json's north_star asks (BucketedGradientAllReduce).  NOT the default: with a live RCCL communicator
+            # and the 8 hardware queues the step otherwise wants, collectives that run beside backward double the step on
+            # this stack (1 rank, no wire: bucket 68-71 ms, torch DDP static_graph 72 ms, flat 32.3 ms; with
+            # GPU_MAX_HW_QUEUES=2 bucket 32.6 / flat 32.8; profiles/r04_ddp_modes_hw_queues.txt) -- until a multi-GPU node
+            # says otherwise the exchange that cannot run beside anything is the safe one.
             # "static" / "find_unused" / "plain": torch DistributedDataParallel as in the reference, with
             # static_graph=True / find_unused_parameters=True ($CQ/config.yaml:183) / neither.  The literal
             # find_unused_parameters setting costs +14 ms/step: with locally unused parameters (the skipped FPN
             # levels) DDP makes a BLOCKING D2H copy of its "used" bitmap at the end of every backward.
-            mode = ddp_mode or os.environ.get("EFG_DDP_MODE", "bucket")
+            mode = ddp_mode or os.environ.get("EFG_DDP_MODE", "flat")
             self.ddp_mode = mode
             if mode == "bucket" and not hasattr(self.model, "grad_watch"):
                 mode = self.ddp_mode = "flat"   # a model without the bucket hooks (CenterPoint, TrajectoryFormer)
