@@ -532,7 +532,6 @@ struct WriteArgs {
   float* mean;
   int f, rs, max_points, coors_cols, out_base, scene;
   unsigned beg;
-  int exp;   // timing experiments only (EFG_VOX_EXP): 1 = no row / padding stores, 2 = no row loads
 };
 
 __device__ __forceinline__ void voxel_coords(const WriteArgs& a, const BinGeom& bg, unsigned sc, unsigned lc, long long vid,
@@ -558,7 +557,7 @@ struct __attribute__((packed, aligned(4))) i4u {
 // The common shapes (max_points == KMAX, f == F, both compile-time: ConQueR / Voxel-DETR 5 x 5, CenterPoint 4-sweep
 // 5 x 6) written with 16-byte stores: 7 + 2 + 1 store instructions per voxel instead of 25 + 5 + 4 four-byte ones.
 // A lane's scattered store costs the address pipeline one cache line whatever its width; with the four-byte stores the
-// output stores were a third of the kernel (EFG_VOX_EXP=1: 39 -> 27 us).
+// output stores were a third of the kernel (a build without them: 39 -> 27 us).
 template <int KMAX, int F>
 __device__ __forceinline__ void emit_voxel_static(const WriteArgs& a, const BinGeom& bg, unsigned sc, unsigned lc,
                                                   unsigned bin_base, const unsigned* seg_idx, const unsigned* seg_e,
@@ -590,10 +589,6 @@ __device__ __forceinline__ void emit_voxel_static(const WriteArgs& a, const BinG
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const float4* r = reinterpret_cast<const float4*>(a.rows + ((size_t)bin_base + be[k < kept ? k : 0]) * 8);   // rs == 8
-    if (a.exp & 2) {
-      r0[k] = r1[k] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
-      continue;
-    }
     r0[k] = r[0];
     r1[k] = F > 4 ? r[1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
@@ -628,7 +623,7 @@ __device__ __forceinline__ void emit_voxel_static(const WriteArgs& a, const BinG
       acc[t] = __fadd_rn(acc[t], v);   // slot order, like the reader's sum(dim=1); + 0.0f past `kept` changes nothing
     }
   }
-  if (!(a.exp & 1)) {
+  {
     float* o = a.voxels + vid * (KMAX * F);
 #pragma unroll
     for (int q = 0; q + 4 <= KMAX * F; q += 4) {
@@ -687,10 +682,6 @@ __device__ __forceinline__ void emit_voxel(const WriteArgs& a, const BinGeom& bg
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       const float4* r = reinterpret_cast<const float4*>(a.rows + ((size_t)bin_base + be[k < kept ? k : 0]) * a.rs);
-      if (a.exp & 2) {
-        r0[k] = r1[k] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
-        continue;
-      }
       r0[k] = r[0];
       r1[k] = a.rs > 4 ? r[1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
@@ -706,7 +697,7 @@ __device__ __forceinline__ void emit_voxel(const WriteArgs& a, const BinGeom& bg
       if (k < kept) {
 #define EFG_VOX_PUT(t, val)                  \
   if (t < a.f) {                             \
-    if (!(a.exp & 1)) o[k * a.f + t] = val;  \
+    o[k * a.f + t] = val;                    \
     acc[t] = __fadd_rn(acc[t], val); /* slot order, like the reader's sum(dim=1) */ \
   }
         EFG_VOX_PUT(0, r0[k].x)
@@ -720,8 +711,7 @@ __device__ __forceinline__ void emit_voxel(const WriteArgs& a, const BinGeom& bg
 #undef EFG_VOX_PUT
       }
     }
-    if (!(a.exp & 1))
-      for (int k = kept * a.f; k < a.max_points * a.f; ++k) o[k] = 0.0f;
+    for (int k = kept * a.f; k < a.max_points * a.f; ++k) o[k] = 0.0f;
     if (a.mean) {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -776,7 +766,7 @@ vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, cons
                  const int* __restrict__ voxel_num, int max_points, int coors_cols, float* __restrict__ voxels,
                  int* __restrict__ coors, int* __restrict__ npv, float* __restrict__ mean,
                  unsigned* __restrict__ seg_idx_g, unsigned* __restrict__ seg_e_g, size_t seg_stride,
-                 unsigned long long* dbg, int exp) {
+                 unsigned long long* dbg) {
   __shared__ unsigned tab[kWriteLds];
   __shared__ int smem[17];
   mark(dbg, 4, 0);
@@ -799,7 +789,6 @@ vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, cons
   a.coors_cols = coors_cols;
   a.scene = scene;
   a.beg = (unsigned)so.off[scene];
-  a.exp = exp;
   a.out_base = 0;
   for (int b = 0; b < scene; ++b) a.out_base += voxel_num[b];
   const unsigned ib = i_break[scene];  // points from here on are never processed (voxelization_cpu.cpp:78-79)
@@ -1096,12 +1085,11 @@ int bins_hard_voxelize(const HardArgs& a) {
   hipLaunchKernelGGL(vox_rank_kernel, dim3(nchunks2, batch), blk, 0, stream, so, sw, flags, part2, nchunks2, bits, prefix,
                      a.voxel_num, i_break, a.max_voxels, g_dbg);
   EFG_LAUNCH_CHECK();
-  const int exp = getenv("EFG_VOX_EXP") ? atoi(getenv("EFG_VOX_EXP")) : 0;   // (timing experiments: wrong results)
   if (a.n_total > 0) {
 #define EFG_VOX_WRITE(KM, FF)                                                                                            \
   hipLaunchKernelGGL((vox_write_kernel<KM, FF>), dim3(gx, batch), blk, 0, stream, so, sw, L.bg, f, L.rs, small_list,       \
                      big_list, nlist, meta, rows, bits, prefix, i_break, a.voxel_num, a.max_points, a.coors_cols, a.voxels, \
-                     a.coors, a.npv, a.mean, seg_idx, seg_e, (size_t)L.n, g_dbg, exp)
+                     a.coors, a.npv, a.mean, seg_idx, seg_e, (size_t)L.n, g_dbg)
     if (a.max_points == 5 && f == 5) EFG_VOX_WRITE(5, 5);
     else if (a.max_points == 5 && f == 6) EFG_VOX_WRITE(5, 6);
     else if (a.max_points <= 5 && f <= 8) EFG_VOX_WRITE(5, 0);
