@@ -182,13 +182,13 @@ class Det3DLoss(nn.Module):
                                          num_boxes, parts=("ce",))
             bx, _ = self._layer_losses(None, m_boxes, sel, tgt_labels, tgt_boxes, num_boxes, parts=("box",))
             per_layer = {"loss_ce": ce["loss_ce"], **{k: v for k, v in bx.items() if k != "loss_ce"}}
-            self._metric_logits = m_logits[sel[0], sel[1], sel[2]]
+            self.__dict__["_metric_logits"] = m_logits[sel[0], sel[1], sel[2]]
         else:
             per_layer, cls = self._layer_losses(logits, boxes, sel, tgt_labels, tgt_boxes, num_boxes)
             # pairs are ordered layer-major: the last layer's are the final n_gt entries
-            self._metric_logits = logits[-1][sel[1][-n_gt:], sel[2][-n_gt:]] if n_gt else logits[-1][:0, 0]
+            self.__dict__["_metric_logits"] = logits[-1][sel[1][-n_gt:], sel[2][-n_gt:]] if n_gt else logits[-1][:0, 0]
             cls = cls[-n_gt:] if n_gt else cls[:0]
-        self._metric_classes = cls
+        self.__dict__["_metric_classes"] = cls   # (plain attributes, set past nn.Module.__setattr__)
 
         # every family is an [L] vector (aux layers first, the final layer last): the scalar entries are views of it
         fam_keys, fam_vecs = [], []

@@ -196,7 +196,9 @@ class Transformer(nn.Module):
         emb_k = torch.gather(enc_embed, 1, indexes.expand(-1, -1, enc_embed.shape[-1]))
         ref_k = torch.gather(ref_windows, 1, indexes.expand(-1, -1, ref_windows.shape[-1]))
         boxes_k = box_refine(head.bbox_embed[0](emb_k), ref_k)   # (delta + inverse_sigmoid(ref_k)).sigmoid()
-        self.enc_outputs = {"pred_logits": out_logits, "topk_boxes": boxes_k, "topk_indexes": indexes}
+        # (plain instance attribute, set past nn.Module.__setattr__: its walk over the parameter / buffer / module tables
+        # costs 50-80 us per assignment on the host)
+        self.__dict__["enc_outputs"] = {"pred_logits": out_logits, "topk_boxes": boxes_k, "topk_indexes": indexes}
         out_ref_windows = torch.cat((boxes_k.detach(), topk_probs.detach().expand(-1, -1, 3)), dim=-1)
         return None, None, out_ref_windows, indexes
 
@@ -314,8 +316,13 @@ class Transformer(nn.Module):
 
     @torch.no_grad()
     def _momentum_update_gt_decoder(self):
-        qs = [p.data for p in self.decoder.parameters()]
-        ks = [p.data for p in self.decoder_gt.parameters()]
+        # the two parameter lists are walked once (module traversal: ~1 ms of host time per step for the two decoders);
+        # nn.Module.to() / load_state_dict() keep the Parameter objects, and a changed count rebuilds the lists
+        lists = self.__dict__.get("_ema_lists")
+        if lists is None or lists[2] != (len(self.decoder._modules), id(self.decoder), id(self.decoder_gt)):
+            qs, ks = list(self.decoder.parameters()), list(self.decoder_gt.parameters())
+            lists = self.__dict__["_ema_lists"] = (qs, ks, (len(self.decoder._modules), id(self.decoder), id(self.decoder_gt)))
+        qs, ks = lists[0], lists[1]
         # param_k = param_k * m + param_q * (1 - m) (:84-89), one fused multi-tensor pass
         torch._foreach_mul_(ks, self.m)
         torch._foreach_add_(ks, qs, alpha=1.0 - self.m)

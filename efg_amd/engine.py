@@ -526,7 +526,15 @@ class Trainer:
         self._steps += 1
         if self._manual_gc:
             self._collect_garbage()
-        self.optimizer.zero_grad(set_to_none=True)
+        # == optimizer.zero_grad(set_to_none=True) over the optimizer's own parameters, without its per-call bookkeeping
+        # (0.4 ms of host time per step for 261 parameters)
+        zg = self.__dict__.get("_zero_grad_params")
+        if zg is None or zg[0] != sum(len(g["params"]) for g in self.optimizer.param_groups):
+            plist = [p for g in self.optimizer.param_groups for p in g["params"]]
+            zg = self.__dict__["_zero_grad_params"] = (len(plist), plist)
+        for p in zg[1]:
+            if p.grad is not None:
+                p.grad = None
         if hasattr(self.grad_sync, "begin_step"):
             self.grad_sync.begin_step()
         with record_function("efg::forward"):

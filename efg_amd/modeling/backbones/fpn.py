@@ -88,7 +88,7 @@ class FPN(nn.Module):
 
     def forward(self, *args, **kwargs):
         bottom_up_features = self.bottom_up(*args, **kwargs)
-        self.last_bottom_up = bottom_up_features  # (the engine's bucketed gradient exchange hooks these tensors)
+        self.__dict__["last_bottom_up"] = bottom_up_features  # (the engine's bucketed gradient exchange hooks these tensors; set past Module.__setattr__)
         levels = ["p{}".format(int(math.log2(self._out_feature_strides[n]))) for n in self._out_features]
         active = set(levels) if self.active_levels is None else set(self.active_levels)
         names_td = [n for n in self._out_features if n in

@@ -426,16 +426,17 @@ class _on_geometry_stream:
         self.wait = wait
 
     def __enter__(self):
+        # (set_stream directly: the torch.cuda.stream() context asks for the current stream once more on entry -- ~60 such
+        # scopes per step, each query building a Stream object through _get_device_index)
         self.main = None
         if _GEO is not None:
             self.main = torch.cuda.current_stream()
-            self.ctx = torch.cuda.stream(_GEO)
-            self.ctx.__enter__()
+            torch.cuda.set_stream(_GEO)
         return self.main
 
     def __exit__(self, *exc):
         if self.main is not None:
-            self.ctx.__exit__(*exc)
+            torch.cuda.set_stream(self.main)
             if self.wait:
                 self.main.wait_stream(_GEO)  # device-side dependency, the host does not block
         return False
@@ -470,7 +471,8 @@ class Rulebook:
             with _on_geometry_stream() as main:
                 self._plan_fwd = _build_plan(self.nbr, self.m_out, self.kvol)
                 _hand_over(main, self._plan_fwd)
-                self._plan_stream = torch.cuda.current_stream() if self._plan_fwd is not None else None
+                self._plan_stream = ((_GEO if main is not None else torch.cuda.current_stream())
+                                     if self._plan_fwd is not None else None)
         return self._plan_fwd
 
     def prepare_wgrad(self, cin, cout):
@@ -482,7 +484,7 @@ class Rulebook:
             return
         plan = self.plan_fwd()
         with _on_geometry_stream(wait=False) as main:
-            cur = torch.cuda.current_stream()
+            cur = _GEO if main is not None else torch.cuda.current_stream()
             if self._plan_stream is not None and self._plan_stream != cur:
                 cur.wait_stream(self._plan_stream)   # (a plan built outside the scope this runs in)
             sched = _build_wgrad_sched(plan, self.m_out, cin, cout, self.kvol)
@@ -490,7 +492,7 @@ class Rulebook:
             event = None
             if main is not None:
                 event = torch.cuda.Event()
-                event.record(torch.cuda.current_stream())
+                event.record(_GEO)
         ws_bytes = L.lib().efg_spconv_wgrad_tiled_workspace_bytes(self.m_out, cin, cout, self.kvol)
         self._wgrad_sched[key] = [sched, ws_bytes, event]
 
