@@ -14,14 +14,18 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-out = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tunableop_results.csv")
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+out = os.path.abspath(args[0] if args else "gpurun_out/tunableop_results.csv")
+# --queries N: tune the shapes of another query count (BASELINE configs[2] names 900; the reference YAML 1000); merge the
+# new rows into efg_amd/tuned/gemm_gfx950.csv by hand (same validators)
+queries = int(sys.argv[sys.argv.index("--queries") + 1]) if "--queries" in sys.argv else None
 os.makedirs(os.path.dirname(out), exist_ok=True)
 
 import torch.cuda.tunable as tunable
 from efg_amd.engine import Trainer, synthetic_batch
 
 dev = torch.device("cuda:0")
-tr = Trainer(device=dev, seed=0)
+tr = Trainer(device=dev, seed=0, overrides={"model.transformer.num_queries": queries} if queries else None)
 pool = [synthetic_batch(2000 + 100 * p, 2, device=dev) for p in range(2)]
 
 
