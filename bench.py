@@ -441,9 +441,11 @@ def main():
             line["arm_bf16x3"] = {
                 "ms_per_step": 1000.0 * e3 / args.steps, "value": args.scenes * args.steps / e3, "unit": "scenes/s",
                 "steps": args.steps, "warmup": args.warmup,
-                "dtype": "f32 + bf16x3: forward, data-gradient and weight-gradient products of the >= 16384-row Linear layers as "
-                         "hi.hi + hi.lo + lo.hi of bf16-split operands, fp32 accumulate (csrc/gemm_bf16x3.hip); everything else "
-                         "exact fp32",
+                "dtype": "f32 + bf16x3: forward, data-gradient and weight-gradient products of the >= 16384-row Linear layers, the "
+                         "64-channel-wide sparse-conv tile kernel (EFG_CONV_ARM) and, since round 4, the neck's dense 3 x 3 "
+                         "convolution (EFG_CONV2D_ARM; three products per pass over overlapping-row views of the padded map) as "
+                         "hi.hi + hi.lo + lo.hi of bf16-split operands, fp32 accumulate (csrc/gemm_bf16x3.hip, csrc/spconv_tiles.hip); "
+                         "everything else exact fp32",
                 "note": "A/B arm, not the headline: `value` above is the exact-fp32 step"}
         finally:
             _lin._ARM_BF16X3 = False

@@ -359,7 +359,9 @@ extern "C" int efg_gemm_bf16x3_pack_f32(const float* w, int64_t stride_k, int64_
 extern "C" int efg_gemm_bf16x3_f32(const float* a, int64_t m, int k, int64_t lda, const void* packed_b, int n,
                                    const float* bias, int relu, float* c, int64_t ldc, void* stream) {
   EFG_CHECK_ARG(a && packed_b && c && m >= 0 && k >= 1 && n >= 1, "gemm_bf16x3: bad arguments");
-  EFG_CHECK_ARG(k % 4 == 0 && lda % 4 == 0 && lda >= k && ldc >= n && ((uintptr_t)a & 15) == 0,
+  // (lda < k is allowed: rows that OVERLAP -- row r of a 3 x 3 convolution's ky-th tap block is the 3 c consecutive channels
+  // starting at row r of the padded channels-last map, operators/conv2d.py; the kernel only forms a + r * lda + col)
+  EFG_CHECK_ARG(k % 4 == 0 && lda % 4 == 0 && lda >= 4 && ldc >= n && ((uintptr_t)a & 15) == 0,
                 "gemm_bf16x3: A rows must be 16-byte aligned with K a multiple of 4 (k %d, lda %lld)", k, (long long)lda);
   if (m == 0) return EFG_OK;
   GemmArgs g;
@@ -392,7 +394,7 @@ extern "C" size_t efg_gemm_bf16x3_wgrad_workspace_bytes(int64_t m, int n, int k)
 extern "C" int efg_gemm_bf16x3_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t m, int n, int k,
                                          float* dw, void* ws, size_t ws_bytes, void* stream) {
   EFG_CHECK_ARG(g && x && dw && m >= 1 && n >= 1 && k >= 1, "gemm_bf16x3 wgrad: bad arguments");
-  EFG_CHECK_ARG(n % 4 == 0 && k % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && ldg >= n && ldx >= k &&
+  EFG_CHECK_ARG(n % 4 == 0 && k % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && ldg >= n && ldx >= 4 &&   // (ldx < k: overlapping rows, as above)
                     ((uintptr_t)g & 15) == 0 && ((uintptr_t)x & 15) == 0,
                 "gemm_bf16x3 wgrad: rows must be 16-byte aligned, n and k multiples of 4 (n %d, k %d)", n, k);
   const size_t need = efg_gemm_bf16x3_wgrad_workspace_bytes(m, n, k);

@@ -1,10 +1,13 @@
 """Norm / activation factories and the Conv2d(+norm) wrapper (efg/modeling/common/batch_norm.py:140-188,
 efg/modeling/common/blocks.py:45-100).  Dense ops stay on PyTorch-ROCm (MIOpen / hipBLASLt)."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...operators.conv2d import conv3x3, deterministic_mode
+from ...operators import linear as _linear_mod
+from ...operators.conv2d import arm_covers, conv3x3, conv3x3_arm, deterministic_mode
 from ...operators.linear import linear
 
 
@@ -54,7 +57,11 @@ class Conv2d(nn.Conv2d):
             x = y.permute(0, 3, 1, 2)
         elif (x.is_cuda and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
               and self.dilation == (1, 1) and self.groups == 1 and torch.is_grad_enabled() and deterministic_mode()):
-            x = conv3x3(x, self.weight, self.bias)   # EFG_DETERMINISTIC=1: weight gradient without MIOpen's atomics
+            x = conv3x3(x, self.weight, self.bias)   # EFG_DETERMINISTIC=1: the layer off MIOpen, as fixed-order GEMMs
+        elif (x.is_cuda and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+              and self.dilation == (1, 1) and self.groups == 1 and torch.is_grad_enabled() and _linear_mod._ARM_BF16X3
+              and os.environ.get("EFG_CONV2D_ARM", "1") != "0" and arm_covers(x, self.weight)):
+            x = conv3x3_arm(x, self.weight, self.bias)   # the split-precision A/B arm (never the default)
         else:
             x = super().forward(x)
         if self.norm is not None:

@@ -105,3 +105,74 @@ class Conv3x3Function(Function):
 
 def conv3x3(x, weight, bias):
     return Conv3x3Function.apply(x, weight, bias)
+
+
+def _tap_rows(buf, start_row, rows, c):
+    """[rows, 3c] view of the padded map: row r = the 3c consecutive floats starting at row start_row + r, i.e. the three
+    kx taps of one ky side by side.  The rows OVERLAP (row stride c): the convolution's im2col block without a copy."""
+    return buf.as_strided((rows, 3 * c), (c, 1), buf.storage_offset() + start_row * c)
+
+
+class Conv3x3ArmFunction(Function):
+    """The same convolution on the split-precision A/B arm (EFG_GEMM_ARM=bf16x3; never the default): per ky ONE product of
+    the overlapping-row view above with the [3 Ci, Co] block of the weights (csrc/gemm_bf16x3.hip takes the row stride as an
+    argument), three products per pass instead of MIOpen's implicit GEMM -- forward, data gradient and weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import gemm_bf16x3 as G
+
+        b, ci, h, w = x.shape
+        co = weight.shape[0]
+        wp, front = w + 2, w + 3
+        xb, _, rows = _pad_rows(x, front)
+        wk = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][ci][co]
+        out = None
+        for ky in range(3):
+            y = G.gemm(_tap_rows(xb, front + (ky - 1) * wp - 1, rows, ci), G.pack(wk[ky], 3 * ci, co, co, 1), co,
+                       bias=bias if ky == 0 else None)
+            out = y if out is None else out.add_(y)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        ctx.geom = (b, h, w)
+        return _unpad_rows(out, b, h, w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        from . import gemm_bf16x3 as G
+
+        xb, weight = ctx.saved_tensors
+        b, h, w = ctx.geom
+        co, ci = weight.shape[:2]
+        wp, front = w + 2, w + 3
+        gbuf, _, rows = _pad_rows(gy, front)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # gx[p] = sum_k G[p - off_k] W_k: per ky the rows p - (ky - 1) wp + 1, .. , - 1 side by side, i.e. kx = 2, 1, 0
+            wd = weight.detach().flip(3).permute(2, 3, 0, 1).contiguous()     # [ky][2 - kx][co][ci]
+            acc = None
+            for ky in range(3):
+                y = G.gemm(_tap_rows(gbuf, front - (ky - 1) * wp - 1, rows, co), G.pack(wd[ky], 3 * co, ci, ci, 1), ci)
+                acc = y if acc is None else acc.add_(y)
+            gx = _unpad_rows(acc, b, h, w)
+        if ctx.needs_input_grad[1]:
+            g_rows = gbuf[front:front + rows]
+            gw = torch.empty((co, ci, 3, 3), dtype=weight.dtype, device=weight.device)
+            for ky in range(3):
+                d = G.wgrad(g_rows, _tap_rows(xb, front + (ky - 1) * wp - 1, rows, ci))   # [co, 3 ci] = (kx, ci)
+                gw[:, :, ky, :] = d.view(co, 3, ci).permute(0, 2, 1)
+            if weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous():
+                gw = gw.contiguous(memory_format=torch.channels_last)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb
+
+
+def conv3x3_arm(x, weight, bias):
+    return Conv3x3ArmFunction.apply(x, weight, bias)
+
+
+def arm_covers(x, weight):
+    """The arm's products want 16-byte rows and whole 64-channel blocks on both sides."""
+    return weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0 and x.dtype == torch.float32

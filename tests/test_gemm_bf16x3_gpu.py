@@ -102,6 +102,32 @@ def test_arm_passes_the_parity_gate_on_a_full_size_conquer_step(monkeypatch):
     assert arm_norm == pytest.approx(ref_norm, rel=5e-4)
 
 
+def test_arm_conv3x3_matches_the_fp32_convolution():
+    """operators/conv2d.py:Conv3x3ArmFunction -- the dense 3 x 3 convolution of the neck as three split-precision products per
+    pass over overlapping-row views of the padded channels-last map -- against F.conv2d in fp64: forward, data gradient,
+    weight and bias gradient at the accuracy of the split (a few 1e-6 of the tensor's scale)."""
+    import torch.nn.functional as F
+
+    from efg_amd.operators.conv2d import conv3x3_arm
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 37, 29, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = torch.randn(128, generator=g).to(dev).requires_grad_(True)
+    y = conv3x3_arm(x, w, b)
+    up = torch.randn(y.shape, generator=g).to(dev)
+    (y * up).sum().backward()
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, padding=1)
+    (yr * up.double()).sum().backward()
+
+    def rel(a, ref):
+        return float((a.double() - ref).abs().max() / ref.abs().max())
+
+    assert rel(y, yr) < 2e-5 and rel(x.grad, xr.grad) < 2e-5 and rel(w.grad, wr.grad) < 2e-5 and rel(b.grad, br.grad) < 2e-5
+
+
 def test_split_weights_follow_the_optimizer(monkeypatch):
     """The arm caches the split weight per parameter version: after an (in-place, fused) optimizer step the next product must
     use the NEW weight."""
