@@ -117,8 +117,10 @@ class Det3DLoss(nn.Module):
                 tcls.index_put_((l_idx, b_idx, q_idx), cls.to(torch.int32))
                 out["loss_ce"] = FocalLossLayers.apply(logits, tcls, denom, self.focal_alpha, 2.0)
             if want_box:
-                sums = BoxLossLayers.apply(boxes, tgt_boxes, l_idx, b_idx, q_idx, g_idx, denom)
-                out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
+                sums = BoxLossLayers.apply(boxes, tgt_boxes, l_idx, b_idx, q_idx, g_idx, denom)   # [L, 3]
+                # the three families as ONE family-major [3 L] vector under a joint key: three column selects would put
+                # three SelectBackward nodes (zero-fill + copy + add each) into the graph, three times per step
+                out["loss_bbox|loss_giou|loss_rad"] = sums.t().reshape(-1)
             return out, cls
         if want_ce:
             onehot = torch.zeros_like(logits)
@@ -194,7 +196,7 @@ class Det3DLoss(nn.Module):
         fam_keys, fam_vecs = [], []
         n_aux = len(layers) - 1
         for k, v in per_layer.items():
-            fam_keys.append([k + f"_{i}" for i in range(n_aux)] + [k])
+            fam_keys.append([[nm + f"_{i}" for i in range(n_aux)] + [nm] for nm in k.split("|")])   # (joint key: family-major)
             fam_vecs.append(v)
 
         if dn_meta is not None:
@@ -223,11 +225,11 @@ class Det3DLoss(nn.Module):
             dn_per_layer, _ = self._layer_losses(dn_logits, dn_boxes, tuple(sel_dn), tgt_labels, tgt_boxes,
                                                  num_boxes * scalar)
             for k, v in dn_per_layer.items():
-                fam_keys.append([k + f"_dn_{i}" for i in range(nl - 1)] + [k + "_dn"])
+                fam_keys.append([[nm + f"_dn_{i}" for i in range(nl - 1)] + [nm + "_dn"] for nm in k.split("|")])
                 fam_vecs.append(v)
         # ONE weighted vector for all terms of this head: weight_dict per key, 1 for keys it does not name (the *_dn terms,
         # as in the reference: heads.py compute_losses only scales keys found in the dict)
-        keys = [k for ks in fam_keys for k in ks]
+        keys = [k for fams in fam_keys for ks in fams for k in ks]
         vec = torch.cat(fam_vecs) if len(fam_vecs) > 1 else fam_vecs[0]
         if weights is not None:
             w = self._weight_vector(tuple(keys), weights, vec.device)

@@ -96,3 +96,25 @@ for e in ev:
     per[key][2][e.name] += len(e.kernels)
 for key, (n, us, ops_) in sorted(per.items(), key=lambda kv: -kv[1][0]):
     print("%-28s %5d launches %8.3f ms   top: %s" % (key, n, us / 1e3, ", ".join("%s x%d" % kv for kv in ops_.most_common(6))))
+print("\n-- backward launches by autograd node (the enclosing `autograd::engine::evaluate_function: X` range)")
+nodes = sorted((e for e in ev if e.device_type == torch.autograd.DeviceType.CPU and e.thread != main_thread
+                and e.name.startswith("autograd::engine::evaluate_function")), key=lambda e: e.time_range.start)
+starts = [n.time_range.start for n in nodes]
+import bisect  # noqa: E402
+
+per_node = collections.defaultdict(lambda: [0, 0, 0.0, collections.Counter()])   # node evaluations, launches, kernel us, ops
+for n in nodes:
+    per_node[n.name.split(": ", 1)[-1]][0] += 1
+for e in ev:
+    if e.device_type != torch.autograd.DeviceType.CPU or e.thread == main_thread or not e.kernels:
+        continue
+    i = bisect.bisect_right(starts, e.time_range.start) - 1
+    if i < 0 or e.time_range.end > nodes[i].time_range.end or e.name.startswith("autograd::engine"):
+        continue
+    rec = per_node[nodes[i].name.split(": ", 1)[-1]]
+    rec[1] += len(e.kernels)
+    rec[2] += sum(k.duration for k in e.kernels)
+    rec[3][e.name] += len(e.kernels)
+for name, (n, launches, us, ops_) in sorted(per_node.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%-44s %4d nodes %5d launches %8.3f ms   %s" % (name[:44], n, launches, us / 1e3,
+                                                         ", ".join("%s x%d" % kv for kv in ops_.most_common(5))))
