@@ -135,3 +135,32 @@ assert float(z2.sum()) == 5 * 1024
 print("CHILD_OK")
 """)
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_momentum_decoder_on_its_own_stream_changes_no_bit(monkeypatch):
+    """EFG_GT_STREAM: the momentum decoder issued right after the encoder on a side stream (beside the decoder) or on the
+    main stream after it -- the same kernels on the same inputs, so three training steps give the same loss terms and the
+    same parameters bit for bit (the EMA update of the momentum decoder reads the optimizer's output of the previous
+    step on the OTHER stream: a missing dependency would show here)."""
+    from efg_amd.engine import Trainer, synthetic_batch
+
+    dev = torch.device("cuda:0")
+    # the benchmark's own size with EFG_DETERMINISTIC=1: there two runs of a step agree bit for bit (tests/test_determinism_gpu.py;
+    # at reduced shapes the GEMM library picks atomic split-K solutions), so any difference here is the stream's
+    monkeypatch.setenv("EFG_DETERMINISTIC", "1")
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EFG_GT_STREAM", flag)
+        tr = Trainer(device=dev, seed=0)
+        tr.model.noise_generator = torch.Generator().manual_seed(77)
+        trace = []
+        for s in range(3):
+            losses, total = tr.step(synthetic_batch(900 + s, 2, device=dev))
+            trace.append({k: float(v.detach()) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        runs.append((trace, [p.detach().clone() for p in tr.model.parameters()]))
+        tr.close()
+        del tr
+    (ta, pa), (tb, pb) = runs
+    assert ta == tb
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))

@@ -238,8 +238,9 @@ def test_linear_refuses_nothing_on_cpu():
 
 
 def test_conv3x3_fixed_order_weight_gradient(dev):
-    """EFG_DETERMINISTIC=1: the dense 3 x 3 convolution's weight gradient as nine fixed-order GEMMs over the padded
-    channels-last maps (operators/conv2d.py) -- equal to MIOpen's to fp32 rounding, and the same bits every time."""
+    """EFG_DETERMINISTIC=1: the dense 3 x 3 convolution (forward, data gradient, weight gradient) as nine fixed-order GEMMs
+    each over the padded channels-last maps (operators/conv2d.py) -- equal to fp64 F.conv2d to fp32 rounding, and the same
+    bits every time."""
     from efg_amd.operators.conv2d import conv3x3
 
     g = torch.Generator().manual_seed(0)
@@ -260,5 +261,6 @@ def test_conv3x3_fixed_order_weight_gradient(dev):
     for got, exp, name in ((y, ref.detach(), "out"), (gx, rx, "grad x"), (gw, rw, "grad w"), (gb, rb, "grad b")):
         scale = float(exp.abs().max())
         assert float((got.double() - exp.double()).abs().max()) < 2e-5 * scale, name
-    for o in outs[1:]:
+    for o in outs[1:]:   # forward, data and weight gradient all run as fixed-order GEMMs: the same bits every time
+        assert torch.equal(o[0], y) and torch.equal(o[1], gx), "output / data gradient differ between two identical passes"
         assert torch.equal(o[2], gw), "weight gradient differs between two identical backward passes"
