@@ -28,7 +28,7 @@
 //                  occupied cells are compacted into a voxel list, then one thread per voxel takes the max_points
 //                  lowest point indices in order, looks its voxel id up in the bitmap prefix (rank of its first point)
 //                  and writes rows, zero padding, coordinates, count and the fused mean.
-// 5 kernels + 1 memset (counters, chunk totals, tickets) per call.  All scenes of a batch go through one launch per
+// 6 kernels + 1 clear kernel (counters, chunk totals, look-back records) per call.  All scenes of a batch go through one launch per
 // stage (blockIdx.y = scene).  K4 / K5 run a fixed grid whose workgroups loop over the work lists (a launch sized for
 // the worst case -- 19k workgroups, 5 % of them with work -- spent 20 us on dispatching the empty ones).
 #include "voxelize_common.h"
@@ -121,6 +121,15 @@ __device__ __forceinline__ int stage_rows(const float* __restrict__ pts, long lo
 
 // K1 ------------------------------------------------------------------------------------------------------------
 // pos[i] = xcd << 28 | place of point i inside its (supercell, xcd) group; kNone for points outside the range.
+// counters, chunk totals and look-back records of a call: cleared words
+__global__ void __launch_bounds__(256) vox_clear_kernel(unsigned* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n) p[i + u * 256] = 0u;
+  }
+}
+
 template <bool STAGE>
 __global__ void __launch_bounds__(256)
 vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords sw, int f, VoxGeom g, BinGeom bg,
@@ -1048,8 +1057,11 @@ int bins_hard_voxelize(const HardArgs& a) {
               bins_workspace_bytes(a.n_total, batch, f, a.g), a.ws_bytes);
     return EFG_E_WORKSPACE;
   }
-  EFG_HIP_TRY(hipMemsetAsync(count, 0, cleared_words * 4, stream));
   const dim3 blk(256);
+  // (a kernel, not hipMemsetAsync: captured into a HIP graph the memset NODE of this call did not take effect on the second
+  // replay -- counters left dirty, wild offsets, "write access to a read-only page"; scripts/ubench/vox_graph_probe.py)
+  hipLaunchKernelGGL(vox_clear_kernel, dim3((unsigned)std::min<size_t>(ceil_div((int64_t)cleared_words, 1024), 1024)), blk, 0, stream,
+                     reinterpret_cast<unsigned*>(count), (size_t)cleared_words);
   const int tiles = (int)std::max<int64_t>(1, ceil_div(a.max_scene, kTile));
   const bool stage = f <= 8;
   if (stage)

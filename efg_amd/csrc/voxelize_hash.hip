@@ -26,6 +26,15 @@ constexpr int kFirstFlag = 1 << 30;
 
 __device__ __forceinline__ unsigned hash_cell(unsigned key, int shift) { return (key * 2654435761u) >> shift; }
 
+// the hash table and the per-scene break / total words of a call: filled words
+__global__ void __launch_bounds__(256) vox_fill_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n) p[i + u * 256] = v;
+  }
+}
+
 // K1: slot_of_point[i] = hash slot of the point's cell (or -1); table[slot] = {cell, min point}.
 __global__ void __launch_bounds__(256)
 vox_insert_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom g, unsigned vol,
@@ -278,9 +287,14 @@ int hash_hard_voxelize(const HardArgs& a) {
   int* scene_base = small;                                   // [batch+1]
   unsigned* i_break = cleared_small;                         // [batch]  0xffffffff = no break
   int* scene_total = reinterpret_cast<int*>(cleared_small + kMaxBatch);  // [batch]  -1 + number of first points
-  EFG_HIP_TRY(hipMemsetAsync(table, 0xff, reinterpret_cast<char*>(cleared_small + 2 * kMaxBatch) - reinterpret_cast<char*>(table),
-                             stream));
   const dim3 blk(256);
+  {
+    // (a kernel, not hipMemsetAsync: the memset NODE of a captured call did not take effect on the second replay of the
+    // graph on this stack -- scripts/ubench/vox_graph_probe.py; the region is a whole number of 4-byte words)
+    const size_t words = (size_t)(reinterpret_cast<char*>(cleared_small + 2 * kMaxBatch) - reinterpret_cast<char*>(table)) / 4;
+    hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)std::min<size_t>(ceil_div((int64_t)words, 1024), 1024)), blk, 0, stream,
+                       reinterpret_cast<unsigned*>(table), words, 0xffffffffu);
+  }
   static const int precheck = getenv("EFG_VOX_PRECHECK") ? atoi(getenv("EFG_VOX_PRECHECK")) : 1;  // 0: every point of a voxel issues its atomicMin (A/B)
   if (n_total > 0) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);

@@ -211,3 +211,90 @@ def test_full_size_both_implementations_agree(dev, impl, oracle_mod):
 
     pts, _, _ = make_scene(2024, n_points=720000, n_sweeps=4)
     _check_vs_oracle(dev, oracle_mod, pts, VOXEL_SIZE, PC_RANGE, 5, 200000)
+
+
+@pytest.mark.parametrize("impl", ["bins", "hash"])
+def test_hard_voxelize_writes_nothing_outside_its_buffers(impl, monkeypatch):
+    """Every output and the workspace sit between two 1 MiB guard bands of a known byte: after a batched call at the
+    benchmark's size (and a 6-feature, 4-scene one) the bands are untouched -- an out-of-bounds write inside the caching
+    allocator's segments would otherwise corrupt a neighbour silently."""
+    from efg_amd import _lib as L
+    from efg_amd.engine import synthetic_batch
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("EFG_VOX_IMPL", impl)
+    guard = 1 << 20
+
+    def guarded(nbytes, dtype):
+        raw = torch.full((nbytes + 2 * guard,), 0xAB, dtype=torch.uint8, device=dev)
+        return raw, raw[guard:guard + nbytes].view(dtype)
+
+    def run(pts, max_points=5, max_voxels=120000):
+        offsets = [0]
+        for p in pts:
+            offsets.append(offsets[-1] + p.shape[0])
+        points = torch.cat(pts, 0).contiguous()
+        f, n, batch = points.shape[1], offsets[-1], len(pts)
+        cap = min(batch * max_voxels, n)
+        lib = L.lib()
+        vs, cr = L.host_f32([0.1, 0.1, 0.15], 3), L.host_f32([-75.2, -75.2, -2.0, 75.2, 75.2, 4.0], 6)
+        ws_bytes = lib.efg_hard_voxelize_workspace_bytes(n, batch, f, max_points, max_voxels, vs, cr)
+        specs = {"voxels": (cap * max_points * f * 4, torch.float32), "coors": (cap * 16, torch.int32), "npv": (cap * 4, torch.int32),
+                 "mean": (cap * f * 4, torch.float32), "num": (batch * 4, torch.int32), "ws": (ws_bytes, torch.uint8)}
+        bufs = {k: guarded(*v) for k, v in specs.items()}
+        bufs["num"][1].zero_()
+        L.check(lib.efg_hard_voxelize_f32(L.ptr(points), L.host_i64(offsets), batch, f, vs, cr, max_points, max_voxels,
+                                          bufs["voxels"][1].data_ptr(), bufs["coors"][1].data_ptr(), 4, bufs["npv"][1].data_ptr(),
+                                          bufs["num"][1].data_ptr(), bufs["mean"][1].data_ptr(), bufs["ws"][1].data_ptr(),
+                                          ws_bytes, L.stream()))
+        torch.cuda.synchronize()
+        assert min(bufs["num"][1].tolist()) > 1000
+        for k, (nbytes, _) in specs.items():
+            raw = bufs[k][0]
+            assert bool((raw[:guard] == 0xAB).all()) and bool((raw[guard + nbytes:] == 0xAB).all()), "write outside `%s`" % k
+
+    pts = [s[0]["points"] for s in synthetic_batch(2000, 2, device=dev)]
+    run(pts)
+    run([torch.cat([p, p[:, :1]], 1) for p in pts] * 2)
+    run([pts[0][:16000]])
+
+
+@pytest.mark.parametrize("impl", ["bins", "hash"])
+def test_hard_voxelize_replays_from_a_hip_graph(impl, monkeypatch):
+    """The call's launches captured into a HIP graph and replayed give the eager result every time.  (With hipMemsetAsync
+    for the counters the SECOND replay ran on dirty counters on this stack -- a memory fault in the binned path, a hang in the
+    hash path; both paths clear with a kernel since round 4.)"""
+    from efg_amd.engine import synthetic_batch
+    from efg_amd.hipgraph import capture
+    from efg_amd.operators import voxelize as V
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("EFG_VOX_IMPL", impl)
+    pts = [s[0]["points"] for s in synthetic_batch(2000, 2, device=dev)]
+    points = torch.cat(pts, 0).contiguous()
+    offsets = [0, pts[0].shape[0], pts[0].shape[0] + pts[1].shape[0]]
+    cap, f = 240000, points.shape[1]
+
+    def buffers():
+        return (torch.full((cap, 5, f), -7.0, device=dev), torch.full((cap, 4), -7, dtype=torch.int32, device=dev),
+                torch.full((cap,), -7, dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev),
+                torch.full((cap, f), -7.0, device=dev))
+
+    def launch(bufs):
+        bufs[3].zero_()
+        V._hard_voxelize_launch(points, offsets, [0.1, 0.1, 0.15], [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0], 5, 120000, *bufs)
+
+    want = buffers()
+    launch(want)
+    torch.cuda.synchronize()
+    m = int(want[3].sum())
+    got = buffers()
+    graph, _ = capture(lambda: launch(got), dev)
+    for _ in range(4):
+        for t in (got[0], got[1], got[2], got[4]):
+            t.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert got[3].tolist() == want[3].tolist()
+        for a, b in zip(got, want):
+            assert torch.equal(a[:m] if a.shape[0] == cap else a, b[:m] if b.shape[0] == cap else b)
