@@ -944,46 +944,57 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int* __restrict__ offse
     }
 }
 
+// max |x| of a tensor as float bits (0x7f800000 and above: an Inf / NaN is present): one atomicMax per wave
+__global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restrict__ x, long long n4, unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = ld4(x + i * 4);
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+    m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // grad_value row `bin` += sum over its entries of weight * grad_out[row]; 8 lanes x float4 per bin.  After the
 // main kernel cursor[bin] is the END of the bin, offsets[bin] its start.
 // The entries of a bin sit in the order their atomics arrived, which differs run to run; a float accumulation in list
 // order would make grad_value (and every gradient upstream of it) differ in the last bits between two identical steps.
-// The sum is therefore taken as EXACT 64-bit fixed-point integers: pass 1 finds the largest |weight * grad_out| of the
-// lane's four channels over the bin, which fixes a scale 2^sh at which no sum of the bin's n products can overflow;
-// pass 2 adds round(weight * grad_out * 2^sh) -- the product is exact in double (24 x 24 bits), integer addition is
-// associative -- and the row receives the correctly rounded total.  Entries are read twice (the second time from L1 / L2).
+// The sum is therefore taken as EXACT 64-bit fixed-point integers at a scale 2^sh at which no sum of the bin's n products
+// can overflow: every |weight * grad_out| of the bin is below (largest |weight| of the bin) x (largest |grad_out| of the
+// call, `gmax_bits`, absmax_bits_kernel) -- the first is one pass over the bin's 8-byte entries, no row is gathered for
+// it (round 4, first version: a first gather pass found the bin's exact largest product; the gathers are the cost of this
+// kernel, and it doubles as the boxes grow and most corners of the encoder leave their query tile's window).  Each product
+// is exact in double (24 x 24 bits), integer addition is associative, and the row receives the total rounded once: exact
+// to 2^-(61 - log2 n) of the bound, i.e. to ~1e-13 of the call's largest gradient element.
 __global__ void __launch_bounds__(256)
 box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ cursor, const int2* __restrict__ entries,
-                      const float* __restrict__ grad_out, long long nbins, float* __restrict__ grad_value) {
+                      const float* __restrict__ grad_out, long long nbins, const unsigned* __restrict__ gmax_bits,
+                      float* __restrict__ grad_value) {
   const int c4 = (threadIdx.x & 7) * 4;
+  const unsigned gbits = *gmax_bits;
+  const bool finite = gbits < 0x7f800000u;
+  const float gmax = __uint_as_float(gbits);
   for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
     const int s = offsets[bin], e = min(cursor[bin], offsets[bin + 1]);  // offsets has nbins + 1 entries
     if (s == e) continue;
-    float mx = 0.0f;
-    bool finite = true;
-    for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight
-      int2 en[4];
-      float4 g[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) en[u] = entries[min(i0 + u, e - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) g[u] = ld4(grad_out + (long long)en[u].x * 32 + c4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float w = fabsf(__int_as_float(en[u].y));
-        const float m4 = fmaxf(fmaxf(fabsf(g[u].x), fabsf(g[u].y)), fmaxf(fabsf(g[u].z), fabsf(g[u].w))) * w;
-        finite = finite && (m4 < INFINITY);   // (false for NaN too)
-        mx = fmaxf(mx, m4);
-      }
-    }
     float4 acc = ld4(grad_value + bin * 32 + c4);
     if (finite) {
+      float mw = 0.0f;
+      for (int i0 = s; i0 < e; i0 += 4) {
+        int2 en[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = entries[min(i0 + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mw = fmaxf(mw, fabsf(__int_as_float(en[u].y)));
+      }
       int ex = 0, ln = 0;
-      frexpf(mx * 1.0000002f, &ex);          // every |product| < 2^ex (the float product above may round down by one ulp)
+      frexpf(fminf(mw * gmax * 1.0000002f, 3.0e38f), &ex);   // every |product| < 2^ex (a NaN weight: fminf keeps the bound finite)
       while ((1 << ln) < e - s + 1) ++ln;    // n + 1 <= 2^ln
       const int sh = 61 - ln - ex;
       long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-      for (int i0 = s; i0 < e; i0 += 4) {
+      for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight
         int2 en[4];
         float4 g[4];
 #pragma unroll
@@ -1004,7 +1015,7 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
       acc.y = __fadd_rn(acc.y, (float)ldexp((double)a1, -sh));
       acc.z = __fadd_rn(acc.z, (float)ldexp((double)a2, -sh));
       acc.w = __fadd_rn(acc.w, (float)ldexp((double)a3, -sh));
-    } else {   // Inf / NaN among the addends: so is the sum, in any order
+    } else {   // Inf / NaN among the gradients: so are the sums they reach, in any order
       for (int i = s; i < e; ++i) {
         const int2 en = entries[i];
         const float4 g = ld4(grad_out + (long long)en.x * 32 + c4);
@@ -1050,7 +1061,7 @@ BinPlan bin_plan(int b, int s, int h, int l, int lq, int p) {
 // offsets[bin + 1] ends every bin); cursor = copy of offsets
 int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long long* starts, const float* ref,
                 const float* off, const float* kidx, const BoxDims& dm, int outside_tile_window, int tqy, hipStream_t st,
-                int** offs, int** cursor, int2** entries, int** overflow) {
+                int** offs, int** cursor, int2** entries, int** overflow, const float* grad_out, long long grad_out_floats) {
   char* base = static_cast<char*>(ws);
   *overflow = reinterpret_cast<int*>(base + pl.off_flag);
   *offs = reinterpret_cast<int*>(base + pl.off_offsets);
@@ -1059,6 +1070,9 @@ int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long
   *entries = reinterpret_cast<int2*>(base + pl.off_entries);
   // flag + offsets are adjacent: one memset
   EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
+  // the flag block's second word: largest |grad_out| of the call as float bits (the scale of box_bin_reduce_kernel)
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(ceil_div(grad_out_floats / 4, 256), 1), 2048)),
+                     dim3(256), 0, st, grad_out, grad_out_floats / 4, reinterpret_cast<unsigned*>(*overflow) + 1);
   const long long nboxes = (long long)dm.b * dm.lq * dm.h * dm.l;
   hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(nboxes, 256)), dim3(256), 0, st, shapes, starts, ref,
                      off, kidx, dm, *offs, outside_tile_window, tqy);
@@ -1146,7 +1160,8 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       if (binned) {
         EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
         if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
-                                 kernel_indices, dm, 1, tqy, st, &offs, &cursor, &entries, &overflow))
+                                 kernel_indices, dm, 1, tqy, st, &offs, &cursor, &entries, &overflow, grad_out,
+                                 (long long)dm.b * dm.lq * dm.h * dm.d))
           return rc;
       }
       // EFG_BOX_DETERMINISTIC (default 1): the tiles in NCY x NCX colour classes whose windows never overlap, one launch
@@ -1178,7 +1193,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
         EFG_LAUNCH_CHECK();
         const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
         hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out, pl.nbins,
-                           grad_value);
+                           reinterpret_cast<const unsigned*>(overflow) + 1, grad_value);
       }
     }
     else
@@ -1198,7 +1213,8 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
     if (binned) {
       EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
       if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
-                               kernel_indices, dm, 0, 8, st, &offs, &cursor, &entries, &overflow))
+                               kernel_indices, dm, 0, 8, st, &offs, &cursor, &entries, &overflow, grad_out,
+                               (long long)dm.b * dm.lq * dm.h * dm.d))
         return rc;
     } else if (ws != nullptr && ws_bytes >= sizeof(int)) {
       EFG_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), st));  // the overflow word is defined whenever a workspace is given
@@ -1211,7 +1227,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       EFG_LAUNCH_CHECK();
       const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
       hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out,
-                         pl.nbins, grad_value);
+                         pl.nbins, reinterpret_cast<const unsigned*>(overflow) + 1, grad_value);
     }
   }
   EFG_LAUNCH_CHECK();
