@@ -248,8 +248,7 @@ ColsumPlan colsum_plan(int64_t rows, int cols, int64_t row_stride, const void* x
 
 // Ticket counters of the fused final: a ring of zero-initialised device words per device; a call takes `n` consecutive ones
 // (one per column group).  A slot comes round again after kRing / n calls -- far beyond what a stream keeps in flight --
-// and each counter is back at 0 when its kernel ends.  nullptr (=> two launches) while the stream is being captured
-// before the ring exists (hipMalloc is not capturable).
+// and each counter is back at 0 when its kernel ends.  nullptr (=> two launches) while the stream is being captured.
 constexpr unsigned kRing = 8192;
 std::mutex g_ring_mu;
 unsigned* g_ring[64] = {};
@@ -258,10 +257,12 @@ unsigned g_ring_next[64] = {};
 unsigned* ticket_slots(int n, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || n < 1 || (unsigned)n > kRing / 4) return nullptr;
+  // a launch that is being CAPTURED keeps the two-launch form: its ring slot would be baked into the graph and every
+  // replay would use it again, possibly beside an eager call (or another graph) that drew the same slot
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return nullptr;   // (the null stream cannot capture)
   std::lock_guard<std::mutex> lock(g_ring_mu);
   if (!g_ring[dev]) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     unsigned* p = nullptr;
     if (hipMalloc(&p, sizeof(unsigned) * kRing) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, sizeof(unsigned) * kRing) != hipSuccess) {
