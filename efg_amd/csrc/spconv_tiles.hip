@@ -176,8 +176,14 @@ __device__ float4 g_zero_piece;  // (zero-initialised, never written; not const:
 // (4 rows x 16 pieces per instruction instead of one row), the A tile is stored as 16-byte pieces at slot
 // piece ^ row (conflict-free 16-byte writes and fragment reads without padding) and a lane's four A operands of a
 // 16-channel step come from ONE ds_read_b128.  V4 = 0: the 4-byte path (any channel count).
+#ifndef EFG_TILE_WPE_R2
+#define EFG_TILE_WPE_R2 4   // waves per SIMD asked of the compiler for the stream-K R = 2 shape (A/B builds: scripts/build_ab.sh)
+#endif
+#ifndef EFG_TILE_WPE_R1
+#define EFG_TILE_WPE_R1 5
+#endif
 template <int NT, int R, int KS, int V4, int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 2) ? (R == 2 ? 4 : 5) : 1)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 2) ? (R == 2 ? EFG_TILE_WPE_R2 : EFG_TILE_WPE_R1) : 1)))
 conv_tile_kernel(TileArgs a) {
   constexpr int SK = (MODE >> 1) & 1;  // stream-K: the (unit, offset) items are cut into equal shares, one per workgroup
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
