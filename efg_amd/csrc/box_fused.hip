@@ -944,17 +944,35 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int* __restrict__ offse
     }
 }
 
-// max |x| of a tensor as float bits (0x7f800000 and above: an Inf / NaN is present): one atomicMax per wave
+// max |x| of a tensor as float bits (0x7f800000 and above: an Inf / NaN is present) into 63 slots (out[1 + block % 63]: one
+// address is one serial atomic unit, ~15 ns per atomic); eight 16-byte loads in flight per thread, one atomic per block.
+// (First version: one load per trip and an atomic per wave on ONE word -- 66 us for 72 MB.)
+constexpr int kAbsmaxSlots = 63;
 __global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restrict__ x, long long n4, unsigned* __restrict__ out) {
+  __shared__ unsigned sm[4];
   unsigned m = 0u;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const float4 v = ld4(x + i * 4);
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  auto fold = [&](const float4& v) {
     m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
     m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  };
+  for (; i + 7 * stride < n4; i += 8 * stride) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4(x + (i + u * stride) * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fold(v[u]);
   }
+  for (; i < n4; i += stride) fold(ld4(x + i * 4));
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, 64));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+    if (m) atomicMax(out + 1 + blockIdx.x % kAbsmaxSlots, m);
+  }
 }
 
 // grad_value row `bin` += sum over its entries of weight * grad_out[row]; 8 lanes x float4 per bin.  After the
@@ -963,7 +981,7 @@ __global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restric
 // order would make grad_value (and every gradient upstream of it) differ in the last bits between two identical steps.
 // The sum is therefore taken as EXACT 64-bit fixed-point integers at a scale 2^sh at which no sum of the bin's n products
 // can overflow: every |weight * grad_out| of the bin is below (largest |weight| of the bin) x (largest |grad_out| of the
-// call, `gmax_bits`, absmax_bits_kernel) -- the first is one pass over the bin's 8-byte entries, no row is gathered for
+// call, the maximum over `gmax_bits[1..63]`, absmax_bits_kernel) -- the first is one pass over the bin's 8-byte entries, no row is gathered for
 // it (round 4, first version: a first gather pass found the bin's exact largest product; the gathers are the cost of this
 // kernel, and it doubles as the boxes grow and most corners of the encoder leave their query tile's window).  Each product
 // is exact in double (24 x 24 bits), integer addition is associative, and the row receives the total rounded once: exact
@@ -973,7 +991,8 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
                       const float* __restrict__ grad_out, long long nbins, const unsigned* __restrict__ gmax_bits,
                       float* __restrict__ grad_value) {
   const int c4 = (threadIdx.x & 7) * 4;
-  const unsigned gbits = *gmax_bits;
+  unsigned gbits = 0u;   // (the 63 slots of absmax_bits_kernel, after the overflow word of the flag block)
+  for (int i = 1; i <= kAbsmaxSlots; ++i) gbits = max(gbits, gmax_bits[i]);
   const bool finite = gbits < 0x7f800000u;
   const float gmax = __uint_as_float(gbits);
   for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
@@ -1070,9 +1089,9 @@ int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long
   *entries = reinterpret_cast<int2*>(base + pl.off_entries);
   // flag + offsets are adjacent: one memset
   EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
-  // the flag block's second word: largest |grad_out| of the call as float bits (the scale of box_bin_reduce_kernel)
-  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(ceil_div(grad_out_floats / 4, 256), 1), 2048)),
-                     dim3(256), 0, st, grad_out, grad_out_floats / 4, reinterpret_cast<unsigned*>(*overflow) + 1);
+  // words 1..63 of the (zeroed) flag block: largest |grad_out| of the call as float bits (the scale of box_bin_reduce_kernel)
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(ceil_div(grad_out_floats / 4, 2048), 1), 1024)),
+                     dim3(256), 0, st, grad_out, grad_out_floats / 4, reinterpret_cast<unsigned*>(*overflow));
   const long long nboxes = (long long)dm.b * dm.lq * dm.h * dm.l;
   hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(nboxes, 256)), dim3(256), 0, st, shapes, starts, ref,
                      off, kidx, dm, *offs, outside_tile_window, tqy);
@@ -1193,7 +1212,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
         EFG_LAUNCH_CHECK();
         const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
         hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out, pl.nbins,
-                           reinterpret_cast<const unsigned*>(overflow) + 1, grad_value);
+                           reinterpret_cast<const unsigned*>(overflow), grad_value);
       }
     }
     else
@@ -1227,7 +1246,7 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
       EFG_LAUNCH_CHECK();
       const unsigned blocks = (unsigned)std::min<long long>(ceil_div(pl.nbins, 32), 16384);
       hipLaunchKernelGGL(box_bin_reduce_kernel, dim3(blocks), dim3(256), 0, st, offs, cursor, entries, grad_out,
-                         pl.nbins, reinterpret_cast<const unsigned*>(overflow) + 1, grad_value);
+                         pl.nbins, reinterpret_cast<const unsigned*>(overflow), grad_value);
     }
   }
   EFG_LAUNCH_CHECK();
