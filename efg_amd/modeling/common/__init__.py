@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ...operators import batchnorm as _bn
 from ...operators import linear as _linear_mod
 from ...operators.conv2d import arm_covers, conv3x3, conv3x3_arm, deterministic_mode
 from ...operators.linear import linear
@@ -65,7 +66,15 @@ class Conv2d(nn.Conv2d):
         else:
             x = super().forward(x)
         if self.norm is not None:
-            x = self.norm(x)
+            if _bn.fusable_nhwc(self.norm, x):
+                # a training-mode BatchNorm2d over a channels-last map (+ ReLU): the [B*H*W, C] row kernels of the sparse
+                # backbone (operators/batchnorm.py) instead of MIOpen's batch norm + a separate ReLU each way
+                relu = type(self.activation) is nn.ReLU
+                x = _bn.bn_act_nhwc(x, self.norm, relu)
+                if relu:
+                    return x
+            else:
+                x = self.norm(x)
         if self.activation is not None:
             x = self.activation(x)
         return x
