@@ -49,10 +49,11 @@ class Det3DHead(nn.Module):
         box_coords = box_refine(self.bbox_embed[layer_idx](embed), anchors)   # (delta + inverse_sigmoid(anchors)).sigmoid()
         return cls_logits, box_coords
 
-    def compute_losses(self, outputs, targets, dn_meta=None):
+    def compute_losses(self, outputs, targets, dn_meta=None, prepared=None, q_of_g=None):
         # weighted in the loss module, all terms in one multiply (*_dn / *_dn_i keys are not in the dict -> weight 1, as in
-        # the reference's loop over weight_dict)
-        loss_dict = self.losses(outputs, targets, dn_meta=dn_meta, weights=self.losses.weight_dict)
+        # the reference's loop over weight_dict); `prepared` / `q_of_g`: the caller matched this call already (losses.match_together)
+        loss_dict = self.losses(outputs, targets, dn_meta=dn_meta, weights=self.losses.weight_dict, prepared=prepared,
+                                q_of_g=q_of_g)
         if self.with_metrics:
             with torch.no_grad():
                 loss_dict["accuracy"] = accuracy(*self.losses.get_target_classes())

@@ -82,6 +82,37 @@ def _pad_targets(targets, device):
     return labels, boxes, counts
 
 
+def match_together(calls):
+    """calls: [(matcher, prepare() dict), ...] with equal query and (padded) GT counts -> the assignments [L_i, B, G] of every
+    call from ONE device-side assignment launch: the Hungarian kernel is one workgroup per (layer, scene) problem and as long
+    as its slowest problem, so the encoder-proposal matching (B problems) and the decoder's (L x B) cost one launch's time
+    instead of two (2 x ~190 us on the step's critical path).  None when the calls cannot share a launch (host tensors,
+    different shapes): the caller then lets every loss match for itself."""
+    from ..operators.assignment import linear_sum_assignment_batched
+    from ..operators.det_loss import match_cost
+
+    if not calls or not all(pr["m_logits"].is_cuda for _, pr in calls):
+        return None
+    q, g = calls[0][1]["m_logits"].shape[2], calls[0][1]["tgt_labels"].shape[1]
+    if any(pr["m_logits"].shape[2] != q or pr["tgt_labels"].shape[1] != g for _, pr in calls):
+        return None
+    dev = calls[0][1]["m_logits"].device
+    sizes = [pr["m_logits"].shape[0] * pr["m_logits"].shape[1] for _, pr in calls]
+    cost = torch.empty((sum(sizes), q, g), dtype=torch.float32, device=dev)
+    off, ng = 0, []
+    for (matcher, pr), n in zip(calls, sizes):
+        match_cost(pr["m_logits"], pr["m_boxes"], pr["tgt_labels"], pr["tgt_boxes"], matcher.cost_class, matcher.cost_bbox,
+                   matcher.cost_giou, matcher.cost_rad, out=cost[off:off + n])
+        ng += list(pr["counts"]) * pr["m_logits"].shape[0]
+        off += n
+    assigned = linear_sum_assignment_batched(cost, torch.tensor(ng, dtype=torch.int32).to(dev, non_blocking=True))
+    out, off = [], 0
+    for (_, pr), n in zip(calls, sizes):
+        out.append(assigned[off:off + n].view(pr["m_logits"].shape[0], pr["m_logits"].shape[1], g))
+        off += n
+    return out
+
+
 class Det3DLoss(nn.Module):
     """$CQ/losses.py:111-214 (+ ClassificationLoss :26-73, RegressionLoss :76-108)."""
 
@@ -138,21 +169,12 @@ class Det3DLoss(nn.Module):
             out["loss_bbox"], out["loss_giou"], out["loss_rad"] = sums[:, 0], sums[:, 1], sums[:, 2]
         return out, cls
 
-    def forward(self, outputs, targets, dn_meta=None, weights=None):
-        """`weights`: {key: coefficient} applied to the terms in one multiply (None: unweighted terms)."""
+    def prepare(self, outputs, targets):
+        """The layer-stacked tensors the matcher and the losses of `forward` read (auxiliary layers first, the final layer
+        last), so that a caller can match SEVERAL loss calls in one assignment launch (`match_together`) and hand each its
+        share back through `forward(..., prepared=, q_of_g=)`."""
         dev = outputs["pred_logits"].device
-        n_gt = sum(len(t["labels"]) for t in targets)
-        if get_world_size() > 1:
-            # kept on the device (0-dim tensor): the reference reads it back with .item() (losses.py:131-135),
-            # which would drain the stream once per step for a value that is only ever a divisor
-            nb = torch.tensor([float(n_gt)]).to(dev, non_blocking=True)
-            torch.distributed.all_reduce(nb)
-            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
-        else:
-            num_boxes = max(float(n_gt), 1.0)
         tgt_labels, tgt_boxes, counts = _pad_targets(targets, dev)
-
-        # stack the layers: auxiliary outputs first, the final layer last
         layers = list(outputs.get("aux_outputs", [])) + [outputs]
         logits = torch.stack([o["pred_logits"] for o in layers])
         topk = outputs.get("topk_indexes")
@@ -167,7 +189,27 @@ class Det3DLoss(nn.Module):
         else:
             boxes = torch.stack([o["pred_boxes"] for o in layers])
             m_logits, m_boxes = logits, boxes
-        q_of_g = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L,B,G] on dev
+        return {"layers": layers, "logits": logits, "boxes": boxes, "m_logits": m_logits, "m_boxes": m_boxes, "topk": topk,
+                "tgt_labels": tgt_labels, "tgt_boxes": tgt_boxes, "counts": counts}
+
+    def forward(self, outputs, targets, dn_meta=None, weights=None, prepared=None, q_of_g=None):
+        """`weights`: {key: coefficient} applied to the terms in one multiply (None: unweighted terms).  `prepared` /
+        `q_of_g`: this call's `prepare()` and its assignment [L, B, G], when the caller has matched it already."""
+        dev = outputs["pred_logits"].device
+        n_gt = sum(len(t["labels"]) for t in targets)
+        if get_world_size() > 1:
+            # kept on the device (0-dim tensor): the reference reads it back with .item() (losses.py:131-135),
+            # which would drain the stream once per step for a value that is only ever a divisor
+            nb = torch.tensor([float(n_gt)]).to(dev, non_blocking=True)
+            torch.distributed.all_reduce(nb)
+            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
+        else:
+            num_boxes = max(float(n_gt), 1.0)
+        pr = prepared if prepared is not None else self.prepare(outputs, targets)
+        layers, logits, boxes, m_logits, m_boxes, topk = (pr[k] for k in ("layers", "logits", "boxes", "m_logits", "m_boxes", "topk"))
+        tgt_labels, tgt_boxes, counts = pr["tgt_labels"], pr["tgt_boxes"], pr["counts"]
+        if q_of_g is None:
+            q_of_g = self.matcher.match_layers(m_logits, m_boxes, tgt_labels, tgt_boxes, counts)  # [L,B,G] on dev
         outputs["matched_query_of_gt"] = q_of_g[-1]
         # (layer, scene, gt) of every matched pair is known from the GT counts alone: built on the host, one
         # asynchronous upload; the matched query comes from the device-side assignment

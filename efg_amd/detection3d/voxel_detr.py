@@ -35,7 +35,7 @@ from ..spconv import core as spconv_core
 from .box_coder import VoxelBoxCoder3D
 from .cdn import dn_attn_mask, dn_post_process, prepare_for_cdn
 from .heads import Det3DHead
-from .losses import LossDict, PaddedTargets
+from .losses import match_together, LossDict, PaddedTargets
 from .position_encoding import build_position_encoding
 from .transformer import Transformer
 
@@ -274,13 +274,24 @@ class VoxelDETR(nn.Module):
             for tgt in bin_targets:
                 tgt["labels"].fill_(0)
         enc_outputs = dict(self.transformer.enc_outputs)  # class logits of all tokens + boxes of the top-k (one evaluation)
-        enc_losses = self.transformer.proposal_head.compute_losses(enc_outputs, bin_targets)
-        losses.merge(enc_losses, "_enc")
         nq = self.num_queries
         outputs = {"pred_logits": outputs_class[-1][:, :nq], "pred_boxes": outputs_coord[-1][:, :nq],
                    "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
+        # the encoder-proposal and the decoder matchings in ONE assignment launch (losses.match_together); host tensors and
+        # EFG_MATCH_TOGETHER=0: every loss matches for itself, as the reference does
+        phead = self.transformer.proposal_head
+        prep_e = prep_d = q_e = q_d = None
+        if outputs_class.is_cuda and os.environ.get("EFG_MATCH_TOGETHER", "1") != "0":
+            prep_e, prep_d = phead.losses.prepare(enc_outputs, bin_targets), head.losses.prepare(outputs, targets)
+            both = match_together([(phead.losses.matcher, prep_e), (head.losses.matcher, prep_d)])
+            if both is None:
+                prep_e = prep_d = None
+            else:
+                q_e, q_d = both
+        enc_losses = phead.compute_losses(enc_outputs, bin_targets, prepared=prep_e, q_of_g=q_e)
+        losses.merge(enc_losses, "_enc")
         with record_function("efg::losses.decoder"):
-            losses.merge(head.compute_losses(outputs, targets, dn_meta))
+            losses.merge(head.compute_losses(outputs, targets, dn_meta, prepared=prep_d, q_of_g=q_d))
         if self.is_conquer:
             with record_function("efg::losses.contrastive"):
                 losses.merge(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],

@@ -16,13 +16,15 @@ def device_scalar(value, device):
     return torch.tensor(float(value), dtype=torch.float32).to(device, non_blocking=True)
 
 
-def match_cost(logits, boxes, tgt_labels, tgt_boxes, w_class, w_bbox, w_giou, w_rad, alpha=0.25, gamma=2.0):
-    """logits [L,B,Q,C], boxes [L,B,Q,7], tgt_labels [B,G] int64, tgt_boxes [B,G,7] -> cost [L*B, Q, G]."""
+def match_cost(logits, boxes, tgt_labels, tgt_boxes, w_class, w_bbox, w_giou, w_rad, alpha=0.25, gamma=2.0, out=None):
+    """logits [L,B,Q,C], boxes [L,B,Q,7], tgt_labels [B,G] int64, tgt_boxes [B,G,7] -> cost [L*B, Q, G] (into `out`, a
+    contiguous [L*B, Q, G] fp32 view, if given)."""
     L.require_gpu(logits, boxes, tgt_labels, tgt_boxes)
     n_layers, b, q, c = logits.shape
     g = tgt_labels.shape[1]
     lg, bx = logits.detach().contiguous().float(), boxes.detach().contiguous().float()
-    cost = torch.empty((n_layers * b, q, g), dtype=torch.float32, device=logits.device)
+    cost = out if out is not None else torch.empty((n_layers * b, q, g), dtype=torch.float32, device=logits.device)
+    assert cost.shape == (n_layers * b, q, g) and cost.dtype == torch.float32 and cost.is_contiguous()
     L.check(L.lib().efg_match_cost_f32(L.ptr(lg), L.ptr(bx), L.ptr(tgt_labels.contiguous()),
                                        L.ptr(tgt_boxes.contiguous().float()), n_layers * b, b, q, c, g, float(w_class),
                                        float(w_bbox), float(w_giou), float(w_rad), float(alpha), float(gamma),
