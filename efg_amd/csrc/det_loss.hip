@@ -70,7 +70,9 @@ __device__ __forceinline__ float focal_elem(float x, bool t, float alpha, float 
   const float p = 1.0f / (1.0f + expf(-x));
   const float ce = fmaxf(x, 0.f) - (t ? x : 0.f) + log1pf(expf(-fabsf(x)));
   const float pt = t ? p : 1.f - p;
-  float loss = ce * powf(1.f - pt, gamma);
+  // (gamma == 2, the reference's value: ATen evaluates pow(x, 2.0) as x * x too; the general powf was half of this kernel)
+  const float one_m = 1.f - pt;
+  float loss = ce * (gamma == 2.0f ? one_m * one_m : powf(one_m, gamma));
   if (alpha >= 0.f) loss *= t ? alpha : 1.f - alpha;
   return loss;
 }
@@ -83,7 +85,8 @@ __device__ __forceinline__ float focal_elem_grad(float x, bool t, float alpha, f
   const float one_m = 1.f - pt;
   const float dce = p - (t ? 1.f : 0.f);                 // d ce / dx
   const float dpt = (t ? 1.f : -1.f) * p * (1.f - p);    // d p_t / dx
-  float g = dce * powf(one_m, gamma) - ce * gamma * powf(one_m, gamma - 1.f) * dpt;
+  float g = gamma == 2.0f ? dce * (one_m * one_m) - ce * 2.0f * one_m * dpt
+                          : dce * powf(one_m, gamma) - ce * gamma * powf(one_m, gamma - 1.f) * dpt;
   if (alpha >= 0.f) g *= t ? alpha : 1.f - alpha;
   return g;
 }
