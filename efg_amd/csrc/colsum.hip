@@ -246,15 +246,19 @@ ColsumPlan colsum_plan(int64_t rows, int cols, int64_t row_stride, const void* x
   return p;
 }
 
+}  // namespace
+
 // Ticket counters of the fused final: a ring of zero-initialised device words per device; a call takes `n` consecutive ones
 // (one per column group).  A slot comes round again after kRing / n calls -- far beyond what a stream keeps in flight --
 // and each counter is back at 0 when its kernel ends.  nullptr (=> two launches) while the stream is being captured.
+namespace {
 constexpr unsigned kRing = 8192;
 std::mutex g_ring_mu;
 unsigned* g_ring[64] = {};
 unsigned g_ring_next[64] = {};
+}  // namespace
 
-unsigned* ticket_slots(int n, hipStream_t st) {
+unsigned* ticket_slots(int n, hipStream_t st) {   // (declared in common.h: det_loss.hip draws from the same ring)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || n < 1 || (unsigned)n > kRing / 4) return nullptr;
   // a launch that is being CAPTURED keeps the two-launch form: its ring slot would be baked into the graph and every
@@ -277,7 +281,6 @@ unsigned* ticket_slots(int n, hipStream_t st) {
   return out;
 }
 
-}  // namespace
 }  // namespace efg
 
 using namespace efg;

@@ -111,4 +111,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* smem, int* total
   return r;
 }
 
+// `n` consecutive words of a per-device ring of device words that are ZERO at rest (csrc/colsum.hip): ticket counters and
+// small scratch of single-launch reductions -- whoever draws them stores 0 back before its kernel ends.  nullptr while the
+// stream is being captured (a slot baked into a graph could meet an eager call's) or when the ring cannot be created: the
+// caller then takes its form without tickets.
+unsigned* ticket_slots(int n, hipStream_t st);
+
 }  // namespace efg

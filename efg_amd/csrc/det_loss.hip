@@ -12,6 +12,8 @@
 // Reductions are one workgroup per layer with a fixed tree: deterministic.
 #include "common.h"
 
+#include <algorithm>
+
 namespace efg {
 namespace {
 
@@ -136,6 +138,56 @@ focal_sum_kernel(const float* __restrict__ logits, const int* __restrict__ tcls,
   }
   const float s = block_sum_1024(acc, sm);
   if (threadIdx.x == 0) out[l] = s / denom[0];
+}
+
+// The same sum over SPLIT workgroups per layer (the encoder's 70 688 tokens on one workgroup were 88 us of one CU's
+// transcendental throughput): workgroup (l, s) sums the elements  s * 1024 + t + k * (1024 * split)  of layer l -- a thread's
+// elements in ascending order, as above --, publishes its partial and takes a ticket; the workgroup that draws the layer's last
+// ticket adds the partials in s order and stores 0 back into the slots (efg::ticket_slots: zero at rest).  Deterministic: the
+// ticket decides WHO adds, not the order.   slots: [layers] counters | [layers * split] partial sums (float bits)
+__global__ void __launch_bounds__(1024)
+focal_sum_split_kernel(const float* __restrict__ logits, const int* __restrict__ tcls, long long N, int C, float alpha,
+                       float gamma, const float* __restrict__ denom, float* __restrict__ out, unsigned* __restrict__ slots) {
+  __shared__ float sm[16];
+  __shared__ int s_last;
+  const int l = blockIdx.x, split = gridDim.y, sidx = blockIdx.y;
+  const float* lg = logits + (long long)l * N * C;
+  const int* tc = tcls + (long long)l * N;
+  unsigned* counter = slots + l;
+  float* partial = reinterpret_cast<float*>(slots + gridDim.x) + (long long)l * split;
+  const long long total = N * C, stride = 1024ll * split;
+  float acc = 0.f;
+  constexpr int kFly = 8;
+  for (long long e0 = (long long)sidx * 1024 + threadIdx.x; e0 < total; e0 += kFly * stride) {
+    float x[kFly];
+    bool hit[kFly], on[kFly];
+#pragma unroll
+    for (int u = 0; u < kFly; ++u) {
+      const long long e = e0 + stride * u;
+      on[u] = e < total;
+      const long long ec = on[u] ? e : 0;
+      x[u] = lg[ec];
+      hit[u] = tc[ec / C] == (int)(ec % C);
+    }
+#pragma unroll
+    for (int u = 0; u < kFly; ++u)
+      if (on[u]) acc += focal_elem(x[u], hit[u], alpha, gamma);
+  }
+  const float s = block_sum_1024(acc, sm);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + sidx, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == (unsigned)split - 1;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  float t = 0.f;
+  for (int i = 0; i < split; ++i) {
+    t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(partial + i, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  out[l] = t / denom[0];
 }
 
 __global__ void __launch_bounds__(256)
@@ -303,8 +355,17 @@ extern "C" int efg_focal_loss_forward_f32(const float* logits, const int32_t* ta
   EFG_CHECK_ARG(layers >= 0 && n >= 0 && c >= 1, "focal_loss: bad sizes");
   if (layers == 0) return EFG_OK;
   EFG_CHECK_ARG(denom && out && (n == 0 || (logits && target_class)), "focal_loss: null pointer");
-  hipLaunchKernelGGL(focal_sum_kernel, dim3(layers), dim3(1024), 0, (hipStream_t)stream, logits, target_class,
-                     (long long)n, c, alpha, gamma, denom, out);
+  // from ~16k elements per layer: split over up to 32 workgroups per layer (a fixed function of the shape: the grouping of
+  // the sum, hence its bits, depends on nothing else)
+  const long long per_layer = (long long)n * c;
+  const int split = (int)std::min<long long>(32, per_layer / 8192);
+  unsigned* slots = split >= 2 ? ticket_slots(layers * (1 + split), (hipStream_t)stream) : nullptr;
+  if (slots)
+    hipLaunchKernelGGL(focal_sum_split_kernel, dim3(layers, split), dim3(1024), 0, (hipStream_t)stream, logits, target_class,
+                       (long long)n, c, alpha, gamma, denom, out, slots);
+  else
+    hipLaunchKernelGGL(focal_sum_kernel, dim3(layers), dim3(1024), 0, (hipStream_t)stream, logits, target_class,
+                       (long long)n, c, alpha, gamma, denom, out);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
 }

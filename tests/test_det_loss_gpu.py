@@ -70,6 +70,24 @@ def test_focal_layers(shape):
     _close(g_fused, logits.grad, "grad logits")
 
 
+def test_focal_sum_over_split_workgroups_is_reproducible():
+    """From ~16k elements per layer the focal sum runs on several workgroups per layer; the one that draws the layer's last
+    ticket adds the partial sums in index order and zeroes its ring slots: a hundred calls (two shapes interleaved, so the
+    slots are reused by calls of another size) give the first call's bits."""
+    from efg_amd.operators.det_loss import FocalLossLayers, device_scalar
+
+    g = torch.Generator().manual_seed(1)
+    cases = []
+    for shape in [(1, 2, 35344, 1), (3, 2, 9000, 3)]:
+        logits = (torch.randn(shape, generator=g) * 3).cuda()
+        tcls = torch.randint(-1, shape[-1], shape[:-1], generator=g, dtype=torch.int32).cuda()
+        cases.append((logits, tcls, device_scalar(11.0, logits.device)))
+    first = [FocalLossLayers.apply(lg, tc, dn, 0.25, 2.0).clone() for lg, tc, dn in cases]
+    for _ in range(100):
+        for (lg, tc, dn), want in zip(cases, first):
+            assert torch.equal(FocalLossLayers.apply(lg, tc, dn, 0.25, 2.0), want)
+
+
 def test_box_loss_layers():
     from efg_amd.detection3d.utils import box_cxcyczlwh_to_xyxyxy, paired_box3d_giou
     from efg_amd.operators.det_loss import BoxLossLayers, device_scalar
