@@ -7,6 +7,7 @@ layers x {matching, denoising} x {labels, boxes} x scenes with ~40 tiny kernels 
 each (~1000 launches and 4 syncs per step at 3 layers); here all layers are stacked, matched with ONE
 cost-matrix transfer, and each loss family is one pass whose per-layer sums are read off a vector.
 """
+import contextlib
 import os
 
 import torch
@@ -82,12 +83,14 @@ def _pad_targets(targets, device):
     return labels, boxes, counts
 
 
-def match_together(calls):
+def match_together(calls, side=None):
     """calls: [(matcher, prepare() dict), ...] with equal query and (padded) GT counts -> the assignments [L_i, B, G] of every
     call from ONE device-side assignment launch: the Hungarian kernel is one workgroup per (layer, scene) problem and as long
     as its slowest problem, so the encoder-proposal matching (B problems) and the decoder's (L x B) cost one launch's time
-    instead of two (2 x ~190 us on the step's critical path).  None when the calls cannot share a launch (host tensors,
-    different shapes): the caller then lets every loss match for itself."""
+    instead of two (2 x ~190 us on the step's critical path).  `side`: a stream to queue the cost and assignment kernels on
+    (after everything queued on the current one; the caller joins it) -- the small host-to-device copy of the GT counts stays
+    on the CURRENT stream.  None when the calls cannot share a launch (host tensors, different shapes): the caller then lets
+    every loss match for itself."""
     from ..operators.assignment import linear_sum_assignment_batched
     from ..operators.det_loss import match_cost
 
@@ -98,14 +101,25 @@ def match_together(calls):
         return None
     dev = calls[0][1]["m_logits"].device
     sizes = [pr["m_logits"].shape[0] * pr["m_logits"].shape[1] for _, pr in calls]
-    cost = torch.empty((sum(sizes), q, g), dtype=torch.float32, device=dev)
-    off, ng = 0, []
-    for (matcher, pr), n in zip(calls, sizes):
-        match_cost(pr["m_logits"], pr["m_boxes"], pr["tgt_labels"], pr["tgt_boxes"], matcher.cost_class, matcher.cost_bbox,
-                   matcher.cost_giou, matcher.cost_rad, out=cost[off:off + n])
+    ng = []
+    for _, pr in calls:
         ng += list(pr["counts"]) * pr["m_logits"].shape[0]
-        off += n
-    assigned = linear_sum_assignment_batched(cost, torch.tensor(ng, dtype=torch.int32).to(dev, non_blocking=True))
+    ng_dev = torch.tensor(ng, dtype=torch.int32).to(dev, non_blocking=True)
+    main = None
+    if side is not None:
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        cost = torch.empty((sum(sizes), q, g), dtype=torch.float32, device=dev)
+        off = 0
+        for (matcher, pr), n in zip(calls, sizes):
+            match_cost(pr["m_logits"], pr["m_boxes"], pr["tgt_labels"], pr["tgt_boxes"], matcher.cost_class, matcher.cost_bbox,
+                       matcher.cost_giou, matcher.cost_rad, out=cost[off:off + n])
+            off += n
+        assigned = linear_sum_assignment_batched(cost, ng_dev)
+    if side is not None:
+        ng_dev.record_stream(side)
+        cost.record_stream(side)
     out, off = [], 0
     for (_, pr), n in zip(calls, sizes):
         out.append(assigned[off:off + n].view(pr["m_logits"].shape[0], pr["m_logits"].shape[1], g))

@@ -16,6 +16,7 @@ OUR side of the operator boundary and none changing a result:
     and discards them; their parameters get no gradient there either);
   * the contrastive loss's Python double loop (:234-253) is evaluated in batched tensor form.
 """
+import contextlib
 import copy
 import os
 
@@ -280,14 +281,30 @@ class VoxelDETR(nn.Module):
         # the encoder-proposal and the decoder matchings in ONE assignment launch (losses.match_together); host tensors and
         # EFG_MATCH_TOGETHER=0: every loss matches for itself, as the reference does
         phead = self.transformer.proposal_head
-        prep_e = prep_d = q_e = q_d = None
+        prep_e = prep_d = q_e = q_d = sim = None
         if outputs_class.is_cuda and os.environ.get("EFG_MATCH_TOGETHER", "1") != "0":
             prep_e, prep_d = phead.losses.prepare(enc_outputs, bin_targets), head.losses.prepare(outputs, targets)
-            both = match_together([(phead.losses.matcher, prep_e), (head.losses.matcher, prep_d)])
+            # EFG_MATCH_STREAM=1: the assignment (one workgroup per problem, ~200 us with the device otherwise idle) on the side
+            # stream, the matching-independent half of the contrastive loss (its projections and the similarity product) on
+            # the main one meanwhile.  Off by default: measured neutral on the shared side stream (31.69 / 31.74 against
+            # 31.68 / 31.76) -- and 61-65 ms per step on a stream of its own (streams.py)
+            side = main = None
+            if os.environ.get("EFG_MATCH_STREAM", "0") == "1":
+                from ..streams import side_stream
+
+                side, main = side_stream(outputs_class.device, "matching"), torch.cuda.current_stream(outputs_class.device)
+            both = match_together([(phead.losses.matcher, prep_e), (head.losses.matcher, prep_d)], side=side)
+            if self.is_conquer and dn_meta is not None and sum(t["gt_boxes"].shape[0] for t in targets) > 0:
+                sim = self._contrastive_similarity(outputs_class, outputs_coord)
+            if side is not None:
+                main.wait_stream(side)
             if both is None:
                 prep_e = prep_d = None
             else:
                 q_e, q_d = both
+                if side is not None:
+                    q_e.record_stream(main)
+                    q_d.record_stream(main)
         enc_losses = phead.compute_losses(enc_outputs, bin_targets, prepared=prep_e, q_of_g=q_e)
         losses.merge(enc_losses, "_enc")
         with record_function("efg::losses.decoder"):
@@ -295,10 +312,24 @@ class VoxelDETR(nn.Module):
         if self.is_conquer:
             with record_function("efg::losses.contrastive"):
                 losses.merge(self._contrastive_losses(outputs_class, outputs_coord, outputs["matched_query_of_gt"],
-                                                      targets, dn_meta))
+                                                      targets, dn_meta, sim=sim))
         return losses
 
-    def _contrastive_losses(self, outputs_class, outputs_coord, query_of_gt, targets, dn_meta):
+    def _contrastive_similarity(self, outputs_class, outputs_coord):
+        """The half of the contrastive loss that does not depend on the matching: projections of the noised-GT rows and of the
+        queries, normalised, and EVERY noised-GT row against every query of its scene in one [R, C] x [C, Q] product per
+        (layer, scene) -> [L, B, R, Q] / tau.  (Gathering the per-pair operands first, as the loop form suggests,
+        materialises a [L, n, Q, C] copy of the query projections -- 245 MB for 80 boxes -- and runs L*n small products over
+        it, forward and backward.)  `_losses` issues it while the assignment kernel runs on the matching stream."""
+        nq, n_layers = self.num_queries, self.config.model.transformer.dec_layers
+        projs = torch.cat((outputs_class[:n_layers], outputs_coord[:n_layers]), dim=-1)     # [L, B, Q+gt, 10]
+        gt_projs = self.projector(projs[:, :, nq:].detach())                                 # [L, B, gt, C]
+        pred_projs = self.predictor(self.projector(projs[:, :, :nq]))                        # [L, B, Q, C]
+        gt_n = F.normalize(gt_projs, dim=-1, eps=1e-8)                                        # [L, B, R, C]
+        pn = F.normalize(pred_projs, dim=-1, eps=1e-8)                                        # [L, B, Q, C]
+        return torch.matmul(gt_n, pn.transpose(-1, -2)) / self.tau
+
+    def _contrastive_losses(self, outputs_class, outputs_coord, query_of_gt, targets, dn_meta, sim=None):
         """voxel_detr.py:223-254 in batched form.  For decoder layer li and scene bi, every matched
         (query p, gt g) contributes the mean over the G positive-noised GT copies r = g + max_gt*pi of
         log(exp(s[r,p]) + sum_{q unmatched} exp(s[r,q])) - s[r,p], s = cos-sim / tau.  All layers and
@@ -312,6 +343,8 @@ class VoxelDETR(nn.Module):
         nq, groups = self.num_queries, dn_meta["num_dn_group"]
         dev = outputs_class.device
         n_layers = self.config.model.transformer.dec_layers
+        if sim is None:
+            sim = self._contrastive_similarity(outputs_class, outputs_coord)
         # (scene, gt) of all matched pairs follow from the GT counts (host -> one asynchronous upload); the
         # matched query stays on the device
         static = torch.stack([torch.cat([torch.full((n,), bi, dtype=torch.int64) for bi, n in enumerate(per_gt)]),
@@ -323,16 +356,7 @@ class VoxelDETR(nn.Module):
         neg_mask = torch.ones(len(targets), nq, dtype=torch.bool, device=dev)
         neg_mask.index_put_((b_idx, q_idx), torch.zeros((), dtype=torch.bool, device=dev))  # unmatched queries
         rows = g_idx[:, None] + (torch.arange(1, groups + 1, device=dev) * max_gt)[None, :]  # [n, G]
-        projs = torch.cat((outputs_class[:n_layers], outputs_coord[:n_layers]), dim=-1)     # [L, B, Q+gt, 10]
-        gt_projs = self.projector(projs[:, :, nq:].detach())                                 # [L, B, gt, C]
-        pred_projs = self.predictor(self.projector(projs[:, :, :nq]))                        # [L, B, Q, C]
-        # every noised-GT row against every query of its scene in ONE [R, C] x [C, Q] product per (layer, scene),
-        # then pick the rows of the matched pairs.  (Gathering the per-pair operands first, as the loop form
-        # suggests, materialises a [L, n, Q, C] copy of the query projections -- 245 MB for 80 boxes -- and runs
-        # L*n small products over it, forward and backward.)
-        gt_n = F.normalize(gt_projs, dim=-1, eps=1e-8)                                        # [L, B, R, C]
-        pn = F.normalize(pred_projs, dim=-1, eps=1e-8)                                        # [L, B, Q, C]
-        sim = (torch.matmul(gt_n, pn.transpose(-1, -2)) / self.tau)[:, b_idx[:, None], rows]  # [L, n, G, Q]
+        sim = sim[:, b_idx[:, None], rows]                                                    # [L, n, G, Q]
         pos = sim.gather(3, q_idx[None, :, None, None].expand(n_layers, n, groups, 1))
         neg = (torch.exp(sim) * neg_mask[b_idx][None, :, None, :]).sum(dim=-1, keepdim=True)
         per_layer = (torch.log(torch.exp(pos) + neg) - pos).mean(dim=(2, 3)).sum(dim=1)      # [L]

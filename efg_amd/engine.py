@@ -319,7 +319,9 @@ class BucketedGradientAllReduce:
             _pack_found_inf(buf, self.found_inf)
         if main is not None:
             if self.comm is None:
-                self.comm = torch.cuda.Stream(device=dev)
+                from .streams import side_stream
+
+                self.comm = side_stream(dev, "exchange")   # the shared side stream (streams.py: why not one of its own)
             self.comm.wait_stream(main)
             with torch.cuda.stream(self.comm):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
@@ -412,6 +414,9 @@ class Trainer:
                 torch.backends.cudnn.deterministic = True
         torch.manual_seed(seed)
         self.cfg = cfg
+        from .streams import create_side_streams
+
+        create_side_streams(torch.device(str(cfg.model.device)))   # before anything else asks for a pool stream (streams.py)
         self.model = (model_cls or VoxelDETR)(cfg)
         self.model.train()
         self.optimizer = build_optimizer(cfg, self.model)
