@@ -753,7 +753,9 @@ extern "C" int efg_spconv_pack_weights_multi(const void* items_dev, int n, void*
   EFG_CHECK_ARG(n >= 0 && (n == 0 || items_dev), "pack_weights_multi: bad arguments");
   static_assert(sizeof(PackItem) == 32, "PackItem is 2 pointers + 4 ints (the Python side writes it as 4 int64)");
   if (n == 0) return EFG_OK;
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+  // (256 workgroups per item: a thread of the largest layer -- 256 x 27 x 256 weights -- then walks 27 elements, one dependent
+  // load each, instead of 108: the launch was 89 us of load latency)
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(256, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const PackItem*>(items_dev));
   EFG_LAUNCH_CHECK();
   return EFG_OK;
