@@ -44,9 +44,30 @@ int make_geom(const float* vs, const float* cr, VoxGeom* g, unsigned long long* 
 // supercell of the grid) that a small cloud does not amortise -- 16k points: 44 us against 31 us for the hash path,
 // 2 x 180k: 80 against 94, 8 x 180k: 181 against 288 (profiles/r04_vox_times.txt).
 constexpr int64_t kBinsMinPoints = 65536;
+
+// The binned path keeps one counter row per XCD and updates it with atomics that stay in the L2 of the XCD the workgroup
+// runs on (voxelize_bins.hip K1: the row is picked by the XCC_ID hardware register, 8 rows).  That is only a race-free
+// protocol on a part whose XCC_ID values are distinct per L2 and fit the 8 rows: gfx950 (MI350X / MI355X, at most 8 XCDs
+// per device in every partition mode).  Queried once per device; anything else takes the hash path (agent-scope atomics).
+bool bins_supported_here() {
+  static std::atomic<unsigned long long> known{0}, ok{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const unsigned long long bit = 1ull << dev;
+  if (!(known.load(std::memory_order_acquire) & bit)) {
+    hipDeviceProp_t prop;
+    bool good = hipGetDeviceProperties(&prop, dev) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6) &&
+                prop.multiProcessorCount <= 8 * 32;   // (8 XCDs x 32 CUs: more CUs than that is not the part this was built for)
+    if (good) ok.fetch_or(bit, std::memory_order_relaxed);
+    known.fetch_or(bit, std::memory_order_release);
+  }
+  return (ok.load(std::memory_order_relaxed) & bit) != 0;
+}
+
 int pick_impl(int64_t n_total) {
   const char* e = getenv("EFG_VOX_IMPL");
   if (e && !strcmp(e, "hash")) return 1;
+  if (!bins_supported_here()) return 1;
   if (e && !strcmp(e, "bins")) return 0;
   return n_total < kBinsMinPoints ? 1 : 0;
 }

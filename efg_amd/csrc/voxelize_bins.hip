@@ -212,7 +212,7 @@ vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords 
 __global__ void __launch_bounds__(256)
 vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ count, unsigned long long* __restrict__ part,
                     int nchunks, unsigned* __restrict__ basex, uint4* __restrict__ small_list,
-                    uint4* __restrict__ big_list, unsigned* __restrict__ nlist,
+                    uint4* __restrict__ big_list, unsigned* __restrict__ nlist, unsigned* __restrict__ err,
                     unsigned long long* dbg) {
   __shared__ int smem[17];
   __shared__ unsigned long long s_w[4];
@@ -262,6 +262,8 @@ vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ co
       if (x) break;
       __builtin_amdgcn_s_sleep(2);
     }
+    // a chunk that never published: the prefix below would be silently wrong -- K4b turns the flag into voxel_num = -1
+    if (!x) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a_pts += (x >> 30) & 0x1ffffffffull;
     a_s += (unsigned)x & 0x7fffu;
     a_b += ((unsigned)x >> 15) & 0x7fffu;
@@ -476,7 +478,7 @@ vox_first_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, const uint4* __rest
 __global__ void __launch_bounds__(256)
 vox_rank_kernel(SceneOffsets so, SceneWords sw, const unsigned char* __restrict__ flags, unsigned* __restrict__ part2,
                 int nchunks2, unsigned* __restrict__ bits, unsigned* __restrict__ prefix, int* __restrict__ voxel_num,
-                unsigned* __restrict__ i_break, int max_voxels, unsigned long long* dbg) {
+                unsigned* __restrict__ i_break, int max_voxels, unsigned* __restrict__ err, unsigned long long* dbg) {
   __shared__ int smem[17];
   __shared__ unsigned s_w[4];
   mark(dbg, 5, 0);
@@ -506,6 +508,7 @@ vox_rank_kernel(SceneOffsets so, SceneWords sw, const unsigned char* __restrict_
       if (x) break;
       __builtin_amdgcn_s_sleep(2);
     }
+    if (!x) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see K2)
     acc += x & 0x7fffffffu;
   }
 #pragma unroll
@@ -524,7 +527,11 @@ vox_rank_kernel(SceneOffsets so, SceneWords sw, const unsigned char* __restrict_
   }
   if (chunk == nchunks2 - 1 && tid == 255) {   // (run + c of the scene's last word = its number of first points)
     const int total = run + c;
-    voxel_num[scene] = min(total, max_voxels);
+    // The scene's last chunk has looked back over EVERY chunk of K4b, and K2 finished before this launch began: a look-back
+    // of the call that ran out of polls (a broken dispatch-order invariant) is visible here.  The call then reports -1
+    // voxels for the scene -- the write kernel skips it, the host raises -- instead of wrong voxel ids.
+    const bool bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    voxel_num[scene] = bad ? -1 : min(total, max_voxels);
     if (total <= max_voxels) i_break[scene] = kNone;
   }
   mark(dbg, 5, 1);
@@ -799,7 +806,10 @@ vox_write_kernel(SceneOffsets so, SceneWords sw, BinGeom bg, int f, int rs, cons
   a.scene = scene;
   a.beg = (unsigned)so.off[scene];
   a.out_base = 0;
-  for (int b = 0; b < scene; ++b) a.out_base += voxel_num[b];
+  for (int b = 0; b <= scene; ++b) {
+    if (voxel_num[b] < 0) return;   // a look-back of this call failed (K2 / K4b): nothing is written, the host raises
+    if (b < scene) a.out_base += voxel_num[b];
+  }
   const unsigned ib = i_break[scene];  // points from here on are never processed (voxelization_cpu.cpp:78-79)
   // Items are dealt in a zig-zag (w, 2G-1-w, 2G+w, ...): the big bins come first in the list, so the workgroups that
   // hold them (the slowest of a round) take their next item LAST and from the cheap end.
@@ -1000,7 +1010,7 @@ size_t bins_workspace_bytes(int64_t n_total, int batch, int f, const VoxGeom& g)
   if (!bins_layout(n_total, batch, f, g, &L)) return 0;
   const size_t words = (size_t)(n_total / 32 + 4 * batch + 4);
   size_t b = 0;
-  b += align_up((L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + ((size_t)(n_total / 8192 + 2) * batch)) * 4, 256);  // count, part, part2 (cleared)
+  b += align_up((L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + ((size_t)(n_total / 8192 + 2) * batch) + 4) * 4, 256);  // count, part, part2, err (cleared)
   b += align_up(L.s_total * kXcd * 4, 256);                    // basex
   b += 5 * align_up(L.s_total * 16, 256);                      // small_list, big_list x4 (16-byte bin records)
   b += align_up(4 * kMaxBatch * 4, 256);                       // nlist, i_break
@@ -1034,11 +1044,12 @@ int bins_hard_voxelize(const HardArgs& a) {
   for (int b = 0; b < batch; ++b) max_words = std::max(max_words, sw.wb[b + 1] - sw.wb[b]);
   const int nchunks2 = std::max(1, (int)ceil_div(max_words, 256));   // K4b: 256 words = 8192 points per workgroup
   const size_t part2_words = (size_t)(a.n_total / 8192 + 2) * batch;   // >= nchunks2 * batch
-  const size_t cleared_words = L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + part2_words;
+  const size_t cleared_words = L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + part2_words + 4;   // (+ the error word)
   unsigned* count = w.take<unsigned>(cleared_words);
   // (8-byte aligned: s_total is a multiple of 4)
   unsigned long long* part = count ? reinterpret_cast<unsigned long long*>(count + L.s_total * kXcd) : nullptr;
   unsigned* part2 = count ? count + L.s_total * kXcd + (size_t)L.nchunks * batch * 2 : nullptr;
+  unsigned* err = count ? count + cleared_words - 4 : nullptr;
   unsigned* basex = w.take<unsigned>(L.s_total * kXcd);
   uint4* small_list = w.take<uint4>(L.s_total);
   uint4* big_list = w.take<uint4>(4 * L.s_total);
@@ -1072,7 +1083,7 @@ int bins_hard_voxelize(const HardArgs& a) {
                        pos, flags, g_dbg);
   EFG_LAUNCH_CHECK();
   hipLaunchKernelGGL(vox_bin_scan_kernel, dim3(L.nchunks, batch), blk, 0, stream, so, L.bg, count, part, L.nchunks, basex,
-                     small_list, big_list, nlist, g_dbg);
+                     small_list, big_list, nlist, err, g_dbg);
   EFG_LAUNCH_CHECK();
   if (a.n_total > 0) {
     if (stage)
@@ -1095,7 +1106,7 @@ int bins_hard_voxelize(const HardArgs& a) {
     EFG_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(vox_rank_kernel, dim3(nchunks2, batch), blk, 0, stream, so, sw, flags, part2, nchunks2, bits, prefix,
-                     a.voxel_num, i_break, a.max_voxels, g_dbg);
+                     a.voxel_num, i_break, a.max_voxels, err, g_dbg);
   EFG_LAUNCH_CHECK();
   if (a.n_total > 0) {
 #define EFG_VOX_WRITE(KM, FF)                                                                                            \

@@ -17,6 +17,11 @@ from .. import _lib as L
 from .. import _prof
 
 
+_LOOKBACK_MSG = ("efg_hip: hard_voxelize gave up waiting for a look-back record (csrc/voxelize_bins.hip: a workgroup's prefix "
+                 "never arrived -- dispatch-order invariant broken on this device / partition mode); no voxels were written. "
+                 "EFG_VOX_IMPL=hash selects the implementation without look-back scans")
+
+
 def dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3):
     """efg._C.dynamic_voxelize (efg/operators/src/voxelize/voxelization.h:71-83): fills
     coors[N,3] int32 (z,y,x), (-1,-1,-1) outside the range."""
@@ -63,7 +68,10 @@ def hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors
     voxel_num = torch.zeros(1, dtype=torch.int32, device=points.device)
     _hard_voxelize_launch(points, [0, points.shape[0]], voxel_size, coors_range, max_points, max_voxels, voxels, coors,
                           num_points_per_voxel, voxel_num, None)
-    return int(voxel_num.item())
+    n = int(voxel_num.item())
+    if n < 0:
+        raise RuntimeError(_LOOKBACK_MSG)
+    return n
 
 
 class _Voxelization(Function):
@@ -148,6 +156,8 @@ def voxelize_concat(points, offsets, voxel_size, coors_range, max_points, max_vo
         _hard_voxelize_launch(points, offsets, voxel_size, coors_range, max_points, max_voxels, voxels, coors, npv,
                               voxel_num, mean)
     counts = voxel_num.tolist()  # the one sync
+    if min(counts, default=0) < 0:
+        raise RuntimeError(_LOOKBACK_MSG)
     box["m"] = sum(counts)
     m = sum(counts)
     out = {
