@@ -176,9 +176,6 @@ __device__ float4 g_zero_piece;  // (zero-initialised, never written; not const:
 // (4 rows x 16 pieces per instruction instead of one row), the A tile is stored as 16-byte pieces at slot
 // piece ^ row (conflict-free 16-byte writes and fragment reads without padding) and a lane's four A operands of a
 // 16-channel step come from ONE ds_read_b128.  V4 = 0: the 4-byte path (any channel count).
-#ifndef EFG_KNOCK
-#define EFG_KNOCK 0   // diagnostic A/B builds only (scripts/build_ab.sh): 1 no gathers, 2 no weight loads, 4 no LDS staging, 8 no epilogue
-#endif
 #ifndef EFG_TILE_WPE_R2
 #define EFG_TILE_WPE_R2 4   // waves per SIMD asked of the compiler for the stream-K R = 2 shape (A/B builds: scripts/build_ab.sh)
 #endif
@@ -310,10 +307,8 @@ conv_tile_kernel(TileArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) offs[j] = (unsigned)nbs[s * 512 + col * 16 + j] + cc4;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (EFG_KNOCK & 1) pre[s * 16 + j] = __int_as_float((int)offs[j]);
-          else pre[s * 16 + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
-        }
+        for (int j = 0; j < 16; ++j)
+          pre[s * 16 + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
       }
     }
   };
@@ -331,7 +326,6 @@ conv_tile_kernel(TileArgs a) {
         }
       return;
     }
-    if (EFG_KNOCK & 4) return;
 #pragma unroll
     for (int s = 0; s < R; ++s)
       if (pre_m[s]) {
@@ -350,13 +344,8 @@ conv_tile_kernel(TileArgs a) {
   const unsigned bstep = (unsigned)a.np * 64u;
   auto load_b = [&](float4* b, unsigned boff0, int i) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (EFG_KNOCK & 2) {
-        const float f = __int_as_float((int)(boff0 + (unsigned)i * bstep + (unsigned)t * 1024u));
-        b[t] = make_float4(f, f, f, f);
-      } else
+    for (int t = 0; t < NT; ++t)
       b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
-    }
   };
   auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
     if (BF3) {
@@ -412,8 +401,6 @@ conv_tile_kernel(TileArgs a) {
           a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3];
         } else {
           const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
-          if (EFG_KNOCK & 4) a0 = pre[s * 16 + i], a1 = pre[s * 16 + i + 4], a2 = pre[s * 16 + i + 8], a3 = pre[s * 16 + i + 12];
-          else
           a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
         }
 #pragma unroll
@@ -503,15 +490,6 @@ conv_tile_kernel(TileArgs a) {
     }
   }
 
-  if (EFG_KNOCK & 8) {
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < R; ++s)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) sum += (acc[s][t][0] + acc[s][t][1]) + (acc[s][t][2] + acc[s][t][3]);
-    if (sum == 1.2345e38f) a.out[lane] = sum;
-    return;
-  }
   if (KS > 1) {
     // partial accumulators of the other waves of this wave tile, through the (idle) A tiles: 4 n-tiles per pass
     __syncthreads();
@@ -734,12 +712,6 @@ int resident_workgroups(K kernel) {
   return per_cu * cus;
 }
 
-}  // namespace
-}  // namespace efg
-#include "spconv_fat.h"
-namespace efg {
-namespace {
-
 template <int NT, int R, int KS, int V4, int MODE>
 void launch_tiles_k(TileArgs a, unsigned gx, unsigned gy, hipStream_t stream) {
   if (MODE & 2) {
@@ -924,17 +896,6 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   // hipMalloc / hipMemset would invalidate the capture as well.  Captured launches take the plain (non-split) path.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (stream) (void)hipStreamIsCapturing(stream, &cap);
-  // Third generation (spconv_fat.h): one long software pipeline per wave over an equal share of the level's items, for the
-  // 64-channel-wide shape with 4-byte gathers; EFG_CONV_FAT=0: the stream-K tile kernel (A/B).  Not while capturing (first
-  // use allocates the scratch).
-  static const int fat_env = getenv("EFG_CONV_FAT") ? atoi(getenv("EFG_CONV_FAT")) : 0;
-  // (its range arithmetic is 32-bit: items x waves below 2^32, from the upper bound tiles x offsets x slices on the items)
-  if (fat_env && cap == hipStreamCaptureStatusNone && nt == 4 && !a.v4 && !a.bf3 && cin % 64 == 0 &&
-      (unsigned long long)a.n_tiles * (unsigned)kvol * (unsigned)ny < (1ull << 20)) {
-    if (int rc = run_fat(a, pv, stream)) return rc;
-    EFG_LAUNCH_CHECK();
-    return EFG_OK;
-  }
   if (cap == hipStreamCaptureStatusNone && sk_env && nt == 4 && ks == 4 && !a.v4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
     StreamKState* st = nullptr;
     if (int rc = streamk_for_stream(stream, &st)) return rc;
@@ -1013,11 +974,6 @@ extern "C" int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset) {
     if (reset && v) EFG_HIP_TRY(hipMemset(kv.second.flags + kStreamKMaxGrid, 0, sizeof(int)));
   }
   *count_out = total;
-  return EFG_OK;
-}
-
-extern "C" int efg_spconv_fat_debug(void* buf) {   // int64 [2048][16] device buffer (or null): per-wave clock stamps of conv_fat_kernel
-  g_fat_debug = buf;
   return EFG_OK;
 }
 

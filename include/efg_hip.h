@@ -219,10 +219,6 @@ int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, co
 int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset);
 /* 1 when the split-precision arm of the tile kernel covers a (cin -> cout, kvol) convolution of these table sizes. */
 int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out);
-/* Timing study of conv_fat_kernel (scripts/ubench/fat_waves.py): buf = device int64 [2048][16] the next launches fill per
- * wave with {start clock, end clock, steps with both sub-tiles, steps with one, units, cut units, workgroup, XCC id};
- * NULL switches it off.  Not part of the reference surface. */
-int efg_spconv_fat_debug(void* buf);
 
 /* order[m]: the rows of `indices` (int32 [m][4] = b, z, y, x) grouped by the parity of (z, y, x) -- the rows of a
  * stride-2 layer's dgrad that share their set of reachable kernel offsets.  ws: 64 bytes. */
