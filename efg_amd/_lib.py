@@ -76,6 +76,8 @@ _SIGS = {
     "efg_msda_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efg_box_attn_fused_forward_f32": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p, c_void_p]),
+    "efg_box_attn_fused_forward_strided_f32": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "efg_box_attn_fused_backward_strided_f32": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "efg_box_attn_fused_backward_workspace_bytes": (c_size_t, [c_int] * 6),
     "efg_box_attn_fused_backward_f32": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "efg_boxes_bev_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -25,6 +25,9 @@ constexpr int kSoftmaxLds = 4096;  // floats: (pairs per workgroup) x (L*P) must
 struct BoxDims {
   int b, s, h, d, l, lq, p, v;  // v = 4 (no rotation) or 5
   int lp, lp_shift;
+  // row strides (floats) of the offsets / logits matrices and of their gradients: h * l * v and h * l * p when each is a
+  // matrix of its own, the width of the shared matrix when both come out of ONE projection (Box3dAttention)
+  int off_rs, lg_rs;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -152,7 +155,7 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   const int bi = (int)(bq / dm.lq);
   const int row_stride = dm.h * dm.d;
   const int np = dm.l * dm.p;
-  const float* lg = logits + tt * np;
+  const float* lg = logits + bq * dm.lg_rs + m * np;
   // softmax over the L*P logits of the pair, shared by its LP lanes: each lane exponentiates every LP-th
   // logit, the weights go through LDS (the redundant form costs 2*L*P expf per lane)
   __shared__ float a_s[kSoftmaxLds];
@@ -175,7 +178,7 @@ box_fwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
   for (int li = 0; li < dm.l; ++li) {
     const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
     const float* v = value + (((long long)bi * dm.s + starts[li]) * dm.h + m) * dm.d + c0;
-    const BoxGeo g = make_box(ref + bq * 7, off + (tt * dm.l + li) * dm.v, dm.v);
+    const BoxGeo g = make_box(ref + bq * 7, off + bq * dm.off_rs + (m * dm.l + li) * dm.v, dm.v);
     if (dm.lp >= 4 && (long long)dm.s * row_stride < (1ll << 31)) {   // (32-bit row offsets)
       // The lanes of a pair differ only in their channels, and the first version had every one of them work out
       // every point's geometry (110 VALU instructions per point, 50 of them geometry, in a kernel whose 100 gathers
@@ -309,7 +312,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     const int m = (int)(t % dm.h);
     const long long bq = t / dm.h;
     const int bi = (int)(bq / dm.lq);
-    const float* lg = logits + t * np;
+    const float* lg = logits + bq * dm.lg_rs + m * np;
     float* as = a_s[slot];
     float mx = -INFINITY;
     for (int e = sub; e < np; e += LP) mx = fmaxf(mx, lg[e]);
@@ -334,7 +337,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
       const long long vbase = (((long long)bi * dm.s + starts[li]) * dm.h + m) * dm.d + c0;
       const float* v = value + vbase;
       float* gv = grad_value + vbase;
-      const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
+      const BoxGeo g = make_box(ref + bq * 7, off + bq * dm.off_rs + (m * dm.l + li) * dm.v, dm.v);
       float dcx = 0.f, dcy = 0.f, dw = 0.f, dh = 0.f, dth = 0.f;
       for (int pi = 0; pi < dm.p; ++pi) {
         const float kxn = kidx[pi * 2], kyn = kidx[pi * 2 + 1];
@@ -418,7 +421,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
         dth += __shfl_xor(dth, dlt, 64);
       }
       if (qok && sub == 0) {
-        float* go = grad_off + (t * dm.l + li) * dm.v;
+        float* go = grad_off + bq * dm.off_rs + (m * dm.l + li) * dm.v;
         go[0] = dcx * g.rw / 8.0f;
         go[1] = dcy * g.rh / 8.0f;
         go[2] = g.w_on ? dw * g.rw / 8.0f : 0.0f;
@@ -430,7 +433,7 @@ box_bwd_kernel(const float* __restrict__ value, const long long* __restrict__ sh
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // softmax backward: d logit_p = a_p * (ga_p - sum_j a_j ga_j); the LP lanes of the pair share the work
     if (qok) {
-      for (int e = sub; e < np; e += LP) grad_logits[t * np + e] = as[e] * inv * (ga_s[slot][e] - dot);
+      for (int e = sub; e < np; e += LP) grad_logits[bq * dm.lg_rs + m * np + e] = as[e] * inv * (ga_s[slot][e] - dot);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -563,7 +566,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     const long long bq = (long long)bi * dm.lq + (long long)qy * Wm + qx, t = bq * dm.h + m;
     pre.go = ld4(grad_out + t * D + sub * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pre.lg[k] = logits[t * np + min(sub + 8 * k, np - 1)];
+    for (int k = 0; k < 4; ++k) pre.lg[k] = logits[bq * dm.lg_rs + m * np + min(sub + 8 * k, np - 1)];
     const float* r = ref + bq * 7;
     pre.rf[0] = r[0];
     pre.rf[1] = r[1];
@@ -571,7 +574,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     pre.rf[3] = r[4];
     pre.rf[4] = r[6];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) pre.of[k] = off[t * dm.v + min(k, dm.v - 1)];
+    for (int k = 0; k < 5; ++k) pre.of[k] = off[bq * dm.off_rs + m * dm.v + min(k, dm.v - 1)];
   };
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
 
@@ -591,7 +594,8 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     }
     const int qy = ty0 + slot / TQX, qx = tx0 + slot % TQX;
     const bool qok = qy < Hm && qx < Wm;
-    const long long t = qok ? (((long long)bi * dm.lq + (long long)qy * Wm + qx) * dm.h + m) : 0;
+    const long long bqs = qok ? ((long long)bi * dm.lq + (long long)qy * Wm + qx) : 0;
+    const long long t = bqs * dm.h + m;
     *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? pre.go : make_float4(0.f, 0.f, 0.f, 0.f);
     // softmax statistics of the pair (8 lanes share the work)
     float* as = a_s + slot * PMAX;
@@ -729,7 +733,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     dth += __shfl_xor(dth, 4, 64);
     dot += __shfl_xor(dot, 4, 64);
     if (qok && sub == 0) {
-      float* go = grad_off + t * dm.v;
+      float* go = grad_off + bqs * dm.off_rs + m * dm.v;
       go[0] = dcx * g.rw / 8.0f;
       go[1] = dcy * g.rh / 8.0f;
       go[2] = g.w_on ? dw * g.rw / 8.0f : 0.0f;
@@ -738,7 +742,7 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
     }
     __syncthreads();  // G fully consumed; ga_s complete
     if (qok)
-      for (int e = sub; e < np; e += 8) grad_logits[t * np + e] = as[e] * inv * (ga_s[slot * PMAX + e] - dot);
+      for (int e = sub; e < np; e += 8) grad_logits[bqs * dm.lg_rs + m * np + e] = as[e] * inv * (ga_s[slot * PMAX + e] - dot);
 
     // ---- S3 / S4 (pass B): W[cell][q] = sum of attn * bilinear weight ---------------------------------------
     for (int i = tid; i < NC * WS / 4; i += kThreads) reinterpret_cast<float4*>(GW)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -858,7 +862,7 @@ box_bin_count_kernel(const long long* __restrict__ shapes, const long long* __re
   const int H = (int)shapes[li * 2], W = (int)shapes[li * 2 + 1];
   int wy0 = 0, wx0 = 0;
   const int winy = tqy + 2 * bt::R, winx = bt::TQX + 2 * bt::R;
-  const BoxGeo g = make_box(ref + bq * 7, off + (t * dm.l + li) * dm.v, dm.v);
+  const BoxGeo g = make_box(ref + bq * 7, off + bq * dm.off_rs + (m * dm.l + li) * dm.v, dm.v);
   if (outside_tile_window) {
     const int q = (int)(bq % dm.lq);
     wy0 = (q / W) / tqy * tqy - bt::R;
@@ -1116,7 +1120,7 @@ int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) 
   }
   EFG_CHECK_ARG((256 / lp) * l * p <= kSoftmaxLds, "box_attn_fused: (256/(d/4)) * L*P = %d exceeds the LDS scratch (%d)",
                 (256 / lp) * l * p, kSoftmaxLds);
-  *dm = BoxDims{b, s, h, d, l, lq, p, v, lp, sh};
+  *dm = BoxDims{b, s, h, d, l, lq, p, v, lp, sh, h * l * v, h * l * p};
   return EFG_OK;
 }
 
@@ -1125,12 +1129,29 @@ int check(int b, int s, int h, int d, int l, int lq, int p, int v, BoxDims* dm) 
 
 using namespace efg;
 
-extern "C" int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
-                                              const float* ref_windows, const float* offsets, const float* logits,
-                                              const float* kernel_indices, int b, int s, int h, int d, int l, int lq,
-                                              int p, int v, float* out, void* stream) {
+namespace {
+// row strides of the offsets / logits matrices (0: each is a dense matrix of its own)
+int set_strides(BoxDims* dm, int off_rs, int lg_rs) {
+  if (off_rs) {
+    EFG_CHECK_ARG(off_rs >= dm->h * dm->l * dm->v, "box_attn_fused: offsets row stride %d below the row width %d", off_rs, dm->h * dm->l * dm->v);
+    dm->off_rs = off_rs;
+  }
+  if (lg_rs) {
+    EFG_CHECK_ARG(lg_rs >= dm->h * dm->l * dm->p, "box_attn_fused: logits row stride %d below the row width %d", lg_rs, dm->h * dm->l * dm->p);
+    dm->lg_rs = lg_rs;
+  }
+  return EFG_OK;
+}
+}  // namespace
+
+extern "C" int efg_box_attn_fused_forward_strided_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                                      const float* ref_windows, const float* offsets, int off_row_stride,
+                                                      const float* logits, int logit_row_stride, const float* kernel_indices,
+                                                      int b, int s, int h, int d, int l, int lq, int p, int v, float* out,
+                                                      void* stream) {
   BoxDims dm;
   if (int rc = check(b, s, h, d, l, lq, p, v, &dm)) return rc;
+  if (int rc = set_strides(&dm, off_row_stride, logit_row_stride)) return rc;
   const long long total = (long long)b * lq * h;
   if (total == 0) return EFG_OK;
   const int pairs_per_block = 4 * (64 / dm.lp);
@@ -1141,19 +1162,28 @@ extern "C" int efg_box_attn_fused_forward_f32(const float* value, const int64_t*
   return EFG_OK;
 }
 
+extern "C" int efg_box_attn_fused_forward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                              const float* ref_windows, const float* offsets, const float* logits,
+                                              const float* kernel_indices, int b, int s, int h, int d, int l, int lq,
+                                              int p, int v, float* out, void* stream) {
+  return efg_box_attn_fused_forward_strided_f32(value, shapes, level_start, ref_windows, offsets, 0, logits, 0, kernel_indices, b, s, h,
+                                                d, l, lq, p, v, out, stream);
+}
+
 extern "C" size_t efg_box_attn_fused_backward_workspace_bytes(int b, int s, int h, int l, int lq, int p) {
   if (b < 0 || s < 0 || h < 1 || l < 1 || lq < 0 || p < 1) return 0;
   return bin_plan(b, s, h, l, lq, p).bytes;
 }
 
-extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
-                                               const float* ref_windows, const float* offsets, const float* logits,
-                                               const float* kernel_indices, const float* grad_out, int b, int s, int h,
-                                               int d, int l, int lq, int p, int v, float* grad_value,
-                                               float* grad_offsets, float* grad_logits, void* ws, size_t ws_bytes,
-                                               void* stream) {
+extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                                       const float* ref_windows, const float* offsets, int off_row_stride,
+                                                       const float* logits, int logit_row_stride, const float* kernel_indices,
+                                                       const float* grad_out, int b, int s, int h, int d, int l, int lq, int p,
+                                                       int v, float* grad_value, float* grad_offsets, float* grad_logits,
+                                                       void* ws, size_t ws_bytes, void* stream) {
   BoxDims dm;
   if (int rc = check(b, s, h, d, l, lq, p, v, &dm)) return rc;
+  if (int rc = set_strides(&dm, off_row_stride, logit_row_stride)) return rc;   // (the gradients have the strides of their matrices)
   EFG_CHECK_ARG(d == 32, "box_attn_fused backward: head dim 32 only (got %d); use the unfused op", d);
   const long long total = (long long)b * lq * h;
   if (total == 0) return EFG_OK;
@@ -1251,4 +1281,15 @@ extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t
   }
   EFG_LAUNCH_CHECK();
   return EFG_OK;
+}
+
+extern "C" int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                               const float* ref_windows, const float* offsets, const float* logits,
+                                               const float* kernel_indices, const float* grad_out, int b, int s, int h,
+                                               int d, int l, int lq, int p, int v, float* grad_value,
+                                               float* grad_offsets, float* grad_logits, void* ws, size_t ws_bytes,
+                                               void* stream) {
+  return efg_box_attn_fused_backward_strided_f32(value, shapes, level_start, ref_windows, offsets, 0, logits, 0, kernel_indices,
+                                                 grad_out, b, s, h, d, l, lq, p, v, grad_value, grad_offsets, grad_logits, ws,
+                                                 ws_bytes, stream);
 }

@@ -10,6 +10,8 @@ that kernel does not apply (head width != 32, per-level valid ratios, a gradient
 quantities are materialised with `box_sampling_grid` and handed to the plain sampling op (`BoxAttnFunction`,
 csrc/msda.hip), which is what the reference module does on every call.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -17,6 +19,10 @@ import torch.nn.functional as F
 from ..operators import BoxAttnFunction
 from ..operators import box_attention_func as _baf
 from ..operators.linear import Linear, linear
+
+
+# EFG_BOX_SHARED_PROJ=0: logits and offsets from two projections, as the reference module computes them (A/B)
+_SHARED_PROJECTION = os.environ.get("EFG_BOX_SHARED_PROJ", "1") != "0"
 
 
 def _lattice(k):
@@ -71,10 +77,21 @@ class Box3dAttention(nn.Module):
         if v_mask is not None:
             value = value.masked_fill(v_mask[..., None], 0.0)
         value = value.view(b, value.shape[1], self.num_head, self.head_dim)
-        logits = linear(query, self.linear_attn_weight, self.linear_attn_bias)   # [B, Lq, H * L * k*k]
-        offsets = linear(query, self.linear_box_weight, self.linear_box_bias)    # [B, Lq, H * L * V]
         fused = (v_valid_ratios is None and not ref_windows.requires_grad and
                  _baf.box_attn_fused_available(value, ref_windows, self.head_dim, self.num_level, self.num_point))
+        if fused and _SHARED_PROJECTION:
+            # ONE projection of the query for the attention logits and the box offsets (the two weight matrices stacked:
+            # two tiny copies), handed to the sampling kernel as two column ranges of one matrix: one product instead of
+            # two in the forward, one data-gradient and one weight-gradient product instead of two of each in the
+            # backward, and the two input gradients -- [B, Lq, 256] each, 72 MB on the encoder's 70 688 tokens -- are
+            # never added because they are never separate.  Parameters, names and values are the reference's.
+            lo = linear(query, torch.cat((self.linear_attn_weight, self.linear_box_weight), 0),
+                        torch.cat((self.linear_attn_bias, self.linear_box_bias), 0))   # [B, Lq, H*L*k*k + H*L*V]
+            sampled = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, lo, None,
+                                                      self.kernel_indices, self.num_variable)
+            return self.out_proj(sampled), None
+        logits = linear(query, self.linear_attn_weight, self.linear_attn_bias)   # [B, Lq, H * L * k*k]
+        offsets = linear(query, self.linear_box_weight, self.linear_box_bias)    # [B, Lq, H * L * V]
         if fused:
             sampled = _baf.BoxAttnFusedFunction.apply(value, v_shape, v_start_index, ref_windows, offsets, logits,
                                                       self.kernel_indices, self.num_variable)

@@ -146,18 +146,34 @@ class BoxAttnFusedFunction(Function):
 
     @staticmethod
     def forward(ctx, value, shapes, start, ref, offsets, logits, kidx, num_var):
-        L.require_gpu(value, ref, offsets, logits, kidx)
-        value, ref, offsets, logits, kidx = (t.float().contiguous() for t in (value, ref, offsets, logits, kidx))
+        """`logits` None: `offsets` is the output [B, Lq, H*L*P + H*L*V] of ONE projection (Box3dAttention concatenates
+        its two weight matrices), logits in the leading H*L*P columns, box offsets behind them; the kernels read and
+        write both through the shared row stride, and the backward returns ONE gradient matrix (one data-gradient
+        product and one weight-gradient product instead of two of each and an addition of their input gradients)."""
+        shared = logits is None
+        if shared:
+            L.require_gpu(value, ref, offsets, kidx)
+            value, ref, offsets, kidx = (t.float().contiguous() for t in (value, ref, offsets, kidx))
+        else:
+            L.require_gpu(value, ref, offsets, logits, kidx)
+            value, ref, offsets, logits, kidx = (t.float().contiguous() for t in (value, ref, offsets, logits, kidx))
         b, s, h, d = value.shape
         lq, l, p = ref.shape[1], shapes.size(0), kidx.shape[0]
+        n_lg = h * l * p
+        if shared and offsets.shape[-1] != n_lg + h * l * num_var:
+            raise ValueError("box_attn_fused: shared projection of width %d, expected %d logits + %d offsets" % (
+                offsets.shape[-1], n_lg, h * l * num_var))
         out = torch.empty((b, lq, h * d), dtype=torch.float32, device=value.device)
         cost = lambda: (4 * (b * s * h * d + b * lq * (7 + h * l * (num_var + p)) + b * lq * h * d),  # noqa: E731
                         10 * b * lq * h * l * p * d)
+        rs = offsets.shape[-1] if shared else 0
+        off_ptr = offsets.data_ptr() + 4 * n_lg if shared else L.ptr(offsets)
+        lg_ptr = offsets.data_ptr() if shared else L.ptr(logits)
         with _prof.timed("box_fwd_kernel", cost):
-            L.check(L.lib().efg_box_attn_fused_forward_f32(L.ptr(value), L.ptr(shapes.contiguous()),
-                                                           L.ptr(start.contiguous()), L.ptr(ref), L.ptr(offsets),
-                                                           L.ptr(logits), L.ptr(kidx), b, s, h, d, l, lq, p, num_var,
-                                                           L.ptr(out), L.stream()))
+            L.check(L.lib().efg_box_attn_fused_forward_strided_f32(L.ptr(value), L.ptr(shapes.contiguous()),
+                                                                   L.ptr(start.contiguous()), L.ptr(ref), off_ptr, rs,
+                                                                   lg_ptr, rs, L.ptr(kidx), b, s, h, d, l, lq, p, num_var,
+                                                                   L.ptr(out), L.stream()))
         ctx.save_for_backward(value, shapes, start, ref, offsets, logits, kidx)
         ctx.num_var = num_var
         return out
@@ -169,9 +185,16 @@ class BoxAttnFusedFunction(Function):
         grad_output = grad_output.contiguous()
         b, s, h, d = value.shape
         lq, l, p = ref.shape[1], shapes.size(0), kidx.shape[0]
+        shared = logits is None
+        n_lg = h * l * p
         grad_value = torch.zeros_like(value)
-        grad_off = torch.empty_like(offsets)
-        grad_logits = torch.empty_like(logits)
+        grad_off = torch.empty_like(offsets)     # (shared projection: the gradient of the whole [.., logits | offsets] matrix)
+        grad_logits = None if shared else torch.empty_like(logits)
+        rs = offsets.shape[-1] if shared else 0
+        off_ptr = offsets.data_ptr() + 4 * n_lg if shared else L.ptr(offsets)
+        lg_ptr = offsets.data_ptr() if shared else L.ptr(logits)
+        goff_ptr = grad_off.data_ptr() + 4 * n_lg if shared else L.ptr(grad_off)
+        glg_ptr = grad_off.data_ptr() if shared else L.ptr(grad_logits)
         cost = lambda: (4 * (2 * b * s * h * d + 2 * b * lq * (h * l * (ctx.num_var + p)) + 2 * b * lq * h * d),  # noqa: E731
                         30 * b * lq * h * l * p * d)
         grid = (l == 1 and s == lq and s >= 1024)
@@ -184,12 +207,11 @@ class BoxAttnFusedFunction(Function):
             ws_bytes = L.lib().efg_box_attn_fused_backward_workspace_bytes(b, s, h, l, lq, p)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
         with _prof.timed(name, cost):
-            L.check(L.lib().efg_box_attn_fused_backward_f32(L.ptr(value), L.ptr(shapes.contiguous()),
-                                                            L.ptr(start.contiguous()), L.ptr(ref), L.ptr(offsets),
-                                                            L.ptr(logits), L.ptr(kidx), L.ptr(grad_output), b, s, h,
-                                                            d, l, lq, p, ctx.num_var, L.ptr(grad_value),
-                                                            L.ptr(grad_off), L.ptr(grad_logits), L.ptr(ws), ws_bytes,
-                                                            L.stream()))
+            L.check(L.lib().efg_box_attn_fused_backward_strided_f32(L.ptr(value), L.ptr(shapes.contiguous()),
+                                                                    L.ptr(start.contiguous()), L.ptr(ref), off_ptr, rs,
+                                                                    lg_ptr, rs, L.ptr(kidx), L.ptr(grad_output), b, s, h,
+                                                                    d, l, lq, p, ctx.num_var, L.ptr(grad_value),
+                                                                    goff_ptr, glg_ptr, L.ptr(ws), ws_bytes, L.stream()))
         if ws is not None and _CHECK_BINS:
             # first word of the scratch: entries that did not fit the bin box_bin_count_kernel sized for them (a
             # disagreement between the counting and the writing kernel).  Must be 0; reading it is a sync, so only

@@ -314,6 +314,21 @@ int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, c
                                     int l, int lq, int p, int v, float* grad_value, float* grad_offsets,
                                     float* grad_logits, void* ws, size_t ws_bytes, void* stream);
 
+/* The same two calls with ROW STRIDES (floats; 0 = dense) for the offsets and logits matrices and their gradients:
+ * Box3dAttention computes both with ONE projection [b, lq, h*l*p + h*l*v] (reference $CQ/modules/box_attention.py:97-104
+ * runs two Linears on the same query) and hands the kernels the two column ranges of that matrix; grad_offsets /
+ * grad_logits are then the matching column ranges of one gradient matrix. */
+int efg_box_attn_fused_forward_strided_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                           const float* ref_windows, const float* offsets, int off_row_stride,
+                                           const float* logits, int logit_row_stride, const float* kernel_indices, int b,
+                                           int s, int h, int d, int l, int lq, int p, int v, float* out, void* stream);
+int efg_box_attn_fused_backward_strided_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                            const float* ref_windows, const float* offsets, int off_row_stride,
+                                            const float* logits, int logit_row_stride, const float* kernel_indices,
+                                            const float* grad_out, int b, int s, int h, int d, int l, int lq, int p, int v,
+                                            float* grad_value, float* grad_offsets, float* grad_logits, void* ws,
+                                            size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Rotated BEV overlap / IoU and NMS.  Replaces
  * efg::boxes_overlap_bev_gpu / boxes_iou_bev_gpu / nms_gpu / nms_normal_gpu
