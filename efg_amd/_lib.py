@@ -57,6 +57,7 @@ _SIGS = {
                                              c_int64, c_int, c_void_p, c_void_p]),
     "efg_spconv_tile_bf16x3_ok": (c_int, [c_int, c_int, c_int, c_int64, c_int64]),
     "efg_spconv_streamk_fallbacks": (c_int, [c_void_p, c_int]),
+    "efg_ticket_ring_errors": (c_int, [c_void_p, c_int]),
     "efg_spconv_parity_order": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "efg_spconv_wgrad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,

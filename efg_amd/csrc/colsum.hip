@@ -61,11 +61,21 @@ constexpr int kFusedBlocks = 128;   // row blocks up to which the final sum runs
 
 // Called by every thread of a block after its partial row is stored (by lanes of wave 0): true in the one block that has
 // to sum.  Release/acquire at agent scope: the partial rows were written through other XCDs' L2s.
+// A counter that was NOT at rest when its launch began (a launch that died half way through its tickets -- normally the
+// end of the HIP context, but nothing guarantees it) would make the wrong block sum, over rows that are not all written;
+// the symptom this can see -- a ticket beyond the launch's block count -- is counted here and reported by
+// efg_ticket_ring_errors (the trainer's periodic anomaly check reads it), and the slot is put back to rest.
+__device__ unsigned g_ticket_errors;
+
 __device__ __forceinline__ bool draw_last_ticket(unsigned* counter, unsigned nblocks) {
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev >= nblocks) {
+      atomicAdd(&g_ticket_errors, 1u);
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     s_last = prev == nblocks - 1;
     if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for its next call
   }
@@ -357,6 +367,18 @@ extern "C" int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t r
   } else if (p.nblocks > 1) {
     hipLaunchKernelGGL(colsum_final_kernel<4>, dim3((unsigned)ceil_div(cols, 64)), dim3(256), 0, st, partial, p.nblocks, cols, out);
     EFG_LAUNCH_CHECK();
+  }
+  return EFG_OK;
+}
+
+extern "C" int efg_ticket_ring_errors(int64_t* count_out, int reset) {
+  EFG_CHECK_ARG(count_out != nullptr, "ticket_ring_errors: null output");
+  unsigned v = 0;
+  EFG_HIP_TRY(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ticket_errors), sizeof(v)));   // (synchronises)
+  *count_out = v;
+  if (reset && v) {
+    const unsigned zero = 0;
+    EFG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ticket_errors), &zero, sizeof(zero)));
   }
   return EFG_OK;
 }

@@ -144,12 +144,7 @@ extern "C" int efg_topk_unsorted_f32(const float* x, int64_t rows, int n, int k,
   if (rows == 0) return EFG_OK;
   constexpr int kStagedMax = 36864;   // 144 KB of keys beside the histogram
   if (n <= kStagedMax) {
-    static bool raised = false;   // (dynamic LDS above 64 KB has to be asked for once per kernel)
-    if (!raised) {
-      EFG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kStagedMax * 4));
-      raised = true;
-    }
+    EFG_ALLOW_DYNAMIC_LDS(topk_kernel<true>, kStagedMax * 4);   // (once per device; common.h)
     hipLaunchKernelGGL(topk_kernel<true>, dim3((unsigned)rows), dim3(1024), (size_t)n * 4, (hipStream_t)stream, x, n, k, values,
                        reinterpret_cast<long long*>(indices));
   } else {

@@ -107,6 +107,16 @@ def limit_host_threads():
     return n
 
 
+def _weights_written_behind_autograd():
+    """Weights were just written through `.data` (the parameter broadcast of an exchange object or of torch DDP's
+    constructor, a checkpoint load): neither `Parameter._version` nor the optimizer's post-step hook has moved, so the
+    packed MFMA copies the sparse convolutions cache per parameter must be dropped by hand (spconv.weights_updated) --
+    otherwise forward / dgrad keep multiplying the copy of the OLD weights while wgrad reads the live ones."""
+    from . import spconv
+
+    spconv.weights_updated()
+
+
 class FlatGradientAllReduce:
     """The data-parallel exchange step: ONE all-reduce (mean) of all gradients after backward.
 
@@ -140,6 +150,7 @@ class FlatGradientAllReduce:
             except (AttributeError, RuntimeError):
                 for t in tensors:
                     dist.broadcast(t, 0)
+        _weights_written_behind_autograd()
 
     @torch.no_grad()
     def reduce(self):
@@ -474,6 +485,7 @@ class Trainer:
                     self.model, device_ids=dev_ids, broadcast_buffers=False,
                     bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),
                     gradient_as_bucket_view=os.environ.get("EFG_DDP_BUCKET_VIEW", "1") == "1", **kw)
+                _weights_written_behind_autograd()   # (its constructor broadcasts rank 0's parameters through .data)
 
     def _collect_garbage(self):
         """Python's cyclic collector runs a few hundred times per step on the containers autograd creates and
@@ -520,6 +532,16 @@ class Trainer:
             from .operators.assignment import take_failures
 
             lsap_bad = take_failures(self.model.device)
+            import ctypes
+
+            from . import _lib
+
+            ring = ctypes.c_int64(0)
+            _lib.check(_lib.lib().efg_ticket_ring_errors(ctypes.byref(ring), 1))
+            if ring.value:
+                raise RuntimeError("efg_amd: %d ticket counters of the fused column / focal sums were found not at rest at or "
+                                   "before iteration=%d: bias gradients or loss sums since then are unreliable" % (
+                                       ring.value, self._steps))
         flag, self._nonfinite = self._nonfinite, None
         if flag is not None and not bool(torch.isfinite(flag)):
             raise FloatingPointError("Loss became infinite or NaN at or before iteration=%d!" % self._steps)
@@ -566,6 +588,12 @@ class Trainer:
                 self.grad_sync.reduce()
                 if getattr(self.grad_sync, "found_inf", None) is not None and hasattr(self.optimizer, "_plan"):
                     self.optimizer.found_inf = self.grad_sync.found_inf
+            elif (self.wrapped is not self.model and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                  and getattr(self.optimizer, "found_inf", None) is not None and hasattr(self.optimizer, "_plan")):
+                # torch-DDP modes (static / find_unused / plain): the gradients were averaged inside backward, the flag
+                # was not -- one 1-element MAX so that every rank skips the update or none does (a rank that skipped alone
+                # would leave its replica behind the others for good)
+                dist.all_reduce(self.optimizer.found_inf, op=dist.ReduceOp.MAX)
         with record_function("efg::optimizer"):
             if self.grad_clipper is not None:  # hooks.py:74-79 (disabled in the ConQueR / Voxel-DETR configs)
                 params = [p for p in self.model.parameters() if p.grad is not None]

@@ -314,6 +314,11 @@ int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, c
                                     int l, int lq, int p, int v, float* grad_value, float* grad_offsets,
                                     float* grad_logits, void* ws, size_t ws_bytes, void* stream);
 
+/* Column sums / split focal sums end inside their partial kernel: the block that draws the last ticket of a self-resetting
+ * counter sums the partial rows.  A counter found beyond its launch's block count (a slot that was not at rest) is counted
+ * on the device; this reads (and optionally clears) the count of the current device.  0 in a healthy process. */
+int efg_ticket_ring_errors(int64_t* count_out, int reset);
+
 /* The same two calls with ROW STRIDES (floats; 0 = dense) for the offsets and logits matrices and their gradients:
  * Box3dAttention computes both with ONE projection [b, lq, h*l*p + h*l*v] (reference $CQ/modules/box_attention.py:97-104
  * runs two Linears on the same query) and hands the kernels the two column ranges of that matrix; grad_offsets /
