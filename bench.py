@@ -49,6 +49,9 @@ def parse():
                          "`yaml_config` object times that)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra, untimed steps with per-kernel HIP events")
+    ap.add_argument("--soak-steps", type=int, default=0,
+                    help="N > 0: after the timed run, N more optimizer steps on a 4-batch pool, then the step timed again -> the "
+                         "line's `steady_state` object (the encoder's boxes grow as training proceeds; 0 keeps the default run short)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-arm", action="store_true", help="skip the third timing (bf16x3 split-precision A/B arm)")
     ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")
@@ -494,6 +497,35 @@ def main():
         finally:
             _lin._ARM_BF16X3 = False
     trainer.close()
+    # ---- the step after N optimizer steps of a COMPLETE schedule (profiles/r05_soak.txt: what sustained training runs at) ----------
+    # A fresh model's encoder boxes fit the box-attention backward's query-tile window; trained ones partly do not (those
+    # corners take the binned path).  The timed trainer above is at the start of the config's long schedule, where nothing
+    # moves yet: this one gets a one-cycle schedule of exactly N + steps iterations (as scripts/ubench/soak.py does), so the
+    # weights move as far in N steps as they do over a training run.
+    if args.soak_steps > 0 and world == 1:
+        del trainer
+        torch.cuda.empty_cache()
+        soak_tr = Trainer(config=config, device=dev, overrides=overrides, seed=0, max_iters=args.soak_steps + args.steps + 10)
+        soak_pool = pool + [synthetic_batch(2000 + 100 * p, args.scenes, n_points=args.points, device=dev, n_sweeps=args.sweeps,
+                                            clutter=0.55 if args.dense else 0.0) for p in range(len(pool), 4)]
+        saved_pool = list(pool)
+        pool[:] = soak_pool
+        try:
+            e0 = timed_run(soak_tr, args.steps, args.warmup)
+            for i in range(args.soak_steps):
+                soak_tr.step(soak_pool[i % len(soak_pool)])
+            e5 = timed_run(soak_tr, args.steps, 0)
+        finally:
+            pool[:] = saved_pool
+        soak_tr.close()
+        del soak_tr
+        line["steady_state"] = {"ms_per_step": 1000.0 * e5 / args.steps, "value": args.scenes * args.steps / e5, "unit": "scenes/s",
+                                "steps": args.steps, "after_optimizer_steps": args.soak_steps + args.steps + args.warmup,
+                                "same_trainer_fresh_ms_per_step": 1000.0 * e0 / args.steps,
+                                "host_issue_ms_per_step": round(stats["host_issue_ms_per_step"], 3),
+                                "note": "a second trainer on a one-cycle schedule of exactly that many iterations and a pool of 4 "
+                                        "synthetic batches: timed fresh, run --soak-steps optimizer steps, timed again"}
+        trainer = None
     # ---- the same step with the reference's dead branches evaluated ----------------------------------
     if not args.no_full_graph and not args.full_graph and world == 1:
         del trainer
