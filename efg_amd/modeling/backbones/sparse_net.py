@@ -86,6 +86,56 @@ class SparseBasicResBlock(spconv.SparseModule):
         return out.replace_feature(self.activation(out.features))
 
 
+class SparseBottleneckBlock(spconv.SparseModule):
+    """1x1x1 SubM -> 3x3x3 (SubM, or strided SparseConv3d in a stage's first block) -> 1x1x1 SubM, each + norm, with the
+    identity / strided 3x3x3-conv shortcut of the basic block (reference :168-237; depth 50 of
+    build_sparse_resnet_backbone :388).  Same module tree -- `shortcut.{0,1}`, `conv.{0..7}` -- so its state dicts load.
+
+    One deliberate difference: the reference sizes the LAST norm with `bottleneck_channels` (:214) although it
+    normalises the `out_channels`-wide output of the second 1x1x1 convolution, which only runs when the two widths are
+    equal; here it is sized with `out_channels` (identical parameters in the case that runs, a working block otherwise).
+    The 1x1x1 convolutions share the block's `indice_key` with the 3x3x3 one as in the reference; efg_amd.spconv keys its
+    rulebook cache by (key, kernel size), so they never see each other's tables."""
+
+    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1, norm="BN1d", activation=None, indice_key=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        if in_channels != out_channels:
+            self.shortcut = spconv.SparseSequential(
+                SparseConv3d(in_channels, out_channels, 3, padding=1, stride=stride, bias=False),
+                common.get_norm(norm, out_channels),
+            )
+        else:
+            self.shortcut = None
+        self.activation = common.get_activation(activation)
+        mid = (SubMConv3d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=1, padding=1, bias=False,
+                          indice_key=indice_key) if stride == 1 else
+               SparseConv3d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride, padding=1, bias=False))
+        self.conv = spconv.SparseSequential(
+            SubMConv3d(in_channels, bottleneck_channels, kernel_size=1, stride=1, bias=False, indice_key=indice_key),
+            common.get_norm(norm, bottleneck_channels),
+            common.get_activation(activation),
+            mid,
+            common.get_norm(norm, bottleneck_channels),
+            common.get_activation(activation),
+            SubMConv3d(bottleneck_channels, out_channels, kernel_size=1, bias=False, indice_key=indice_key),
+            common.get_norm(norm, out_channels),
+        )
+
+    def forward(self, x):
+        mods = [m for m in self.conv._modules.values() if m is not None]
+        last = mods[-1]
+        if type(self.activation) is nn.ReLU and isinstance(last, nn.BatchNorm1d):
+            # relu(bn3(conv3(.)) + shortcut) as one fused op (operators/batchnorm.py), as in the basic block
+            out = spconv.run_modules(mods[:-1], x)
+            shortcut = self.shortcut(x) if self.shortcut is not None else x
+            return out.replace_feature(bn_act(out.features, last, relu=True, residual=shortcut.features))
+        out = self.conv(x)
+        shortcut = self.shortcut(x) if self.shortcut is not None else x
+        out = out.replace_feature(out.features + shortcut.features)
+        return out.replace_feature(self.activation(out.features))
+
+
 def make_stage(block_class, num_blocks, first_stride, **kwargs):
     blocks = []
     for i in range(num_blocks):
@@ -170,10 +220,10 @@ def _get(cfg, key):
 
 
 def build_sparse_resnet_backbone(config, in_channels):
-    """res18 / res34 plans of efg/modeling/backbones/sparse_net.py:318-397 (basic blocks only: the
-    bottleneck variant (depth 50) is not used by any detection.3d config)."""
+    """res18 / res34 (basic blocks) and res50 (bottleneck blocks of num_groups * width_per_group channels, doubling
+    per stage) plans of efg/modeling/backbones/sparse_net.py:318-397."""
     depth = _get(config, "depth")
-    stem_width = {18: 16, "18b": 24, "18c": 32, 34: 16, "34b": 24, "34c": 32}[depth]
+    stem_width = {18: 16, "18b": 24, "18c": 32, 34: 16, "34b": 24, "34c": 32, 50: 16}[depth]
     norm, activation = _get(config, "norm"), _get(config, "activation")
     stem = SparseBasicStem(in_channels=in_channels, out_channels=_get(config, "stem_out_channels"), norm=norm,
                            activation=activation, stem_width=stem_width, indice_key="stem")
@@ -181,13 +231,21 @@ def build_sparse_resnet_backbone(config, in_channels):
     in_channels = _get(config, "stem_out_channels")
     out_channels = _get(config, "res1_out_channels")
     num_blocks_per_stage = {18: [2, 2, 2, 2], "18b": [2, 2, 2, 2], "18c": [2, 2, 2, 2], 34: [3, 4, 6, 3],
-                            "34b": [3, 4, 6, 3], "34c": [3, 4, 6, 3]}[depth]
+                            "34b": [3, 4, 6, 3], "34c": [3, 4, 6, 3], 50: [3, 4, 6, 3]}[depth]
+    bottleneck = depth == 50   # (:380-387: basic blocks for 18 / 34, bottleneck blocks otherwise)
+    bottleneck_channels = _get(config, "num_groups") * _get(config, "width_per_group") if bottleneck else None
     max_stage_idx = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
     stages = []
     for idx, stage_idx in enumerate(range(2, max_stage_idx + 1)):
-        blocks = make_stage(SparseBasicResBlock, num_blocks_per_stage[idx], 2, in_channels=in_channels,
-                            out_channels=out_channels, norm=norm, activation=activation,
-                            indice_key="res" + str(stage_idx))
+        if bottleneck:
+            blocks = make_stage(SparseBottleneckBlock, num_blocks_per_stage[idx], 2, in_channels=in_channels,
+                                out_channels=out_channels, bottleneck_channels=bottleneck_channels, norm=norm,
+                                activation=activation, indice_key="res" + str(stage_idx))
+            bottleneck_channels *= 2
+        else:
+            blocks = make_stage(SparseBasicResBlock, num_blocks_per_stage[idx], 2, in_channels=in_channels,
+                                out_channels=out_channels, norm=norm, activation=activation,
+                                indice_key="res" + str(stage_idx))
         in_channels = out_channels
         out_channels *= 2
         stages.append(blocks)

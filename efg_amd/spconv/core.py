@@ -788,7 +788,10 @@ class SparseConvolution(SparseModule):
         ks, st = self.kernel_size, self.stride
         if self.subm:
             pad = tuple(k // 2 for k in ks)  # SubM ignores `padding`: the window is always centred
-            key = ("subm", self.indice_key, ks) if self.indice_key is not None else None
+            # (the spatial shape is part of the key: a strided convolution hands its input's dict on to its output, and a
+            # block that reuses one indice_key on both sides of it -- the reference's strided bottleneck block does,
+            # sparse_net.py:198-213 -- must not pick up the table of the other resolution)
+            key = ("subm", self.indice_key, ks, tuple(int(v) for v in x.spatial_shape)) if self.indice_key is not None else None
             if key is not None and key in x.indice_dict:
                 return x.indice_dict[key], None
             m = x.indices.shape[0]

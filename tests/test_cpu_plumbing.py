@@ -131,3 +131,26 @@ def test_config0_centerpoint_train_step_on_cpu(oracle_mod):
     assert float(loss_dict["0_num_positive"]) == 6.0
     assert all(p.grad is not None for p in tr.model.parameters())            # find_unused_parameters: False holds
     tr.close()
+
+
+def test_res50_backbone_has_the_reference_module_tree():
+    """depth 50 = bottleneck blocks (reference sparse_net.py:168-237, :380-388): [3, 4, 6, 3] blocks per stage, each
+    `conv.{0,3,6}` = 1x1x1 / 3x3x3 / 1x1x1 convolutions with norms at `conv.{1,4,7}`, `shortcut.{0,1}` where the width
+    changes, bottleneck width doubling per stage -- the parameter names and shapes a reference state dict carries."""
+    from efg_amd.modeling.backbones.sparse_net import SparseBottleneckBlock, build_sparse_resnet_backbone
+
+    cfg = dict(depth=50, norm="BN1d", activation=dict(type="ReLU", inplace=True), stem_out_channels=32,
+               out_features=["res3", "res4"], num_groups=1, width_per_group=16, res1_out_channels=64)
+    net = build_sparse_resnet_backbone(cfg, 5)
+    sd = net.state_dict()
+    assert [len(getattr(net, "res%d" % s)) for s in (2, 3, 4)] == [3, 4, 6]
+    assert all(isinstance(b, SparseBottleneckBlock) for s in (2, 3, 4) for b in getattr(net, "res%d" % s))
+    # spconv weight layout [cout, kd, kh, kw, cin]; bottleneck widths 16 / 32 / 64, stage widths 64 / 128 / 256
+    assert tuple(sd["res2.0.conv.0.weight"].shape) == (16, 1, 1, 1, 32)
+    assert tuple(sd["res2.0.conv.3.weight"].shape) == (16, 3, 3, 3, 16)
+    assert tuple(sd["res2.0.conv.6.weight"].shape) == (64, 1, 1, 1, 16)
+    assert tuple(sd["res2.0.conv.7.weight"].shape) == (64,)
+    assert tuple(sd["res2.0.shortcut.0.weight"].shape) == (64, 3, 3, 3, 32)
+    assert "res2.1.shortcut.0.weight" not in sd
+    assert tuple(sd["res4.0.conv.3.weight"].shape) == (64, 3, 3, 3, 64)
+    assert net.res3[0].stride == 2 and net.res3[1].stride == 1

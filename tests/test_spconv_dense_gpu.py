@@ -164,3 +164,70 @@ def test_16_byte_gather_variant_equals_dense(dev, monkeypatch):
     for geom in ("res18 subm k3", "res18 stem/stage conv k3 s2 p1", "centerpoint conv4 k3 s2 p(0,1,1)"):
         for cin, cout in ((16, 32), (64, 64), (64, 128), (256, 256), (20, 36)):
             test_sparse_conv_equals_fp64_dense_conv3d(dev, geom, cin, cout)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bottleneck_block_equals_dense(dev, stride):
+    """The depth-50 block (1x1x1 SubM -> 3x3x3 -> 1x1x1 SubM + the basic block's shortcut; reference
+    sparse_net.py:168-237) against the same block built from dense fp64 conv3d, forward and input gradient."""
+    import efg_amd.spconv as spconv
+    from efg_amd.modeling.backbones.sparse_net import SparseBottleneckBlock
+
+    rng = np.random.default_rng(5 + stride)
+    batch, shape, cin, mid = 2, (9, 18, 20), 64, 32
+    cout = 64 if stride == 1 else 128
+    idx, feat = _random_sparse(rng, batch, shape, 1500, cin)
+    blk = SparseBottleneckBlock(cin, cout, mid, stride=stride, norm="BN1d", activation=dict(type="ReLU", inplace=True),
+                                indice_key="res2").to(dev)
+    blk.train()
+    fx = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    x = spconv.SparseConvTensor(fx, torch.from_numpy(idx).to(dev), list(shape), batch)
+    y = blk(x)
+    i = torch.from_numpy(idx).long()
+    xd = torch.zeros(batch, cin, *shape, dtype=torch.float64)
+    xd[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]] = torch.from_numpy(feat).double()
+    xd.requires_grad_(True)
+    occ = torch.zeros(batch, 1, *shape, dtype=torch.float64)
+    occ[i[:, 0], 0, i[:, 1], i[:, 2], i[:, 3]] = 1
+    act_in = occ[:, 0] > 0
+    act_out = (F.conv3d(occ, torch.ones(1, 1, 3, 3, 3, dtype=torch.float64), None, 2, 1) > 0)[:, 0] if stride == 2 else act_in
+    # rows of a submanifold layer keep the INPUT order; a strided layer's output sites are in canonical (sorted) order
+    sites_in = i
+    sites_out = i if stride == 1 else torch.nonzero(act_out)
+
+    def w_of(conv):
+        return conv.weight.detach().double().cpu().permute(0, 4, 1, 2, 3)
+
+    def bn_rows(rows, bn):
+        m, v = rows.mean(0), rows.var(0, unbiased=False)
+        return (rows - m) / torch.sqrt(v + bn.eps) * bn.weight.detach().double().cpu() + bn.bias.detach().double().cpu()
+
+    def rows_of(d, sites):
+        return d[sites[:, 0], :, sites[:, 1], sites[:, 2], sites[:, 3]]
+
+    def dense_of(rows, sites, spatial):
+        out = torch.zeros(batch, rows.shape[1], *spatial, dtype=torch.float64)
+        out[sites[:, 0], :, sites[:, 1], sites[:, 2], sites[:, 3]] = rows
+        return out
+
+    convs = [m for m in blk.conv._modules.values() if isinstance(m, spconv.SparseModule)]
+    bns = [m for m in blk.conv._modules.values() if isinstance(m, torch.nn.BatchNorm1d)]
+    h = F.conv3d(xd, w_of(convs[0]), None, 1, 0)                           # 1x1x1 on the input sites
+    r = torch.relu(bn_rows(rows_of(h, sites_in), bns[0]))
+    h = F.conv3d(dense_of(r, sites_in, shape), w_of(convs[1]), None, stride, 1)
+    out_spatial = tuple(h.shape[2:])
+    r = torch.relu(bn_rows(rows_of(h, sites_out), bns[1]))
+    h = F.conv3d(dense_of(r, sites_out, out_spatial), w_of(convs[2]), None, 1, 0)
+    r = bn_rows(rows_of(h, sites_out), bns[2])
+    if blk.shortcut is not None:
+        s = F.conv3d(xd, w_of(blk.shortcut[0]), None, stride, 1)
+        rs = bn_rows(rows_of(s, sites_out), blk.shortcut[1])
+    else:
+        rs = rows_of(xd, sites_out)
+    want = torch.relu(r + rs)
+    assert np.array_equal(y.indices.cpu().numpy(), sites_out.numpy().astype(np.int32))
+    _close("bottleneck block", y.features.detach().cpu().numpy(), want.detach().numpy(), rel=1e-4)
+    go = torch.from_numpy(rng.standard_normal(tuple(want.shape)).astype(np.float32))
+    y.features.backward(go.to(dev))
+    want.backward(go.double())
+    _close("bottleneck block input gradient", fx.grad.cpu().numpy(), rows_of(xd.grad, sites_in).numpy(), rel=2e-4)

@@ -61,7 +61,7 @@ def test_subm_conv_vs_oracle(dev, oracle_mod, cin, cout, bias):
     w = conv.weight.detach().cpu().numpy().reshape(cout, 27, cin)
     b = conv.bias.detach().cpu().numpy() if bias else None
     nbr = oracle_mod.spconv_rulebook(idx, idx, batch, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-    assert np.array_equal(x.indice_dict[("subm", "k", (3, 3, 3))].nbr.cpu().numpy(), nbr)
+    assert np.array_equal(x.indice_dict[("subm", "k", (3, 3, 3), tuple(shape))].nbr.cpu().numpy(), nbr)
     ref = oracle_mod.spconv_forward(feat, w, b, nbr)
     np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
     go = rng.standard_normal(ref.shape).astype(np.float32)
