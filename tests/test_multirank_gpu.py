@@ -99,6 +99,8 @@ def test_two_rank_gradients_and_parameters_agree(dev):
     assert res["flat"][0] == "FlatGradientAllReduce" and res["bucket"][0] == "BucketedGradientAllReduce"
     # the same averaged gradient either way.  Two separate 3-step runs: since round 4 no kernel of the step accumulates
     # in arrival order (coloured box-attention tiles, exact-integer bin sums, index-ordered top-k), so the two exchanges --
-    # which add the same two addends per element -- agree to the last printed digit
-    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=2e-3)
+    # which add the same two addends per element -- agree far below the 2e-3 this test used to allow.  Not bit-exact: at
+    # the worker's reduced shapes (60 queries) the GEMM library picks atomic split-K solutions for the skinny class-head
+    # weight gradients, whose sums depend on arrival order (scripts/ubench/determinism_probe.py --small)
+    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=2e-5)
     assert res["bucket"][2] == pytest.approx(res["flat"][2], rel=1e-4)
