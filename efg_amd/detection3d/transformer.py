@@ -17,6 +17,7 @@ from ..operators.layernorm import add_layer_norm
 from ..operators.linear import Linear, linear, self_attention_in_proj
 from .box_attention import Box3dAttention
 from .losses import PaddedTargets
+from . import encoder_layer as _encoder_layer
 from .utils import MLP, flatten_with_shape, get_clones, inverse_sigmoid
 
 
@@ -41,6 +42,10 @@ class TransformerEncoderLayer(nn.Module):
         self.activation = F.relu
 
     def forward(self, src, pos, src_shape, src_start_idx, ref_windows):
+        if _encoder_layer.usable(self, src, pos, ref_windows):
+            # each half as one autograd node: the same forward kernels, the input gradients of its projections accumulated
+            # by their GEMMs instead of by addition kernels (detection3d/encoder_layer.py; EFG_FUSED_ENCODER=0: this form)
+            return _encoder_layer.forward(self, src, pos, src_shape, src_start_idx, ref_windows)
         src2 = self.self_attn(_with_pos(src, pos), src, src_shape, None, src_start_idx, None, ref_windows)[0]
         src = add_layer_norm(src, self.dropout1(src2), self.norm1)
         hidden = linear(src, self.linear1.weight, self.linear1.bias, relu=True)  # activation(linear1(src))
