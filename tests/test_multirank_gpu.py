@@ -99,8 +99,9 @@ def test_two_rank_gradients_and_parameters_agree(dev):
     assert res["flat"][0] == "FlatGradientAllReduce" and res["bucket"][0] == "BucketedGradientAllReduce"
     # the same averaged gradient either way.  Two separate 3-step runs: since round 4 no kernel of the step accumulates
     # in arrival order (coloured box-attention tiles, exact-integer bin sums, index-ordered top-k), so the two exchanges --
-    # which add the same two addends per element -- agree far below the 2e-3 this test used to allow.  Not bit-exact: at
-    # the worker's reduced shapes (60 queries) the GEMM library picks atomic split-K solutions for the skinny class-head
-    # weight gradients, whose sums depend on arrival order (scripts/ubench/determinism_probe.py --small)
-    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=2e-5)
+    # which add the same two addends per element -- would agree to the last digit if the two runs' gradients did.  They do
+    # not at the worker's reduced shapes (60 queries): the GEMM library picks atomic split-K solutions for the skinny
+    # class-head weight gradients there, whose sums depend on arrival order (scripts/ubench/determinism_probe.py --small;
+    # DESIGN.md §10); two runs of the SAME exchange differ by a few 1e-4 of the norm after 3 steps (measured 3.1e-4)
+    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=1e-3)
     assert res["bucket"][2] == pytest.approx(res["flat"][2], rel=1e-4)
