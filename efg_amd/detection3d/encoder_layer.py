@@ -17,38 +17,12 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .._fuse import Ctx as _Ctx, pack as _pack, unpack as _unpack
 from ..operators import box_attention_func as _baf
 from ..operators import linear as _lin
 from ..operators.layernorm import AddLayerNormFunction
 
 _ENABLED = os.environ.get("EFG_FUSED_ENCODER", "1") != "0"
-
-
-class _Ctx:
-    """Stand-in for an autograd context: lets the static forward / backward of the existing Functions be called as plain
-    functions (they only use save_for_backward / saved_tensors / attributes / needs_input_grad)."""
-
-    def __init__(self, n_inputs=16):
-        self.saved_tensors = ()
-        self.needs_input_grad = (True,) * n_inputs
-
-    def save_for_backward(self, *tensors):
-        self.saved_tensors = tensors
-
-
-def _pack(ctx, sub, prefix):
-    """Move a stand-in context's tensors onto the real context's save list (autograd must own saved tensors)."""
-    tensors = list(sub.saved_tensors)
-    attrs = {k: v for k, v in sub.__dict__.items() if k not in ("saved_tensors", "needs_input_grad")}
-    setattr(ctx, prefix + "_attrs", attrs)
-    return tensors
-
-
-def _unpack(ctx, tensors, prefix):
-    sub = _Ctx()
-    sub.saved_tensors = tuple(tensors)
-    sub.__dict__.update(getattr(ctx, prefix + "_attrs"))
-    return sub
 
 
 class EncoderAttentionHalf(Function):

@@ -77,8 +77,13 @@ class SparseBasicResBlock(spconv.SparseModule):
         last = mods[-1]
         if type(self.activation) is nn.ReLU and isinstance(last, nn.BatchNorm1d):
             # relu(bn2(conv2(.)) + shortcut) as one fused op (operators/batchnorm.py) when the features are on the GPU
-            out = spconv.run_modules(mods[:-1], x)
             shortcut = self.shortcut(x) if self.shortcut is not None else x
+            pre = spconv.run_modules(mods[:-2], x)
+            # last convolution + norm + residual + ReLU as one autograd node where that applies (spconv.conv_bn_act)
+            fused = spconv.conv_bn_act(mods[-2], pre, last, relu=True, residual=shortcut.features)
+            if fused is not None:
+                return fused
+            out = spconv.run_modules(mods[-2:-1], pre)
             return out.replace_feature(bn_act(out.features, last, relu=True, residual=shortcut.features))
         out = self.conv(x)
         shortcut = self.shortcut(x) if self.shortcut is not None else x
@@ -127,8 +132,13 @@ class SparseBottleneckBlock(spconv.SparseModule):
         last = mods[-1]
         if type(self.activation) is nn.ReLU and isinstance(last, nn.BatchNorm1d):
             # relu(bn3(conv3(.)) + shortcut) as one fused op (operators/batchnorm.py), as in the basic block
-            out = spconv.run_modules(mods[:-1], x)
             shortcut = self.shortcut(x) if self.shortcut is not None else x
+            pre = spconv.run_modules(mods[:-2], x)
+            # last convolution + norm + residual + ReLU as one autograd node where that applies (spconv.conv_bn_act)
+            fused = spconv.conv_bn_act(mods[-2], pre, last, relu=True, residual=shortcut.features)
+            if fused is not None:
+                return fused
+            out = spconv.run_modules(mods[-2:-1], pre)
             return out.replace_feature(bn_act(out.features, last, relu=True, residual=shortcut.features))
         out = self.conv(x)
         shortcut = self.shortcut(x) if self.shortcut is not None else x

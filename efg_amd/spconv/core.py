@@ -659,6 +659,67 @@ class _SparseConvFunction(Function):
         return grad_in, grad_w, grad_b, None, None
 
 
+class _ConvBnActFunction(Function):
+    """relu?(bn(conv(features)) + residual?) as ONE autograd node (efg_amd/_fuse.py): the convolution and the fused
+    BatchNorm of operators/batchnorm.py run back to back in every layer of the sparse backbones (sparse_net.py:85-95,
+    120-165); as two nodes they cost the host two Function applications per direction and layer (40 of the step's ~250)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, rb, grad_on, residual, gamma, beta, running_mean, running_var, num_batches_tracked,
+                momentum, eps, relu):
+        from .._fuse import Ctx, pack
+        from ..operators.batchnorm import BatchNormActFunction
+
+        conv = Ctx()
+        conv.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, False, False)
+        out = _SparseConvFunction.forward(conv, features, weight, None, rb, grad_on)
+        bn = Ctx()
+        y = BatchNormActFunction.forward(bn, out, residual, gamma, beta, running_mean, running_var, num_batches_tracked,
+                                         momentum, eps, relu)
+        conv_t, bn_t = pack(ctx, conv, "conv"), pack(ctx, bn, "bn")
+        ctx.n_conv = len(conv_t)
+        ctx.save_for_backward(*conv_t, *bn_t)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches_tracked) if t is not None])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        from .._fuse import unpack
+        from ..operators.batchnorm import BatchNormActFunction
+
+        saved = ctx.saved_tensors
+        bn = unpack(ctx, saved[ctx.n_conv:], "bn")
+        dx, dres, dgamma, dbeta = BatchNormActFunction.backward(bn, dy)[:4]
+        conv = unpack(ctx, saved[:ctx.n_conv], "conv", (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, False, False))
+        grad_in, grad_w = _SparseConvFunction.backward(conv, dx)[:2]
+        return grad_in, grad_w, None, None, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+_CONV_BN_FUSED = os.environ.get("EFG_FUSED_CONV_BN", "1") != "0"
+
+
+def conv_bn_act(conv, x, bn, relu=False, residual=None):
+    """relu?(bn(conv(x)) + residual?) -> SparseConvTensor, or None when the single-node form does not apply (the caller
+    then runs the modules one by one): a bias-free SparseConvolution followed by a BatchNorm1d the fused kernels take, GPU."""
+    c = conv.out_channels if isinstance(conv, SparseConvolution) else 0
+    # (the conditions of operators/batchnorm.py:fusable, on the convolution's output shape)
+    if not (_CONV_BN_FUSED and isinstance(conv, SparseConvolution) and conv.bias is None and x.features.is_cuda
+            and x.features.dtype == torch.float32 and x.indices.shape[0] != 0 and isinstance(bn, nn.BatchNorm1d)
+            and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and c % 4 == 0
+            and c <= 1024 and bn.num_features == c and os.environ.get("EFG_FUSED_BN", "1") != "0"):
+        return None
+    rb, geom = conv._rulebook(x)
+    if rb.m_out < 2:
+        return None
+    feats = _ConvBnActFunction.apply(x.features, conv.weight, rb, torch.is_grad_enabled(), residual, bn.weight, bn.bias,
+                                     bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, relu)
+    if conv.subm:
+        return x.replace_feature(feats)
+    out_indices, site_index, out_shape = geom
+    return SparseConvTensor(feats, out_indices, out_shape, x.batch_size, indice_dict=x.indice_dict, _site_index=site_index)
+
+
 def _downsample_geometry(x, ks, st, pad):
     """Output sites of a strided SparseConv3d over x: (out_indices [m_out,4] canonical order, SiteIndex, shape)."""
     lib = L.lib()
@@ -712,6 +773,15 @@ def run_modules(modules, input):
     i = 0
     while i < len(modules):
         module = modules[i]
+        if (isinstance(module, SparseConvolution) and isinstance(input, SparseConvTensor) and i + 1 < len(modules)
+                and isinstance(modules[i + 1], nn.BatchNorm1d)):
+            # convolution + BatchNorm1d (+ ReLU) as one autograd node (conv_bn_act)
+            relu = i + 2 < len(modules) and type(modules[i + 2]) is nn.ReLU
+            fused = conv_bn_act(module, input, modules[i + 1], relu=relu)
+            if fused is not None:
+                input = fused
+                i += 3 if relu else 2
+                continue
         if is_spconv_module(module):
             input = module(input)
         elif isinstance(input, SparseConvTensor):
