@@ -505,7 +505,7 @@ def main():
     if args.soak_steps > 0 and world == 1:
         del trainer
         torch.cuda.empty_cache()
-        soak_tr = Trainer(config=config, device=dev, overrides=overrides, seed=0, max_iters=args.soak_steps + args.steps + 10)
+        soak_tr = Trainer(config=config, device=dev, overrides=overrides, seed=0, max_iters=args.soak_steps + 2 * args.steps + args.warmup + 10)
         soak_pool = pool + [synthetic_batch(2000 + 100 * p, args.scenes, n_points=args.points, device=dev, n_sweeps=args.sweeps,
                                             clutter=0.55 if args.dense else 0.0) for p in range(len(pool), 4)]
         saved_pool = list(pool)
