@@ -231,3 +231,40 @@ def test_bottleneck_block_equals_dense(dev, stride):
     y.features.backward(go.to(dev))
     want.backward(go.double())
     _close("bottleneck block input gradient", fx.grad.cpu().numpy(), rows_of(xd.grad, sites_in).numpy(), rel=2e-4)
+
+
+def test_conv_bn_single_node_is_the_same_computation(dev):
+    """spconv.conv_bn_act runs the convolution and the fused BatchNorm (+ residual + ReLU) as ONE autograd node built from
+    the two existing Functions (efg_amd/_fuse.py): same kernels, same order -> outputs, running statistics and every
+    gradient identical bit for bit to the module-by-module form."""
+    import efg_amd.spconv as spconv
+    from efg_amd.modeling.backbones.sparse_net import SparseBasicResBlock
+    from efg_amd.spconv import core
+
+    rng = np.random.default_rng(11)
+    batch, shape, cin, cout = 2, (9, 18, 20), 32, 64
+    idx, feat = _random_sparse(rng, batch, shape, 1500, cin)
+    go = None
+    results = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        blk = SparseBasicResBlock(cin, cout, stride=2, norm="BN1d", activation=dict(type="ReLU", inplace=True),
+                                  indice_key="res2").to(dev)
+        blk.train()
+        saved = core._CONV_BN_FUSED
+        core._CONV_BN_FUSED = fused
+        try:
+            fx = torch.from_numpy(feat).to(dev).requires_grad_(True)
+            y = blk(spconv.SparseConvTensor(fx, torch.from_numpy(idx).to(dev), list(shape), batch))
+            if go is None:
+                go = torch.from_numpy(rng.standard_normal(tuple(y.features.shape)).astype(np.float32)).to(dev)
+            y.features.backward(go)
+        finally:
+            core._CONV_BN_FUSED = saved
+        results.append((y.features.detach().cpu().numpy(), fx.grad.cpu().numpy(),
+                        {k: p.grad.cpu().numpy() for k, p in blk.named_parameters()},
+                        {k: b.cpu().numpy() for k, b in blk.named_buffers()}))
+    (y0, gx0, gp0, bf0), (y1, gx1, gp1, bf1) = results
+    assert np.array_equal(y0, y1) and np.array_equal(gx0, gx1)
+    assert all(np.array_equal(gp0[k], gp1[k]) for k in gp0) and set(gp0) == set(gp1)
+    assert all(np.array_equal(bf0[k], bf1[k]) for k in bf0)
