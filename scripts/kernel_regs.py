@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / LDS / occupancy report of the kernels in one csrc file (compile-time, no GPU):
-    scripts/kernel_regs.py spconv_tiles.hip [name-filter] [--rev GIT_REV]"""
+    scripts/kernel_regs.py spconv_tiles.hip [name-filter] [--rev GIT_REV]      (KREGS_FLAGS="-DX=1 ..." adds compiler flags)"""
 import re
 import subprocess
 import sys
@@ -17,7 +17,7 @@ if "--rev" in sys.argv:
     open(path, "wb").write(text)
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
        "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "efg_amd", "csrc"), "-x", "hip",
-       "-c", path, "-o", "/tmp/kregs.o", "-Rpass-analysis=kernel-resource-usage"]
+       "-c", path, "-o", "/tmp/kregs.o", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("KREGS_FLAGS", "").split()
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = []
