@@ -694,9 +694,14 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
             gval = GW[slot * GS + e_cell[k]];
           } else {  // the box has grown out of the window: dot product against the global value row
             e_cell[k] = -2;
-            const float* vr = value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D;
-#pragma unroll 4
-            for (int cc = 0; cc < D; ++cc) gval = fmaf(GOs[slot * VS + cc], vr[cc], gval);   // rare: keep it small
+            // (rare on a fresh model, common once the boxes have grown: 16-byte loads, the same 32 additions in order)
+            const float4* vr = reinterpret_cast<const float4*>(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D);
+            const float4* gr = reinterpret_cast<const float4*>(GOs + slot * VS);
+#pragma unroll 1
+            for (int cc = 0; cc < D / 4; ++cc) {
+              const float4 v4 = vr[cc], g4 = gr[cc];
+              gval = fmaf(g4.w, v4.w, fmaf(g4.z, v4.z, fmaf(g4.y, v4.y, fmaf(g4.x, v4.x, gval))));
+            }
           }
         }
 #pragma unroll
@@ -983,13 +988,16 @@ __global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restric
 // main kernel cursor[bin] is the END of the bin, offsets[bin] its start.
 // The entries of a bin sit in the order their atomics arrived, which differs run to run; a float accumulation in list
 // order would make grad_value (and every gradient upstream of it) differ in the last bits between two identical steps.
-// The sum is therefore taken as EXACT 64-bit fixed-point integers at a scale 2^sh at which no sum of the bin's n products
-// can overflow: every |weight * grad_out| of the bin is below (largest |weight| of the bin) x (largest |grad_out| of the
-// call, the maximum over `gmax_bits[1..63]`, absmax_bits_kernel) -- the first is one pass over the bin's 8-byte entries, no row is gathered for
-// it (round 4, first version: a first gather pass found the bin's exact largest product; the gathers are the cost of this
-// kernel, and it doubles as the boxes grow and most corners of the encoder leave their query tile's window).  Each product
-// is exact in double (24 x 24 bits), integer addition is associative, and the row receives the total rounded once: exact
-// to 2^-(61 - log2 n) of the bound, i.e. to ~1e-13 of the call's largest gradient element.
+// The sum is therefore taken as EXACT 64-bit fixed-point integers at a scale 2^sh at which no product leaves 51 bits and no
+// sum of the bin's n products can overflow: every |weight| is at most 1 (a softmax weight times a bilinear weight; 2 is
+// the bound used) and every |grad_out| at most the largest of the call (the maximum over `gmax_bits[1..63]`,
+// absmax_bits_kernel), so the bound needs no pass over the bin (round 4: a pass over the bin's 8-byte entries for its largest
+// |weight|; before that a gather pass for its exact largest product -- the gathers are the cost of this kernel, and it
+// doubles as the boxes grow and most corners of the encoder leave their query tile's window).  Each product is exact in double
+// (24 x 24 bits), scaling by 2^sh is exact, and ONE fused multiply-add with 1.5 * 2^52 rounds it to an integer that sits in
+// the low mantissa bits (|x| < 2^51): two fp64 instructions per product instead of ldexp + a software double -> int64
+// conversion.  Integer addition is associative, and the row receives the total rounded once: exact to 2^-(50 - log2 n) of
+// the bound, i.e. to ~1e-12 of the call's largest gradient element.
 __global__ void __launch_bounds__(256)
 box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ cursor, const int2* __restrict__ entries,
                       const float* __restrict__ grad_out, long long nbins, const unsigned* __restrict__ gmax_bits,
@@ -998,24 +1006,19 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
   unsigned gbits = 0u;   // (the 63 slots of absmax_bits_kernel, after the overflow word of the flag block)
   for (int i = 1; i <= kAbsmaxSlots; ++i) gbits = max(gbits, gmax_bits[i]);
   const bool finite = gbits < 0x7f800000u;
-  const float gmax = __uint_as_float(gbits);
+  int ex = 0;
+  frexpf(fminf(__uint_as_float(gbits) * 2.0000002f, 3.0e38f), &ex);   // every |product| < 2^ex
+  constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52: x + kMagic holds round(x) in its low mantissa bits for |x| < 2^51
+  const long long magic_bits = __double_as_longlong(kMagic);
   for (long long bin = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); bin < nbins; bin += (long long)gridDim.x * 32) {
     const int s = offsets[bin], e = min(cursor[bin], offsets[bin + 1]);  // offsets has nbins + 1 entries
     if (s == e) continue;
     float4 acc = ld4(grad_value + bin * 32 + c4);
     if (finite) {
-      float mw = 0.0f;
-      for (int i0 = s; i0 < e; i0 += 4) {
-        int2 en[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) en[u] = entries[min(i0 + u, e - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) mw = fmaxf(mw, fabsf(__int_as_float(en[u].y)));
-      }
-      int ex = 0, ln = 0;
-      frexpf(fminf(mw * gmax * 1.0000002f, 3.0e38f), &ex);   // every |product| < 2^ex (a NaN weight: fminf keeps the bound finite)
+      int ln = 0;
       while ((1 << ln) < e - s + 1) ++ln;    // n + 1 <= 2^ln
-      const int sh = 61 - ln - ex;
+      const int sh = min(50, 62 - ln) - ex;  // |product * 2^sh| < 2^50 (one rounding bit to spare), |sum| < 2^62
+      const double scale = ldexp(1.0, sh);
       long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
       for (int i0 = s; i0 < e; i0 += 4) {   // four entries (and their grad_out rows) in flight
         int2 en[4];
@@ -1025,14 +1028,13 @@ box_bin_reduce_kernel(const int* __restrict__ offsets, const int* __restrict__ c
 #pragma unroll
         for (int u = 0; u < 4; ++u) g[u] = ld4(grad_out + (long long)en[u].x * 32 + c4);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i0 + u < e) {
-            const double w = (double)__int_as_float(en[u].y);
-            a0 += __double2ll_rn(ldexp(w * (double)g[u].x, sh));
-            a1 += __double2ll_rn(ldexp(w * (double)g[u].y, sh));
-            a2 += __double2ll_rn(ldexp(w * (double)g[u].z, sh));
-            a3 += __double2ll_rn(ldexp(w * (double)g[u].w, sh));
-          }
+        for (int u = 0; u < 4; ++u) {
+          const double w = i0 + u < e ? (double)__int_as_float(en[u].y) : 0.0;   // (past the end: + 0)
+          a0 += __double_as_longlong(fma(w * (double)g[u].x, scale, kMagic)) - magic_bits;
+          a1 += __double_as_longlong(fma(w * (double)g[u].y, scale, kMagic)) - magic_bits;
+          a2 += __double_as_longlong(fma(w * (double)g[u].z, scale, kMagic)) - magic_bits;
+          a3 += __double_as_longlong(fma(w * (double)g[u].w, scale, kMagic)) - magic_bits;
+        }
       }
       acc.x = __fadd_rn(acc.x, (float)ldexp((double)a0, -sh));
       acc.y = __fadd_rn(acc.y, (float)ldexp((double)a1, -sh));
