@@ -55,6 +55,7 @@ _SIGS = {
     "efg_spconv_tile_plan": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_forward_tiled_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                              c_int64, c_int, c_void_p, c_void_p]),
+    "efg_spconv_small_ok": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "efg_spconv_tile_bf16x3_ok": (c_int, [c_int, c_int, c_int, c_int64, c_int64]),
     "efg_spconv_streamk_fallbacks": (c_int, [c_void_p, c_int]),
     "efg_ticket_ring_errors": (c_int, [c_void_p, c_int]),

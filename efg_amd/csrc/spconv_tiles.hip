@@ -702,6 +702,139 @@ conv_tile_kernel(TileArgs a) {
   }
 }
 
+// ---- narrow layers (the stem): at most 32 reduction channels and 32 output channels ------------------------------------
+// conv_tile_kernel gathers with one LANE per reduction channel and stages the rows in LDS: at 16 channels three lanes in four
+// (at 5: eleven in twelve) load nothing, every offset costs 16 dependent loads + an LDS round trip for 4 MFMAs, and the
+// launch takes ~45 us whatever the level holds (7-8 % of the HBM roof on the stem, profiles/r04q).  Here a lane owns
+// (row lane & 15 of the tile, channels [SPC * (lane >> 4), + SPC)), i.e. the 64 lanes of ONE 16-byte load instruction
+// fetch the 16 neighbour rows of an offset whole (16 channels; two instructions at 32) and the loaded registers ARE
+// the A operands of the offset's SPC MFMA steps -- the k index of v_mfma_f32_16x16x4_f32 is ours to assign, so step s takes
+// channel SPC * kk + s from lane group kk and the weights are laid out to match.  No A staging; the layer's weights
+// (<= 55 KB in that order) sit in LDS, read without bank conflicts (64 consecutive floats per step and n-tile); a wave
+// walks whole tiles (all their active offsets, four offsets' indices and rows in flight), so nothing is shared between
+// waves and nothing is summed across them: a row's sum runs over its offsets in table order.
+template <int SPC, int NT, bool VEC>
+__global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
+  extern __shared__ float wl[];   // [kvol][SPC][NT][4 kk][16 n]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {
+    // packed[((k * c16n + r16) * np + n) * 16 + kk' * 4 + j] = W(red = r16 * 16 + 4 * j + kk', n)  (efg_spconv_pack_weight_f32), read
+    // in ITS order as 16-byte pieces -- coalesced, all of a thread's pieces in flight -- and scattered into the LDS order
+    // [col][s][t][kk][n] with red = SPC * kk + s.  (First version: a loop in LDS order with one dependent 4-byte load per
+    // trip, 14-27 trips per thread: 25 of the launch's 33 us.)
+    constexpr int kPieces = (28 * 2 * 2 * 16 * 4 + 511) / 512;   // kvol <= 28, c16n <= 2, np <= 32
+    const int total4 = a.kvol * a.c16n * a.np * 4;
+    const float4* src = reinterpret_cast<const float4*>(a.wp);
+    float4 v[kPieces];
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q) {
+      const int f4 = tid + 512 * q;
+      v[q] = f4 < total4 ? src[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q) {
+      const int f4 = tid + 512 * q;
+      if (f4 >= total4) continue;
+      const int kq = f4 & 3;
+      int r = f4 >> 2;
+      const int n = r % a.np;
+      r /= a.np;
+      const int r16 = r % a.c16n, k = r / a.c16n;
+      const int col = a.flip ? a.kvol - 1 - k : k;
+      const int t = n >> 4, n16 = n & 15;
+      const float vj[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int red = r16 * 16 + 4 * j + kq;
+        if (red < 4 * SPC && t < NT) wl[((((col * SPC + red % SPC) * NT + t) * 4 + red / SPC) * 16) + n16] = vj[j];
+      }
+    }
+  }
+  __syncthreads();
+  const int i = lane & 15, kk = lane >> 4;
+  // XCD x (= blockIdx.x & 7) walks the x-th contiguous eighth of every pass over the tiles (neighbouring tiles gather the
+  // same rows: one L2 fetches them)
+  const unsigned G = gridDim.x, per8 = G >> 3;
+  const unsigned g = blockIdx.x < (per8 << 3) ? (blockIdx.x & 7) * per8 + (blockIdx.x >> 3) : blockIdx.x;
+  const long long nw = (long long)G * 8;
+  for (long long tile = (long long)g * 8 + wv; tile < a.n_tiles; tile += nw) {
+    const int prow = lane < 16 ? a.rows[tile * 16 + lane] : -1;
+    if (__ballot(prow >= 0) == 0ull) continue;   // padding tile at the end of the plan
+    const unsigned active = (unsigned)__builtin_amdgcn_readfirstlane((int)a.vm[tile * 32 + 31]);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int co = t * 16 + i;
+      const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.0f;
+      acc[t] = f32x4{b, b, b, b};
+    }
+    // The tile's whole neighbour block first (one round trip), then the rows in chunks of GC offsets, two chunks in flight:
+    // a wave has ~2 tiles to walk, so the chain of dependent round trips per tile IS its run time (first version: index,
+    // then rows, then MFMAs per four offsets -- 14 dependent round trips per tile, 37 us per launch).
+    constexpr int KMAX = 28, GC = SPC <= 4 ? 7 : 4, NCH = KMAX / GC;   // (kvol <= 28: checked by the launch code)
+    const int* nbp = a.nb + tile * a.kvol * 16 + i;
+    int idx[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) idx[c] = -1;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c)
+      if (c < a.kvol) idx[c] = nbp[c * 16];   // (wave-uniform guard)
+    float xa[GC][SPC], xb[GC][SPC];
+    auto load_rows = [&](float (&x)[GC][SPC], const int* id) {
+#pragma unroll
+      for (int u = 0; u < GC; ++u) {
+        const float* rp = a.in + (size_t)max(id[u], 0) * a.cin + kk * SPC;
+        if constexpr (VEC) {
+#pragma unroll
+          for (int s4 = 0; s4 < SPC / 4; ++s4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(rp + 4 * s4);
+            x[u][4 * s4] = v4.x, x[u][4 * s4 + 1] = v4.y, x[u][4 * s4 + 2] = v4.z, x[u][4 * s4 + 3] = v4.w;
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < SPC; ++s) x[u][s] = rp[min(s, a.cin - 1 - kk * SPC)];   // (clamped; zeroed in `mfmas`)
+        }
+      }
+    };
+    auto mfmas = [&](float (&x)[GC][SPC], const int* id, int c0) {
+#pragma unroll
+      for (int u = 0; u < GC; ++u) {
+        if (!((active >> (c0 + u)) & 1u)) continue;   // (wave-uniform)
+        const float* wp = wl + (size_t)(c0 + u) * SPC * NT * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < SPC; ++s) {
+          const float xv = (id[u] < 0 || (!VEC && kk * SPC + s >= a.cin)) ? 0.0f : x[u][s];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wp[(s * NT + t) * 64], acc[t], 0, 0, 0);
+        }
+      }
+    };
+    load_rows(xa, idx);
+    if (GC < a.kvol) load_rows(xb, idx + GC);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch += 2) {
+      if (ch * GC >= a.kvol) break;
+      mfmas(xa, idx + ch * GC, ch * GC);
+      if constexpr (true) {
+        if (ch + 2 < NCH && (ch + 2) * GC < a.kvol) load_rows(xa, idx + (ch + 2 < NCH ? ch + 2 : 0) * GC);
+      }
+      if (ch + 1 >= NCH || (ch + 1) * GC >= a.kvol) break;
+      mfmas(xb, idx + (ch + 1) * GC, (ch + 1) * GC);
+      if (ch + 3 < NCH && (ch + 3) * GC < a.kvol) load_rows(xb, idx + (ch + 3 < NCH ? ch + 3 : 0) * GC);
+    }
+    // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = __shfl(prow, kk * 4 + r, 64);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int co = t * 16 + i;
+        if (row >= 0 && co < a.cout) a.out[(long long)row * a.cout + co] = acc[t][r];
+      }
+    }
+  }
+}
+
 // workgroups of `kernel` one CU holds at once (LDS / VGPR bound), x the CUs of the device
 template <typename K>
 int resident_workgroups(K kernel) {
@@ -819,6 +952,22 @@ bool bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {
   return nt == 4 && ks == 4 && kvol <= 31 && cin >= 64 && cin % 32 == 0 && cout % 64 == 0;
 }
 
+// conv_small_kernel covers a (cin -> cout, kvol) layer when its instantiation fits 128 VGPRs (two 512-thread workgroups per
+// CU) and the layer's weights 56 KB of LDS: up to 8 reduction channels of any count, 16 and 32 in 16-byte pieces (32 with 16
+// outputs only); at most 32 outputs, 28 offsets.  ONE rule for the launcher and for efg_spconv_small_ok (the host's labels).
+// spc: reduction channels per lane group rounded up to 1 / 2 / 4 / 8; nt: 16-column output tiles.
+bool small_shape(int cin, int cout, int kvol, int* spc_out, int* nt_out) {
+  static const int small_env = getenv("EFG_CONV_SMALL") ? atoi(getenv("EFG_CONV_SMALL")) : 1;
+  const int spc_raw = (cin + 3) / 4;
+  const int spc = spc_raw <= 1 ? 1 : spc_raw <= 2 ? 2 : spc_raw <= 4 ? 4 : 8;
+  const int nt = (cout + 15) / 16;
+  *spc_out = spc;
+  *nt_out = nt;
+  const bool pieces = cin == 4 * spc && spc % 4 == 0;   // rows of whole 16-byte pieces
+  return small_env && cin >= 1 && cin <= 32 && nt <= 2 && kvol <= 28 && (size_t)kvol * spc * nt * 256 <= 56 * 1024 &&
+         (spc <= 2 || (pieces && (spc == 4 || nt == 1)));
+}
+
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
               const void* plan, int64_t m_out, float* out, int flip, int natural_order, int bf3, hipStream_t stream) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
@@ -861,6 +1010,30 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
     a.zero_off = (long long)(zero_piece[dev] - reinterpret_cast<const char*>(in));
   }
   EFG_CHECK_ARG(!natural_order || cin % 4 == 0, "spconv tiled: natural-order weights need cin %% 4 == 0, got %d", cin);
+  // narrow layers (conv_small_kernel): EFG_CONV_SMALL=0 keeps them on the tile kernel (A/B)
+  {
+    int spc = 0, nt_s = 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(wp) & 15) == 0;
+    if (small_shape(cin, cout, kvol, &spc, &nt_s) && !a.v4 && !a.bf3 && aligned) {
+      const size_t lds = (size_t)kvol * spc * nt_s * 256;
+      const unsigned wgs = (unsigned)std::min<long long>(512, std::max<long long>(8, ceil_div(pv.n_tiles, 8) / 8 * 8));
+#define EFG_SMALL_LAUNCH(SP, NTT, VE) \
+  hipLaunchKernelGGL((conv_small_kernel<SP, NTT, VE>), dim3(wgs), dim3(512), lds, stream, a)
+#define EFG_SMALL_NT(SP, VE) \
+  do {                       \
+    if (nt_s == 1) EFG_SMALL_LAUNCH(SP, 1, VE); \
+    else EFG_SMALL_LAUNCH(SP, 2, VE);           \
+  } while (0)
+      if (spc == 1) EFG_SMALL_NT(1, false);
+      else if (spc == 2) EFG_SMALL_NT(2, false);
+      else if (spc == 4) EFG_SMALL_NT(4, true);
+      else EFG_SMALL_LAUNCH(8, 1, true);
+#undef EFG_SMALL_NT
+#undef EFG_SMALL_LAUNCH
+      EFG_LAUNCH_CHECK();
+      return EFG_OK;
+    }
+  }
   const int ntiles = a.np / 16;
   // R = 2 sub-tiles per wave (weights loaded once for 32 rows) once the level has enough row tiles to fill the chip
   // that way; n-tiles per wave as many as the grid allows (A reuse); offsets split over the 4 waves of a workgroup
@@ -975,6 +1148,14 @@ extern "C" int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset) {
   }
   *count_out = total;
   return EFG_OK;
+}
+
+extern "C" int efg_spconv_small_ok(int cin, int cout, int kvol, int* spc, int* nt) {
+  int s_ = 0, n_ = 0;
+  const bool ok = cin >= 1 && cout >= 1 && kvol >= 1 && small_shape(cin, cout, kvol, &s_, &n_);
+  if (spc) *spc = s_;
+  if (nt) *nt = n_;
+  return ok ? 1 : 0;
 }
 
 extern "C" int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {

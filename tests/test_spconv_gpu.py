@@ -46,7 +46,10 @@ def test_regular_conv_vs_oracle(dev, oracle_mod, ks, st, pd, cin, cout):
 
 
 @pytest.mark.parametrize("cin,cout,bias", [(16, 16, False), (16, 32, True), (64, 64, False), (256, 256, False),
-                                           (6, 16, True), (48, 80, False)])
+                                           (6, 16, True), (48, 80, False),
+                                           # the narrow layers' kernel (conv_small_kernel<SPC, NT>), forward and dgrad:
+                                           # <1,1> / <2,1>, <2,2> / <8,1>, <8,1> / <4,2>, tile kernel / tile kernel
+                                           (3, 8, True), (8, 32, False), (32, 16, True), (32, 32, False)])
 def test_subm_conv_vs_oracle(dev, oracle_mod, cin, cout, bias):
     import efg_amd.spconv as spconv
 
@@ -217,3 +220,22 @@ def test_packed_weight_cache_follows_every_weight_update(dev, monkeypatch):
     c2.weight.data.mul_(0.5)                     # behind autograd's back: the documented contract is to say so
     spconv.weights_updated()
     check("after a write through .data + weights_updated()")
+
+
+def test_narrow_layers_run_on_the_small_kernel(dev):
+    """efg_spconv_small_ok is the launcher's own rule: the res18 stem (5 -> 16, 16 -> 16, 16 -> 32 and the dgrads 16 -> 16,
+    32 -> 16) is covered, 32 -> 32 and the wide layers are not, and the host labels its timings accordingly."""
+    import ctypes
+
+    from efg_amd import _lib as L
+    from efg_amd.spconv import core
+
+    spc, nt = ctypes.c_int(), ctypes.c_int()
+    want = {(5, 16): (2, 1), (16, 16): (4, 1), (16, 32): (4, 2), (32, 16): (8, 1), (3, 8): (1, 1), (8, 32): (2, 2)}
+    for (cin, cout), inst in want.items():
+        assert L.lib().efg_spconv_small_ok(cin, cout, 27, ctypes.byref(spc), ctypes.byref(nt)) == 1, (cin, cout)
+        assert (spc.value, nt.value) == inst
+        assert core._tile_kernel_name(cin, cout, 27, 1000, 1000) == "conv_small_kernel<%d,%d>" % inst
+    for cin, cout, kvol in [(32, 32, 27), (64, 32, 27), (16, 64, 27), (12, 16, 27), (16, 16, 29)]:
+        assert L.lib().efg_spconv_small_ok(cin, cout, kvol, None, None) == 0, (cin, cout, kvol)
+    assert core._tile_kernel_name(64, 64, 27, 1000, 1000).startswith("conv_tile_kernel<")
