@@ -713,6 +713,9 @@ conv_tile_kernel(TileArgs a) {
 // (<= 55 KB in that order) sit in LDS, read without bank conflicts (64 consecutive floats per step and n-tile); a wave
 // walks whole tiles (all their active offsets, four offsets' indices and rows in flight), so nothing is shared between
 // waves and nothing is summed across them: a row's sum runs over its offsets in table order.
+#ifndef EFG_SMALL_KO
+#define EFG_SMALL_KO 0   // knock-out builds (scripts/build_ab.sh): 1 no weight staging, 2 no row loads, 3 no neighbour loads, 4 no MFMAs, 5 no stores
+#endif
 template <int SPC, int NT, bool VEC>
 __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
   extern __shared__ float wl[];   // [kvol][SPC][NT][4 kk][16 n]
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
 #pragma unroll
     for (int q = 0; q < kPieces; ++q) {
       const int f4 = tid + 512 * q;
-      v[q] = f4 < total4 ? src[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[q] = (f4 < total4 && EFG_SMALL_KO != 1) ? src[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < kPieces; ++q) {
@@ -778,12 +781,17 @@ __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
     for (int c = 0; c < KMAX; ++c) idx[c] = -1;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c)
-      if (c < a.kvol) idx[c] = nbp[c * 16];   // (wave-uniform guard)
+      if (c < a.kvol) idx[c] = EFG_SMALL_KO == 3 ? (int)((tile * 16 + i + c) % 1000) : nbp[c * 16];   // (wave-uniform guard)
     float xa[GC][SPC], xb[GC][SPC];
     auto load_rows = [&](float (&x)[GC][SPC], const int* id) {
 #pragma unroll
       for (int u = 0; u < GC; ++u) {
         const float* rp = a.in + (size_t)max(id[u], 0) * a.cin + kk * SPC;
+        if (EFG_SMALL_KO == 2) {
+#pragma unroll
+          for (int s = 0; s < SPC; ++s) x[u][s] = (float)id[u];
+          continue;
+        }
         if constexpr (VEC) {
 #pragma unroll
           for (int s4 = 0; s4 < SPC / 4; ++s4) {
@@ -805,7 +813,10 @@ __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
         for (int s = 0; s < SPC; ++s) {
           const float xv = (id[u] < 0 || (!VEC && kk * SPC + s >= a.cin)) ? 0.0f : x[u][s];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wp[(s * NT + t) * 64], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            if (EFG_SMALL_KO == 4) acc[t][0] += xv;
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wp[(s * NT + t) * 64], acc[t], 0, 0, 0);
+          }
         }
       }
     };
@@ -829,7 +840,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int co = t * 16 + i;
-        if (row >= 0 && co < a.cout) a.out[(long long)row * a.cout + co] = acc[t][r];
+        if (row >= 0 && co < a.cout && (EFG_SMALL_KO != 5 || acc[t][r] == 123.456f)) a.out[(long long)row * a.cout + co] = acc[t][r];
       }
     }
   }
