@@ -809,13 +809,19 @@ __global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
       for (int u = 0; u < GC; ++u) {
         if (!((active >> (c0 + u)) & 1u)) continue;   // (wave-uniform)
         const float* wp = wl + (size_t)(c0 + u) * SPC * NT * 64 + lane;
+        // the offset's SPC * NT weight fragments in one batch of LDS reads, then its MFMAs.  (The 16 -> 32 layer spends 18 of
+        // its 44 us here, and that is the matrix pipe itself: 7360 tiles x 216 executed MFMAs x 32 cycles over 1024 SIMDs =
+        // 20.7 us -- a tile runs every offset ANY of its 16 rows needs, 1.8x the useful products on this level.)
+        float wv[SPC * NT];
+#pragma unroll
+        for (int q = 0; q < SPC * NT; ++q) wv[q] = EFG_SMALL_KO == 4 ? 0.0f : wp[q * 64];
 #pragma unroll
         for (int s = 0; s < SPC; ++s) {
           const float xv = (id[u] < 0 || (!VEC && kk * SPC + s >= a.cin)) ? 0.0f : x[u][s];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             if (EFG_SMALL_KO == 4) acc[t][0] += xv;
-            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wp[(s * NT + t) * 64], acc[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wv[s * NT + t], acc[t], 0, 0, 0);
           }
         }
       }
