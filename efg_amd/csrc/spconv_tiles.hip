@@ -702,142 +702,196 @@ conv_tile_kernel(TileArgs a) {
   }
 }
 
-// ---- narrow layers (the stem): at most 32 reduction channels and 32 output channels ------------------------------------
+// ---- narrow layers (the stem): 16 or 32 (or at most 8) reduction channels, at most 32 output channels ------------------
 // conv_tile_kernel gathers with one LANE per reduction channel and stages the rows in LDS: at 16 channels three lanes in four
 // (at 5: eleven in twelve) load nothing, every offset costs 16 dependent loads + an LDS round trip for 4 MFMAs, and the
 // launch takes ~45 us whatever the level holds (7-8 % of the HBM roof on the stem, profiles/r04q).  Here a lane owns
-// (row lane & 15 of the tile, channels [SPC * (lane >> 4), + SPC)), i.e. the 64 lanes of ONE 16-byte load instruction
-// fetch the 16 neighbour rows of an offset whole (16 channels; two instructions at 32) and the loaded registers ARE
-// the A operands of the offset's SPC MFMA steps -- the k index of v_mfma_f32_16x16x4_f32 is ours to assign, so step s takes
-// channel SPC * kk + s from lane group kk and the weights are laid out to match.  No A staging; the layer's weights
-// (<= 55 KB in that order) sit in LDS, read without bank conflicts (64 consecutive floats per step and n-tile); a wave
-// walks whole tiles (all their active offsets, four offsets' indices and rows in flight), so nothing is shared between
-// waves and nothing is summed across them: a row's sum runs over its offsets in table order.
+// (row lane & 15 of the tile, 16-byte piece lane >> 4 of each 64-byte half of the row): the 64 lanes of ONE load
+// instruction fetch the 16 neighbour rows of an offset whole, a 4 x 4 transpose across the four lane groups (two
+// v_permlane32_swap + two v_permlane16_swap per piece -- gfx950) turns the piece into the A operands of the offset's four
+// MFMA steps (step j: channel 4 j + kk from lane group kk, the operand order of the tile kernel), and the layer's PACKED
+// weights (efg_spconv_pack_weight_f32 order, <= 55 KB) sit in LDS where a lane's four B operands are one conflict-free
+// 16-byte read.  No A staging, nothing shared between waves: a wave walks whole tiles with the tile's neighbour block
+// and two chunks of rows in flight.
+// THE SUMS ARE THE TILE KERNEL'S, BIT FOR BIT: same operand placement per MFMA, the active offsets of a tile dealt round
+// robin to four accumulators (the tile kernel's four split-K waves; one accumulator below 8 offsets, as there) and added
+// in the same order -- so every golden, tolerance and run-to-run digest downstream is unchanged
+// (tests/test_spconv_gpu.py::test_small_kernel_bits_equal_tile_kernel).
 #ifndef EFG_SMALL_KO
 #define EFG_SMALL_KO 0   // knock-out builds (scripts/build_ab.sh): 1 no weight staging, 2 no row loads, 3 no neighbour loads, 4 no MFMAs, 5 no stores
 #endif
-template <int SPC, int NT, bool VEC>
-__global__ void __launch_bounds__(512) conv_small_kernel(TileArgs a) {
-  extern __shared__ float wl[];   // [kvol][SPC][NT][4 kk][16 n]
+__device__ __forceinline__ void transpose_pieces(float (&v)[4]) {   // lane group g, element e  <->  lane group e, element g
+  // v_permlane32_swap a, b: a's lanes 32..63 <-> b's lanes 0..31; v_permlane16_swap a, b: a's odd 16-lane rows <-> b's even
+  // rows (gfx950; scripts/ubench/permlane_probe.hip prints both).  Inline asm with both registers read-write: chained through
+  // __builtin_amdgcn_permlane*_swap, this compiler (ROCm 7.2) returns the FIRST result for both halves of the second pair
+  // (the probe's "128 of 256 wrong"); the s_nop covers the VALU-write -> permlane-read hazard the compiler would otherwise pad.
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
+               "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
+// C16: 16-channel groups of the reduction (1 | 2); NT: 16-column output tiles (1 | 2); VEC: cin == 16 * C16 in 16-byte
+// pieces, else cin <= 8 by 4-byte loads (C16 = 1; steps j = 0, 1 -- the tile kernel's steps 2 and 3 add exact zeros there).
+constexpr int kSmallThreads = 256;   // (4 waves share a copy of the weights)
+constexpr int kSmallKmax = 28;       // offsets of a table this kernel walks (checked by the launch code)
+template <int C16, int NT, bool VEC>
+__global__ void __launch_bounds__(kSmallThreads) conv_small_kernel(TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // the packed weights [kvol][C16][np][kk][j] | neighbour blocks of the 4 waves
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int* nbs = reinterpret_cast<int*>(wl + (size_t)a.kvol * C16 * NT * 256) + wv * (kSmallKmax * 16);
   {
-    // packed[((k * c16n + r16) * np + n) * 16 + kk' * 4 + j] = W(red = r16 * 16 + 4 * j + kk', n)  (efg_spconv_pack_weight_f32), read
-    // in ITS order as 16-byte pieces -- coalesced, all of a thread's pieces in flight -- and scattered into the LDS order
-    // [col][s][t][kk][n] with red = SPC * kk + s.  (First version: a loop in LDS order with one dependent 4-byte load per
-    // trip, 14-27 trips per thread: 25 of the launch's 33 us.)
-    constexpr int kPieces = (28 * 2 * 2 * 16 * 4 + 511) / 512;   // kvol <= 28, c16n <= 2, np <= 32
-    const int total4 = a.kvol * a.c16n * a.np * 4;
+    constexpr int kPieces = (kSmallKmax * C16 * NT * 16 * 4 + kSmallThreads - 1) / kSmallThreads;   // 16-byte pieces per thread
+    const int total4 = a.kvol * C16 * NT * 16 * 4;
     const float4* src = reinterpret_cast<const float4*>(a.wp);
     float4 v[kPieces];
 #pragma unroll
     for (int q = 0; q < kPieces; ++q) {
-      const int f4 = tid + 512 * q;
+      const int f4 = tid + kSmallThreads * q;
       v[q] = (f4 < total4 && EFG_SMALL_KO != 1) ? src[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < kPieces; ++q) {
-      const int f4 = tid + 512 * q;
-      if (f4 >= total4) continue;
-      const int kq = f4 & 3;
-      int r = f4 >> 2;
-      const int n = r % a.np;
-      r /= a.np;
-      const int r16 = r % a.c16n, k = r / a.c16n;
-      const int col = a.flip ? a.kvol - 1 - k : k;
-      const int t = n >> 4, n16 = n & 15;
-      const float vj[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int red = r16 * 16 + 4 * j + kq;
-        if (red < 4 * SPC && t < NT) wl[((((col * SPC + red % SPC) * NT + t) * 4 + red / SPC) * 16) + n16] = vj[j];
-      }
+      const int f4 = tid + kSmallThreads * q;
+      if (f4 < total4) reinterpret_cast<float4*>(wl)[f4] = v[q];
     }
   }
   __syncthreads();
   const int i = lane & 15, kk = lane >> 4;
+  constexpr int NJ = VEC ? 4 : 2;   // MFMA steps per 16-channel group
+  constexpr int XS = C16 * NJ;      // A operands of an offset per lane
+  const bool split = a.kvol >= 8;   // the tile kernel's KS = 4 (tile_shape)
   // XCD x (= blockIdx.x & 7) walks the x-th contiguous eighth of every pass over the tiles (neighbouring tiles gather the
   // same rows: one L2 fetches them)
   const unsigned G = gridDim.x, per8 = G >> 3;
   const unsigned g = blockIdx.x < (per8 << 3) ? (blockIdx.x & 7) * per8 + (blockIdx.x >> 3) : blockIdx.x;
-  const long long nw = (long long)G * 8;
-  for (long long tile = (long long)g * 8 + wv; tile < a.n_tiles; tile += nw) {
+  constexpr int kWaves = kSmallThreads / 64;
+  const long long nw = (long long)G * kWaves;
+  for (long long tile = (long long)g * kWaves + wv; tile < a.n_tiles; tile += nw) {
     const int prow = lane < 16 ? a.rows[tile * 16 + lane] : -1;
     if (__ballot(prow >= 0) == 0ull) continue;   // padding tile at the end of the plan
     const unsigned active = (unsigned)__builtin_amdgcn_readfirstlane((int)a.vm[tile * 32 + 31]);
-    f32x4 acc[NT];
+    // the tile's neighbour block, contiguous in the plan: coalesced loads (all in flight) into the wave's LDS block
+    {
+      const int* src = a.nb + tile * a.kvol * 16;
+      const int ne = a.kvol * 16;
+      int ev[(kSmallKmax * 16 + 63) / 64];
+#pragma unroll
+      for (int u = 0; u < (kSmallKmax * 16 + 63) / 64; ++u)
+        ev[u] = EFG_SMALL_KO == 3 ? (int)((tile * 16 + lane + u) % 1000) : src[min(lane + 64 * u, ne - 1)];
+      __builtin_amdgcn_wave_barrier();   // (the previous tile's reads of the block are done)
+#pragma unroll
+      for (int u = 0; u < (kSmallKmax * 16 + 63) / 64; ++u)
+        if (lane + 64 * u < ne) nbs[lane + 64 * u] = ev[u];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f32x4 accs[4][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int co = t * 16 + i;
       const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.0f;
-      acc[t] = f32x4{b, b, b, b};
+      accs[0][t] = f32x4{b, b, b, b};
+#pragma unroll
+      for (int q = 1; q < 4; ++q) accs[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // The tile's whole neighbour block first (one round trip), then the rows in chunks of GC offsets, two chunks in flight:
-    // a wave has ~2 tiles to walk, so the chain of dependent round trips per tile IS its run time (first version: index,
-    // then rows, then MFMAs per four offsets -- 14 dependent round trips per tile, 37 us per launch).
-    constexpr int KMAX = 28, GC = SPC <= 4 ? 7 : 4, NCH = KMAX / GC;   // (kvol <= 28: checked by the launch code)
-    const int* nbp = a.nb + tile * a.kvol * 16 + i;
-    int idx[KMAX];
+    // The ACTIVE offsets of the tile in table order, four at a time: offset number r goes to accumulator r & 3 -- the tile
+    // kernel's split-K wave -- so the accumulator index is static; the rows of the next four are in flight during the MFMAs
+    // of these four (a wave has ~2 tiles to walk: the chain of dependent round trips per tile is its run time).
+    unsigned rem = active;
+    struct Group {
+      int col[4];      // table column (wave-uniform), -1: none
+      int id[4];       // this lane's neighbour row, -1: absent
+      float x[4][XS];
+    };
+    auto fetch = [&](Group& gr) {
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) idx[c] = -1;
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c)
-      if (c < a.kvol) idx[c] = EFG_SMALL_KO == 3 ? (int)((tile * 16 + i + c) % 1000) : nbp[c * 16];   // (wave-uniform guard)
-    float xa[GC][SPC], xb[GC][SPC];
-    auto load_rows = [&](float (&x)[GC][SPC], const int* id) {
-#pragma unroll
-      for (int u = 0; u < GC; ++u) {
-        const float* rp = a.in + (size_t)max(id[u], 0) * a.cin + kk * SPC;
+      for (int q = 0; q < 4; ++q) {
+        gr.col[q] = rem ? __ffs((int)rem) - 1 : -1;
+        rem &= rem - 1;
+        gr.id[q] = -1;
+        if (gr.col[q] < 0) continue;   // (wave-uniform)
+        gr.id[q] = nbs[gr.col[q] * 16 + i];
+        const float* rp = a.in + (size_t)max(gr.id[q], 0) * a.cin;
         if (EFG_SMALL_KO == 2) {
 #pragma unroll
-          for (int s = 0; s < SPC; ++s) x[u][s] = (float)id[u];
+          for (int e = 0; e < XS; ++e) gr.x[q][e] = (float)gr.id[q];
           continue;
         }
         if constexpr (VEC) {
 #pragma unroll
-          for (int s4 = 0; s4 < SPC / 4; ++s4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(rp + 4 * s4);
-            x[u][4 * s4] = v4.x, x[u][4 * s4 + 1] = v4.y, x[u][4 * s4 + 2] = v4.z, x[u][4 * s4 + 3] = v4.w;
+          for (int h = 0; h < C16; ++h) {   // piece kk of the h-th 64-byte half of the row
+            const float4 v4 = *reinterpret_cast<const float4*>(rp + h * 16 + kk * 4);
+            gr.x[q][4 * h] = v4.x, gr.x[q][4 * h + 1] = v4.y, gr.x[q][4 * h + 2] = v4.z, gr.x[q][4 * h + 3] = v4.w;
           }
         } else {
 #pragma unroll
-          for (int s = 0; s < SPC; ++s) x[u][s] = rp[min(s, a.cin - 1 - kk * SPC)];   // (clamped; zeroed in `mfmas`)
+          for (int j = 0; j < NJ; ++j) gr.x[q][j] = rp[min(4 * j + kk, a.cin - 1)];   // channel 4 j + kk (clamped; zeroed below)
         }
       }
     };
-    auto mfmas = [&](float (&x)[GC][SPC], const int* id, int c0) {
+    auto step = [&](f32x4 (&acc)[NT], const float (&x)[XS], const float* wcol) {
 #pragma unroll
-      for (int u = 0; u < GC; ++u) {
-        if (!((active >> (c0 + u)) & 1u)) continue;   // (wave-uniform)
-        const float* wp = wl + (size_t)(c0 + u) * SPC * NT * 64 + lane;
-        // the offset's SPC * NT weight fragments in one batch of LDS reads, then its MFMAs.  (The 16 -> 32 layer spends 18 of
-        // its 44 us here, and that is the matrix pipe itself: 7360 tiles x 216 executed MFMAs x 32 cycles over 1024 SIMDs =
-        // 20.7 us -- a tile runs every offset ANY of its 16 rows needs, 1.8x the useful products on this level.)
-        float wv[SPC * NT];
+      for (int h = 0; h < C16; ++h) {
+        float4 bw[NT];
 #pragma unroll
-        for (int q = 0; q < SPC * NT; ++q) wv[q] = EFG_SMALL_KO == 4 ? 0.0f : wp[q * 64];
+        for (int t = 0; t < NT; ++t)
+          bw[t] = EFG_SMALL_KO == 4 ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                    : *reinterpret_cast<const float4*>(wcol + ((h * NT + t) * 16 + i) * 16 + kk * 4);
 #pragma unroll
-        for (int s = 0; s < SPC; ++s) {
-          const float xv = (id[u] < 0 || (!VEC && kk * SPC + s >= a.cin)) ? 0.0f : x[u][s];
+        for (int j = 0; j < NJ; ++j) {
+          const float av = x[h * NJ + j];
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            if (EFG_SMALL_KO == 4) acc[t][0] += xv;
-            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, wv[s * NT + t], acc[t], 0, 0, 0);
+            const float bv = j == 0 ? bw[t].x : j == 1 ? bw[t].y : j == 2 ? bw[t].z : bw[t].w;
+            if (EFG_SMALL_KO == 4) acc[t][0] += av;
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
           }
         }
       }
     };
-    load_rows(xa, idx);
-    if (GC < a.kvol) load_rows(xb, idx + GC);
+    auto multiply = [&](Group& gr) {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch += 2) {
-      if (ch * GC >= a.kvol) break;
-      mfmas(xa, idx + ch * GC, ch * GC);
-      if constexpr (true) {
-        if (ch + 2 < NCH && (ch + 2) * GC < a.kvol) load_rows(xa, idx + (ch + 2 < NCH ? ch + 2 : 0) * GC);
+      for (int q = 0; q < 4; ++q) {
+        if (gr.col[q] < 0) continue;   // (wave-uniform)
+        float xv[XS];
+#pragma unroll
+        for (int e = 0; e < XS; ++e) xv[e] = gr.x[q][e];
+        if constexpr (VEC) {
+#pragma unroll
+          for (int h = 0; h < C16; ++h) {
+            float pc[4] = {xv[4 * h], xv[4 * h + 1], xv[4 * h + 2], xv[4 * h + 3]};
+            transpose_pieces(pc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * h + j] = pc[j];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < XS; ++e)
+          if (gr.id[q] < 0 || (!VEC && 4 * (e % NJ) + kk >= a.cin)) xv[e] = 0.0f;
+        const int k = a.flip ? a.kvol - 1 - gr.col[q] : gr.col[q];
+        const float* wcol = wl + (size_t)k * C16 * NT * 256;
+        if (split || q == 0) step(accs[q], xv, wcol);
+        else step(accs[0], xv, wcol);   // fewer than 8 offsets: the tile kernel's waves do not split them
       }
-      if (ch + 1 >= NCH || (ch + 1) * GC >= a.kvol) break;
-      mfmas(xb, idx + (ch + 1) * GC, (ch + 1) * GC);
-      if (ch + 3 < NCH && (ch + 3) * GC < a.kvol) load_rows(xb, idx + (ch + 3 < NCH ? ch + 3 : 0) * GC);
+    };
+    Group ga, gb;
+    fetch(ga);
+    while (true) {
+      fetch(gb);
+      multiply(ga);
+      if (gb.col[0] < 0) break;
+      fetch(ga);
+      multiply(gb);
+      if (ga.col[0] < 0) break;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {   // the tile kernel's order: the first wave adds the second's, the third's, the fourth's
+      acc[t] = accs[0][t];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += accs[q][t][r];
     }
     // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -969,20 +1023,18 @@ bool bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out) {
   return nt == 4 && ks == 4 && kvol <= 31 && cin >= 64 && cin % 32 == 0 && cout % 64 == 0;
 }
 
-// conv_small_kernel covers a (cin -> cout, kvol) layer when its instantiation fits 128 VGPRs (two 512-thread workgroups per
-// CU) and the layer's weights 56 KB of LDS: up to 8 reduction channels of any count, 16 and 32 in 16-byte pieces (32 with 16
-// outputs only); at most 32 outputs, 28 offsets.  ONE rule for the launcher and for efg_spconv_small_ok (the host's labels).
-// spc: reduction channels per lane group rounded up to 1 / 2 / 4 / 8; nt: 16-column output tiles.
-bool small_shape(int cin, int cout, int kvol, int* spc_out, int* nt_out) {
-  static const int small_env = getenv("EFG_CONV_SMALL") ? atoi(getenv("EFG_CONV_SMALL")) : 1;
-  const int spc_raw = (cin + 3) / 4;
-  const int spc = spc_raw <= 1 ? 1 : spc_raw <= 2 ? 2 : spc_raw <= 4 ? 4 : 8;
-  const int nt = (cout + 15) / 16;
-  *spc_out = spc;
+// conv_small_kernel covers a (cin -> cout, kvol) layer with 16 or 32 reduction channels (16-byte pieces) or at most 8 (4-byte
+// loads), at most 32 outputs and 28 offsets, whose packed weights fit 56 KB of LDS.  ONE rule for the launcher and for
+// efg_spconv_small_ok (the host's labels).  c16: 16-channel groups of the reduction; nt: 16-column output tiles.
+// EFG_CONV_SMALL=0 (read per call: tests flip it in-process) keeps every layer on conv_tile_kernel.
+bool small_shape(int cin, int cout, int kvol, int* c16_out, int* nt_out) {
+  const char* env = getenv("EFG_CONV_SMALL");
+  const int c16 = (cin + 15) / 16, nt = (cout + 15) / 16;
+  *c16_out = c16;
   *nt_out = nt;
-  const bool pieces = cin == 4 * spc && spc % 4 == 0;   // rows of whole 16-byte pieces
-  return small_env && cin >= 1 && cin <= 32 && nt <= 2 && kvol <= 28 && (size_t)kvol * spc * nt * 256 <= 56 * 1024 &&
-         (spc <= 2 || (pieces && (spc == 4 || nt == 1)));
+  // (32 -> 32 would need 168 VGPRs + spills: it stays on the tile kernel)
+  return !(env && atoi(env) == 0) && (cin == 16 || cin == 32 || (cin >= 1 && cin <= 8)) && nt <= 2 && c16 * nt <= 2 && kvol >= 1 &&
+         kvol <= kSmallKmax && (size_t)kvol * c16 * nt * 1024 <= 56 * 1024;
 }
 
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
@@ -1029,23 +1081,24 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   EFG_CHECK_ARG(!natural_order || cin % 4 == 0, "spconv tiled: natural-order weights need cin %% 4 == 0, got %d", cin);
   // narrow layers (conv_small_kernel): EFG_CONV_SMALL=0 keeps them on the tile kernel (A/B)
   {
-    int spc = 0, nt_s = 0;
+    int c16 = 0, nt_s = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(wp) & 15) == 0;
-    if (small_shape(cin, cout, kvol, &spc, &nt_s) && !a.v4 && !a.bf3 && aligned) {
-      const size_t lds = (size_t)kvol * spc * nt_s * 256;
-      const unsigned wgs = (unsigned)std::min<long long>(512, std::max<long long>(8, ceil_div(pv.n_tiles, 8) / 8 * 8));
-#define EFG_SMALL_LAUNCH(SP, NTT, VE) \
-  hipLaunchKernelGGL((conv_small_kernel<SP, NTT, VE>), dim3(wgs), dim3(512), lds, stream, a)
-#define EFG_SMALL_NT(SP, VE) \
-  do {                       \
-    if (nt_s == 1) EFG_SMALL_LAUNCH(SP, 1, VE); \
-    else EFG_SMALL_LAUNCH(SP, 2, VE);           \
-  } while (0)
-      if (spc == 1) EFG_SMALL_NT(1, false);
-      else if (spc == 2) EFG_SMALL_NT(2, false);
-      else if (spc == 4) EFG_SMALL_NT(4, true);
-      else EFG_SMALL_LAUNCH(8, 1, true);
-#undef EFG_SMALL_NT
+    if (small_shape(cin, cout, kvol, &c16, &nt_s) && !a.v4 && !a.bf3 && aligned) {
+      const size_t lds = (size_t)kvol * c16 * nt_s * 1024 + (size_t)(kSmallThreads / 64) * kSmallKmax * 16 * sizeof(int);
+      // as many workgroups as the device holds at once (up to 4 per CU; 2 with 55 KB of weights), a multiple of 8
+      const long long fit = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)lds)) * 256;
+      const unsigned wgs = (unsigned)std::min<long long>(fit, std::max<long long>(8, ceil_div(pv.n_tiles, 4) / 8 * 8));
+#define EFG_SMALL_LAUNCH(C, NTT, VE) \
+  hipLaunchKernelGGL((conv_small_kernel<C, NTT, VE>), dim3(wgs), dim3(kSmallThreads), lds, stream, a)
+      if (cin <= 8) {
+        if (nt_s == 1) EFG_SMALL_LAUNCH(1, 1, false);
+        else EFG_SMALL_LAUNCH(1, 2, false);
+      } else if (c16 == 1) {
+        if (nt_s == 1) EFG_SMALL_LAUNCH(1, 1, true);
+        else EFG_SMALL_LAUNCH(1, 2, true);
+      } else {
+        EFG_SMALL_LAUNCH(2, 1, true);
+      }
 #undef EFG_SMALL_LAUNCH
       EFG_LAUNCH_CHECK();
       return EFG_OK;
@@ -1167,10 +1220,10 @@ extern "C" int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset) {
   return EFG_OK;
 }
 
-extern "C" int efg_spconv_small_ok(int cin, int cout, int kvol, int* spc, int* nt) {
+extern "C" int efg_spconv_small_ok(int cin, int cout, int kvol, int* c16, int* nt) {
   int s_ = 0, n_ = 0;
   const bool ok = cin >= 1 && cout >= 1 && kvol >= 1 && small_shape(cin, cout, kvol, &s_, &n_);
-  if (spc) *spc = s_;
+  if (c16) *c16 = s_;
   if (nt) *nt = n_;
   return ok ? 1 : 0;
 }

@@ -89,7 +89,7 @@ def _tile_kernel_name(cin, cout, kvol, m_in, m_out):
 
         nt, r, ks = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if L.lib().efg_spconv_small_ok(cin, cout, kvol, ctypes.byref(r), ctypes.byref(nt)):
-            _SHAPE_CACHE[key] = "conv_small_kernel<%d,%d>" % (r.value, nt.value)   # the narrow layers (stem)
+            _SHAPE_CACHE[key] = "conv_small_kernel<%d,%d>" % (r.value, nt.value)   # the narrow layers (stem): <C16, NT>
             return _SHAPE_CACHE[key]
         L.check(L.lib().efg_spconv_tile_shape(cin, cout, kvol, m_in, m_out, ctypes.byref(nt), ctypes.byref(r),
                                               ctypes.byref(ks)))

@@ -217,12 +217,13 @@ int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, co
  * stream is being captured into a HIP graph never uses stream-K (the launch epoch is a kernel argument: a replay would
  * read stale shares). */
 int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset);
-/* 1 when efg_spconv_forward_tiled_f32 runs a (cin -> cout, kvol) layer on conv_small_kernel<SPC, NT> (the narrow layers of a
- * stem: at most 32 reduction and 32 output channels; 16-byte aligned features and packed weights, default weight order):
- * a lane loads 16 bytes of ITS row and the registers are the MFMA operands, the layer's weights sit in LDS.  spc / nt (may
- * be null) receive the instantiation: reduction channels per lane group, 16-column output tiles.  EFG_CONV_SMALL=0
- * keeps every layer on conv_tile_kernel. */
-int efg_spconv_small_ok(int cin, int cout, int kvol, int* spc, int* nt);
+/* 1 when efg_spconv_forward_tiled_f32 runs a (cin -> cout, kvol) layer on conv_small_kernel<C16, NT, VEC> (the narrow layers
+ * of a stem: 16 or 32 reduction channels, or at most 8; at most 32 output channels and 28 offsets; 16-byte aligned features and
+ * packed weights, default weight order): a lane loads 16 bytes of ITS neighbour row, a 4 x 4 register transpose makes them
+ * the MFMA operands, the layer's packed weights sit in LDS -- and the sums are conv_tile_kernel's bit for bit.  c16 / nt
+ * (may be null) receive the instantiation: 16-channel groups of the reduction, 16-column output tiles.  EFG_CONV_SMALL=0
+ * (read per call) keeps every layer on conv_tile_kernel. */
+int efg_spconv_small_ok(int cin, int cout, int kvol, int* c16, int* nt);
 /* 1 when the split-precision arm of the tile kernel covers a (cin -> cout, kvol) convolution of these table sizes. */
 int efg_spconv_tile_bf16x3_ok(int cin, int cout, int kvol, int64_t m_in, int64_t m_out);
 

@@ -230,12 +230,46 @@ def test_narrow_layers_run_on_the_small_kernel(dev):
     from efg_amd import _lib as L
     from efg_amd.spconv import core
 
-    spc, nt = ctypes.c_int(), ctypes.c_int()
-    want = {(5, 16): (2, 1), (16, 16): (4, 1), (16, 32): (4, 2), (32, 16): (8, 1), (3, 8): (1, 1), (8, 32): (2, 2)}
+    c16, nt = ctypes.c_int(), ctypes.c_int()
+    want = {(5, 16): (1, 1), (16, 16): (1, 1), (16, 32): (1, 2), (32, 16): (2, 1), (3, 8): (1, 1), (8, 32): (1, 2)}
     for (cin, cout), inst in want.items():
-        assert L.lib().efg_spconv_small_ok(cin, cout, 27, ctypes.byref(spc), ctypes.byref(nt)) == 1, (cin, cout)
-        assert (spc.value, nt.value) == inst
+        assert L.lib().efg_spconv_small_ok(cin, cout, 27, ctypes.byref(c16), ctypes.byref(nt)) == 1, (cin, cout)
+        assert (c16.value, nt.value) == inst
+        core._SHAPE_CACHE.clear()
         assert core._tile_kernel_name(cin, cout, 27, 1000, 1000) == "conv_small_kernel<%d,%d>" % inst
     for cin, cout, kvol in [(32, 32, 27), (64, 32, 27), (16, 64, 27), (12, 16, 27), (16, 16, 29)]:
         assert L.lib().efg_spconv_small_ok(cin, cout, kvol, None, None) == 0, (cin, cout, kvol)
     assert core._tile_kernel_name(64, 64, 27, 1000, 1000).startswith("conv_tile_kernel<")
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 16), (3, 8), (8, 32)])
+@pytest.mark.parametrize("kind", ["subm", "strided", "column"])
+def test_small_kernel_bits_equal_tile_kernel(dev, monkeypatch, cin, cout, kind):
+    """conv_small_kernel reproduces conv_tile_kernel's sums BIT FOR BIT (same operand placement per MFMA, the tile's active
+    offsets dealt to four accumulators like the tile kernel's four split-K waves and added in its order; one accumulator
+    below 8 offsets): forward and input gradient with the switch on and off (read per call) are the same bits, so nothing
+    downstream -- goldens, tolerances, run-to-run digests -- moved when the narrow layers changed kernels."""
+    import efg_amd.spconv as spconv
+
+    rng = np.random.default_rng(cin * 31 + cout)
+    batch, shape = 2, (9, 36, 40)
+    idx, feat = random_sparse(rng, batch, shape, 9000, cin)
+    torch.manual_seed(cin + cout)
+    if kind == "subm":
+        conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=True, indice_key="k").to(dev)
+    elif kind == "strided":
+        conv = spconv.SparseConv3d(cin, cout, 3, 2, padding=1, bias=False).to(dev)
+    else:   # 3 offsets: the tile kernel does not split those over its waves
+        conv = spconv.SparseConv3d(cin, cout, (3, 1, 1), (2, 1, 1), padding=(1, 0, 0), bias=False).to(dev)
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("EFG_CONV_SMALL", sw)
+        x = _tensor(dev, idx, feat, batch, shape)
+        x.features.requires_grad_(True)
+        y = conv(x)
+        go = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(y.features.shape)).astype(np.float32)).to(dev)
+        y.features.backward(go)
+        outs[sw] = (y.features.detach().clone(), x.features.grad.clone())
+        conv.zero_grad()
+    assert torch.equal(outs["1"][0], outs["0"][0]), "forward bits differ"
+    assert torch.equal(outs["1"][1], outs["0"][1]), "dgrad bits differ"
