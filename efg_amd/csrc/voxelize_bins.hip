@@ -33,6 +33,10 @@
 // the worst case -- 19k workgroups, 5 % of them with work -- spent 20 us on dispatching the empty ones).
 #include "voxelize_common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace efg {
 namespace {
 
@@ -134,11 +138,17 @@ template <bool STAGE>
 __global__ void __launch_bounds__(256)
 vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords sw, int f, VoxGeom g, BinGeom bg,
                      unsigned* __restrict__ count, unsigned* __restrict__ pos, unsigned char* __restrict__ flags,
-                     unsigned long long* dbg) {
-  __shared__ __attribute__((aligned(16))) float stage[STAGE ? kTile * 8 + 8 : 4];
+                     unsigned* __restrict__ records, int record_words, unsigned long long* dbg) {
+  // the staged tile: kTile * f + 8 floats of dynamic LDS (sized by the launch for THIS row width: 20.5 KB at 5 features
+  // instead of the 32.8 KB of the widest staged row -- with the 16 KB of the aggregation table four workgroups per CU instead of three)
+  extern __shared__ __attribute__((aligned(16))) float stage[];
   __shared__ unsigned hkey[kAggSlots], hcnt[kAggSlots];
   mark(dbg, 0, 0);
   const int scene = blockIdx.y, tid = threadIdx.x;
+  // library-owned state (see VoxState): the look-back records of the two scans and the error word of THIS call, all used by
+  // later launches only, are zeroed here -- the counters are left zero by K2 of the previous call
+  if (records && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = tid; i < record_words; i += 256) records[i] = 0u;
   const long long beg = so.off[scene], end = so.off[scene + 1];
   const long long row0 = beg + (long long)blockIdx.x * kTile;
   const int nrows = (int)max(0ll, min((long long)kTile, end - row0));
@@ -210,10 +220,10 @@ vox_bin_count_kernel(const float* __restrict__ pts, SceneOffsets so, SceneWords 
 // K2 ------------------------------------------------------------------------------------------------------------
 // part[chunk] = 1 << 63 | chunk's points << 30 | big bins << 15 | small bins; 0 = not published yet.
 __global__ void __launch_bounds__(256)
-vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ count, unsigned long long* __restrict__ part,
+vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, unsigned* __restrict__ count, unsigned long long* __restrict__ part,
                     int nchunks, unsigned* __restrict__ basex, uint4* __restrict__ small_list,
                     uint4* __restrict__ big_list, unsigned* __restrict__ nlist, unsigned* __restrict__ err,
-                    unsigned long long* dbg) {
+                    int self_clean, unsigned long long* dbg) {
   __shared__ int smem[17];
   __shared__ unsigned long long s_w[4];
   mark(dbg, 1, 0);
@@ -227,6 +237,11 @@ vox_bin_scan_kernel(SceneOffsets so, BinGeom bg, const unsigned* __restrict__ co
   for (int x = 0; x < kXcd; ++x)
     v[x] = sc0 < bg.s_stride ? *reinterpret_cast<const uint4*>(count + xbase + (size_t)x * bg.s_stride + sc0)
                              : make_uint4(0, 0, 0, 0);
+  // library-owned counters (see bins_hard_voxelize): every counter is read exactly once, here -- and left zero for the next call
+  if (self_clean && sc0 < bg.s_stride) {
+#pragma unroll
+    for (int x = 0; x < kXcd; ++x) *reinterpret_cast<uint4*>(count + xbase + (size_t)x * bg.s_stride + sc0) = make_uint4(0, 0, 0, 0);
+  }
   tot[0] = tot[1] = tot[2] = tot[3] = 0u;
 #pragma unroll
   for (int x = 0; x < kXcd; ++x) {
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(256)
 vox_bin_scatter_kernel(const float* __restrict__ pts, SceneOffsets so, int f, VoxGeom g, BinGeom bg,
                        const unsigned* __restrict__ pos, const unsigned* __restrict__ basex, uint2* __restrict__ meta,
                        float* __restrict__ rows, int rs, unsigned long long* dbg) {
-  __shared__ __attribute__((aligned(16))) float stage[STAGE ? kTile * 8 + 8 : 4];
+  extern __shared__ __attribute__((aligned(16))) float stage[];   // kTile * f + 8 floats (see K1)
   const int scene = blockIdx.y, tid = threadIdx.x;
   mark(dbg, 2, 0);
   const long long beg = so.off[scene], end = so.off[scene + 1];
@@ -1000,6 +1015,47 @@ bool bins_layout(int64_t n_total, int batch, int f, const VoxGeom& g, BinsLayout
   return true;
 }
 
+// The words of a call that must be ZERO when it starts -- the per-XCD counters, the look-back records of the two scans, the
+// error word -- live in a buffer the LIBRARY owns per (device, stream): K2, the only reader of the counters, leaves them zero for
+// the next call, and K1 zeroes the few hundred words of records + error word that only later launches of its own call use -- so a
+// call needs no clear launch (7 -> 6 launches, ~4.5 us of a 2 x 180k call).  Allocated with hipMalloc + hipMemset on first use and when a call needs
+// more words than it holds (both synchronise: once per process and size); a call that fails between its launches leaves the
+// buffer marked dirty and the next call zeroes it with one asynchronous memset.  Calls on ONE
+// stream are issued by one thread at a time (as for stream-K, include/efg_hip.h).  While the stream is being CAPTURED into a HIP
+// graph the call takes its cleared words from the caller's workspace and clears them with vox_clear_kernel, as before (a
+// replay must not depend on what eager calls left behind, and the first-use allocation would invalidate the capture).
+// EFG_VOX_OWN_STATE=0: always the workspace + clear kernel (A/B).
+constexpr size_t kOwnRecordWords = 49152;   // >= the records of any call the binned path takes (<= 2^22 supercells, < 2^28 points)
+struct VoxState {
+  unsigned* words = nullptr;
+  size_t cap = 0;
+  bool dirty = true;
+};
+std::mutex g_vox_mu;
+std::map<std::pair<int, hipStream_t>, VoxState> g_vox_pool;
+
+int vox_state_for_stream(hipStream_t stream, size_t words, VoxState** out) {
+  int dev = 0;
+  EFG_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_vox_mu);
+  VoxState& st = g_vox_pool[std::make_pair(dev, stream)];
+  if (st.cap < words) {
+    if (st.words) EFG_HIP_TRY(hipFree(st.words));   // (synchronises: nothing of this stream still reads it)
+    st.words = nullptr;
+    st.cap = 0;
+    const size_t cap = align_up(words + words / 4, 1024);
+    EFG_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st.words), cap * sizeof(unsigned)));
+    st.cap = cap;
+    st.dirty = true;
+  }
+  if (st.dirty) {
+    EFG_HIP_TRY(hipMemsetAsync(st.words, 0, st.cap * sizeof(unsigned), stream));
+    st.dirty = false;
+  }
+  *out = &st;
+  return EFG_OK;
+}
+
 }  // namespace
 
 void bins_set_debug_timeline(unsigned long long* buf) { g_dbg = buf; }
@@ -1045,7 +1101,7 @@ int bins_hard_voxelize(const HardArgs& a) {
   const int nchunks2 = std::max(1, (int)ceil_div(max_words, 256));   // K4b: 256 words = 8192 points per workgroup
   const size_t part2_words = (size_t)(a.n_total / 8192 + 2) * batch;   // >= nchunks2 * batch
   const size_t cleared_words = L.s_total * kXcd + (size_t)L.nchunks * batch * 2 + part2_words + 4;   // (+ the error word)
-  unsigned* count = w.take<unsigned>(cleared_words);
+  unsigned* count = w.take<unsigned>(cleared_words);   // (the workspace keeps its layout whether or not these words are used)
   // (8-byte aligned: s_total is a multiple of 4)
   unsigned long long* part = count ? reinterpret_cast<unsigned long long*>(count + L.s_total * kXcd) : nullptr;
   unsigned* part2 = count ? count + L.s_total * kXcd + (size_t)L.nchunks * batch * 2 : nullptr;
@@ -1069,28 +1125,50 @@ int bins_hard_voxelize(const HardArgs& a) {
     return EFG_E_WORKSPACE;
   }
   const dim3 blk(256);
-  // (a kernel, not hipMemsetAsync: captured into a HIP graph the memset NODE of this call did not take effect on the second
-  // replay -- counters left dirty, wild offsets, "write access to a read-only page"; scripts/ubench/vox_graph_probe.py)
-  hipLaunchKernelGGL(vox_clear_kernel, dim3((unsigned)std::min<size_t>(ceil_div((int64_t)cleared_words, 1024), 1024)), blk, 0, stream,
-                     reinterpret_cast<unsigned*>(count), (size_t)cleared_words);
+  // the cleared words: the library's own, self-cleaning buffer of this stream (see VoxState) unless the stream is being captured
+  VoxState* own = nullptr;
+  {
+    const char* env = getenv("EFG_VOX_OWN_STATE");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing(stream, &cap);
+    const size_t record_words = cleared_words - L.s_total * kXcd;
+    if (cap == hipStreamCaptureStatusNone && !(env && atoi(env) == 0) && record_words <= kOwnRecordWords) {
+      // [records: kOwnRecordWords, zeroed by K1 of the call that uses them][counters: zero at rest].  The records sit at a
+      // FIXED place in front: behind the counters their offset would change with the grid and the batch, and the stale records
+      // of one call would be the next layout's counters.
+      if (int rc = vox_state_for_stream(stream, kOwnRecordWords + L.s_total * kXcd, &own)) return rc;
+      part = reinterpret_cast<unsigned long long*>(own->words);
+      part2 = own->words + (size_t)L.nchunks * batch * 2;
+      err = own->words + record_words - 4;
+      count = own->words + kOwnRecordWords;
+      own->dirty = true;   // until this call's last launch has been issued
+    }
+  }
+  if (!own) {
+    // (a kernel, not hipMemsetAsync: captured into a HIP graph the memset NODE of this call did not take effect on the second
+    // replay -- counters left dirty, wild offsets, "write access to a read-only page"; scripts/ubench/vox_graph_probe.py)
+    hipLaunchKernelGGL(vox_clear_kernel, dim3((unsigned)std::min<size_t>(ceil_div((int64_t)cleared_words, 1024), 1024)), blk, 0, stream,
+                       reinterpret_cast<unsigned*>(count), (size_t)cleared_words);
+  }
   const int tiles = (int)std::max<int64_t>(1, ceil_div(a.max_scene, kTile));
   const bool stage = f <= 8;
+  const size_t stage_bytes = stage ? sizeof(float) * ((size_t)kTile * f + 8) : 16;
   if (stage)
-    hipLaunchKernelGGL(vox_bin_count_kernel<true>, dim3(tiles, batch), blk, 0, stream, a.points, so, sw, f, a.g, L.bg, count,
-                       pos, flags, g_dbg);
+    hipLaunchKernelGGL(vox_bin_count_kernel<true>, dim3(tiles, batch), blk, stage_bytes, stream, a.points, so, sw, f, a.g, L.bg, count,
+                       pos, flags, own ? reinterpret_cast<unsigned*>(part) : nullptr, (int)(cleared_words - L.s_total * kXcd), g_dbg);
   else
-    hipLaunchKernelGGL(vox_bin_count_kernel<false>, dim3(tiles, batch), blk, 0, stream, a.points, so, sw, f, a.g, L.bg, count,
-                       pos, flags, g_dbg);
+    hipLaunchKernelGGL(vox_bin_count_kernel<false>, dim3(tiles, batch), blk, stage_bytes, stream, a.points, so, sw, f, a.g, L.bg, count,
+                       pos, flags, own ? reinterpret_cast<unsigned*>(part) : nullptr, (int)(cleared_words - L.s_total * kXcd), g_dbg);
   EFG_LAUNCH_CHECK();
   hipLaunchKernelGGL(vox_bin_scan_kernel, dim3(L.nchunks, batch), blk, 0, stream, so, L.bg, count, part, L.nchunks, basex,
-                     small_list, big_list, nlist, err, g_dbg);
+                     small_list, big_list, nlist, err, own ? 1 : 0, g_dbg);
   EFG_LAUNCH_CHECK();
   if (a.n_total > 0) {
     if (stage)
-      hipLaunchKernelGGL(vox_bin_scatter_kernel<true>, dim3(tiles, batch), blk, 0, stream, a.points, so, f, a.g, L.bg, pos,
+      hipLaunchKernelGGL(vox_bin_scatter_kernel<true>, dim3(tiles, batch), blk, stage_bytes, stream, a.points, so, f, a.g, L.bg, pos,
                          basex, meta, rows, L.rs, g_dbg);
     else
-      hipLaunchKernelGGL(vox_bin_scatter_kernel<false>, dim3(tiles, batch), blk, 0, stream, a.points, so, f, a.g, L.bg, pos,
+      hipLaunchKernelGGL(vox_bin_scatter_kernel<false>, dim3(tiles, batch), blk, stage_bytes, stream, a.points, so, f, a.g, L.bg, pos,
                          basex, meta, rows, L.rs, g_dbg);
     EFG_LAUNCH_CHECK();
   }
@@ -1121,6 +1199,7 @@ int bins_hard_voxelize(const HardArgs& a) {
 #undef EFG_VOX_WRITE
     EFG_LAUNCH_CHECK();
   }
+  if (own) own->dirty = false;   // every launch of the call is queued: the counters are zero again when K2 has run
   return EFG_OK;
 }
 

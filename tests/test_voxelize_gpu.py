@@ -206,6 +206,32 @@ def test_batched_cap_and_break_per_scene(dev, oracle_mod, impl):
     assert out["num_voxels"][0] == mv and out["num_voxels"][2] == mv and out["num_voxels"][1] < mv
 
 
+def test_library_state_survives_changing_layouts(dev, oracle_mod, monkeypatch):
+    """The binned path keeps its counters in a buffer the library owns per stream, left zero by the call itself (no clear
+    launch).  Calls whose grids / batches / sizes differ -- i.e. whose counters and look-back records sit at different offsets
+    -- alternate on one stream and every one of them is still bit-exact (the first version kept the records behind the
+    counters: the stale records of a small grid were the next, larger layout's counters)."""
+    from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
+    from efg_amd.operators import voxelize_batch
+
+    monkeypatch.setenv("EFG_VOX_IMPL", "bins")
+    rng = np.random.default_rng(11)
+    small = np.concatenate([rng.uniform(0, 6.4, (70000, 3)), rng.uniform(0, 1, (70000, 2))], 1).astype(np.float32)
+    waymo = [make_scene(950 + i, n_points=n)[0][:n] for i, n in enumerate([90000, 300, 120000, 70000, 2000])]
+    for rnd in range(2):
+        _check_vs_oracle(dev, oracle_mod, small, [0.1, 0.1, 0.1], [0.0, 0.0, 0.0, 6.4, 6.4, 6.4], 5, 50000)
+        out = voxelize_batch([torch.from_numpy(s).to(dev) for s in waymo], VOXEL_SIZE, PC_RANGE, 5, 30000)
+        base = 0
+        for b, s_ in enumerate(waymo):
+            ev, ec, en = oracle_mod.hard_voxelize(s_, VOXEL_SIZE, PC_RANGE, 5, 30000)
+            m = out["num_voxels"][b]
+            assert m == ev.shape[0]
+            assert np.array_equal(out["voxels"][base:base + m].cpu().numpy(), ev)
+            assert np.array_equal(out["coordinates"][base:base + m].cpu().numpy()[:, 1:], ec)
+            base += m
+        _check_vs_oracle(dev, oracle_mod, waymo[0], VOXEL_SIZE, PC_RANGE, 5, 120000)
+
+
 def test_full_size_both_implementations_agree(dev, impl, oracle_mod):
     from efg_amd.data.synthetic import PC_RANGE, VOXEL_SIZE, make_scene
 
