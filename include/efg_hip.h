@@ -78,6 +78,13 @@ size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int f, int 
  *   mean     f32 [batch*max_voxels, f] or NULL      fused VoxelMeanFeatureExtractor
  *                                                   (efg/modeling/readers/voxel_reader.py:14-19)
  * With batch == 1 and coors_cols == 3 this is exactly efg::hard_voxelize.
+ *
+ * Besides the caller's workspace the binned implementation owns a little device memory of its own, per (device, stream):
+ * its per-XCD counters and look-back records (a few MB: 8 words per BEV supercell + 192 KB), allocated with hipMalloc +
+ * hipMemset on first use, left ZERO by every call for the next one (so a call has no clear launch) and kept for the life
+ * of the process.  Calls on ONE stream must be issued by one thread at a time.  A call issued while its stream is being
+ * captured into a HIP graph takes those words from the workspace and clears them with a kernel instead (a replay must
+ * not depend on what eager calls left behind); EFG_VOX_OWN_STATE=0 does so always.
  */
 int efg_hard_voxelize_f32(const float* points, const int64_t* point_offsets_host, int batch, int f,
                           const float* voxel_size_host, const float* coors_range_host, int max_points,
