@@ -205,10 +205,11 @@ class SparseResNet(nn.Module):
         wanted = self._out_features if self.dense_features is None else [
             f for f in self._out_features if f in self.dense_features]
         outputs = {}
+        last = max((i for i, (_, n) in enumerate(self.stages_and_names) if n in wanted), default=-1)
+        self._prefetch_geometry(x, wanted, last)
         x = self.stem(x)
         if "stem" in wanted:
             outputs["stem"] = x
-        last = max((i for i, (_, n) in enumerate(self.stages_and_names) if n in wanted), default=-1)
         for i, (stage, name) in enumerate(self.stages_and_names):
             if i > last:
                 break
@@ -219,6 +220,37 @@ class SparseResNet(nn.Module):
             out = getattr(self, out_feature + "_out")(outputs[out_feature])
             outputs[out_feature] = out.dense_bev()  # == out.dense().view(n, c * d, h, w), channels-last memory
         return outputs
+
+    def _prefetch_geometry(self, x, wanted, last):
+        """The strided geometries of this forward pass, asked for up front (spconv.core.prefetch_downsample_chain): the first
+        strided convolution of the stem and of every stage that will run form a chain (submanifold layers keep the sites), the
+        z-collapsing heads branch off the levels they read."""
+        from ...spconv import core
+
+        def first_strided(module):
+            for m in module.modules():
+                if isinstance(m, SparseConv3d) and not m.subm and any(int(v) != 1 for v in m.stride):
+                    return (m.kernel_size, m.stride, m.padding)
+            return None
+
+        chain, level_of = [], {}
+        spec = first_strided(self.stem)
+        if spec is not None:
+            chain.append(spec)
+        level_of["stem"] = len(chain)
+        for i, (stage, name) in enumerate(self.stages_and_names):
+            if i > last:
+                break
+            spec = first_strided(stage)
+            if spec is not None:
+                chain.append(spec)
+            level_of[name] = len(chain)
+        branches = []
+        for name in wanted:
+            spec = first_strided(getattr(self, name + "_out"))
+            if spec is not None and name in level_of:
+                branches.append((level_of[name], spec))
+        core.prefetch_downsample_chain(x, chain, branches)
 
     def output_shape(self):
         return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])

@@ -749,6 +749,50 @@ def _downsample_geometry(x, ks, st, pad):
     return out_indices[:m_out], SiteIndex(oindex, None, x.batch_size, oshape_py), oshape_py
 
 
+class _Sites:
+    """What _downsample_geometry reads of a SparseConvTensor."""
+
+    def __init__(self, indices, spatial_shape, batch_size):
+        self.indices, self.spatial_shape, self.batch_size = indices, list(spatial_shape), batch_size
+
+
+def _t3(v):
+    return tuple(int(a) for a in v)
+
+
+def prefetch_downsample_chain(x, chain, branches=()):
+    """Output sites of a CHAIN of strided convolutions over x -- chain[i] = (kernel_size, stride, padding) applied to the sites
+    chain[i - 1] produced -- and of `branches` = [(level, (ks, st, pad)), ...] applied to the sites of chain level `level`
+    (0 = x itself), computed NOW, back to back, on the geometry stream; the convolutions pick them up from x.indice_dict
+    (SparseConvolution._rulebook checks that the sites it is given ARE the ones the entry was computed from).
+
+    Why: every level's site count is read back by the host (it sizes the level's tensors), and the read-back waits for
+    everything queued on the geometry stream before the level's marking kernel.  Built lazily, level by level, that is the
+    previous level's neighbour tables, tile plans and weight-gradient schedules (~300 us of kernels): ~1.2 ms of a step's host
+    time spent blocked, which IS step time on a loaded host (step = host issue time + ~2 ms there).  Asked for up front the
+    read-backs wait for one marking kernel each, and the plans queue up behind them.  Same kernels, same results; only the
+    order of issue on the geometry stream changes.  EFG_GEOM_PREFETCH=0: off (A/B)."""
+    if _GEO is None or os.environ.get("EFG_GEOM_PREFETCH", "1") == "0" or x.indices.shape[0] == 0:
+        return
+    with _on_geometry_stream(wait=False):
+        levels = [_Sites(x.indices, x.spatial_shape, x.batch_size)]
+        for spec in chain:
+            ks, st, pad = (_t3(v) for v in spec)
+            cur = levels[-1]
+            out_indices, out_si, oshape = _downsample_geometry(cur, ks, st, pad)
+            x.indice_dict[("geom", _t3(cur.spatial_shape), ks, st, pad)] = (cur.indices, out_indices, out_si, oshape)
+            if out_indices.shape[0] == 0:
+                return
+            levels.append(_Sites(out_indices, oshape, x.batch_size))
+        for level, spec in branches:
+            if level >= len(levels):
+                continue
+            ks, st, pad = (_t3(v) for v in spec)
+            cur = levels[level]
+            out_indices, out_si, oshape = _downsample_geometry(cur, ks, st, pad)
+            x.indice_dict[("geom", _t3(cur.spatial_shape), ks, st, pad)] = (cur.indices, out_indices, out_si, oshape)
+
+
 def _build_nbr(si_in, out_indices, m_out, ksize, stride, padding):
     kvol = ksize[0] * ksize[1] * ksize[2]
     nbr = torch.empty((kvol, max(m_out, 1)), dtype=torch.int32, device=out_indices.device)
@@ -882,7 +926,12 @@ class SparseConvolution(SparseModule):
             return x._conv_cache[key]
         with _on_geometry_stream() as main:
             si = x.site_index()
-            out_indices, out_site_index, oshape_py = _downsample_geometry(x, ks, st, pad)
+            pre = x.indice_dict.get(("geom", _t3(x.spatial_shape), _t3(ks), _t3(st), _t3(pad)))
+            if pre is not None and (pre[0] is x.indices or (pre[0].data_ptr() == x.indices.data_ptr() and pre[0].shape == x.indices.shape)):
+                # asked for up front (prefetch_downsample_chain), from THESE sites
+                _, out_indices, out_site_index, oshape_py = pre
+            else:
+                out_indices, out_site_index, oshape_py = _downsample_geometry(x, ks, st, pad)
             m_out = out_indices.shape[0]
             nbr = _build_nbr(si, out_indices, m_out, ks, st, pad)
             _hand_over(main, nbr, out_indices, out_site_index.index, si.index, si.perm)
