@@ -414,8 +414,10 @@ def main():
         "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
         "dist_backend": ("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if dist.is_initialized() else None,
         # N > 1 readiness: which exchange ran, every rank's own step time (the spread is the load imbalance between the
-        # ranks' scenes plus host jitter), and the time the slowest HOST needed to queue a step (the step is within a few
-        # ms of host-bound: value cannot drop below this)
+        # ranks' scenes plus host jitter), and the time the slowest HOST needed to queue a step.  NOTE: with the device a step
+        # behind, launches block on the full queue, so in steady state this reads (step - ~2 ms) on a device-bound box too; the
+        # host's own work is 20-24 ms per step (profiles/r05c_geom_prefetch.txt).  Only a value ABOVE the kernels' time per step
+        # means a host-bound step.
         "ddp_mode": trainer.ddp_mode,
         "rank_ms_per_step": {"min": round(min(stats["rank_ms_per_step"]), 3), "max": round(max(stats["rank_ms_per_step"]), 3),
                              "all": [round(t, 3) for t in stats["rank_ms_per_step"]]},
