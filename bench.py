@@ -49,9 +49,10 @@ def parse():
                          "`yaml_config` object times that)")
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra, untimed steps with per-kernel HIP events")
-    ap.add_argument("--soak-steps", type=int, default=0,
+    ap.add_argument("--soak-steps", type=int, default=300,
                     help="N > 0: after the timed run, N more optimizer steps on a 4-batch pool, then the step timed again -> the "
-                         "line's `steady_state` object (the encoder's boxes grow as training proceeds; 0 keeps the default run short)")
+                         "line's `steady_state` object (the encoder's boxes grow as training proceeds; the default is a ~10 s "
+                         "soak, 0 skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-arm", action="store_true", help="skip the third timing (bf16x3 split-precision A/B arm)")
     ap.add_argument("--no-full-graph", action="store_true", help="skip the second timing with the unused FPN levels")

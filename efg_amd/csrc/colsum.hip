@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace efg {
 namespace {
@@ -371,11 +372,32 @@ extern "C" int efg_relu_bwd_colsum_f32(const float* g, const float* y, int64_t r
   return EFG_OK;
 }
 
+// Health check of the ticket ring of the CURRENT device (the trainer's periodic anomaly check).  Two symptoms are counted:
+// (i) tickets drawn beyond a launch's block count (g_ticket_errors, seen by the kernels themselves), and (ii) ring words that
+// are not zero AT REST: a counter that starts a launch at 0 < k < nblocks makes the (nblocks - k)th block sum rows that are
+// not all written, resets the word, and the remaining k blocks leave it at k again -- no kernel can see that, so the whole
+// ring (32 KB) is read back after a device synchronise, when no launch that draws tickets is in flight (the caller's
+// contract: call it between steps), and every non-zero word is counted.  `reset` puts the ring and the counter back to rest.
 extern "C" int efg_ticket_ring_errors(int64_t* count_out, int reset) {
   EFG_CHECK_ARG(count_out != nullptr, "ticket_ring_errors: null output");
+  int dev = 0;
+  EFG_HIP_TRY(hipGetDevice(&dev));
+  EFG_HIP_TRY(hipDeviceSynchronize());   // (torch's streams are non-blocking: a copy on the null stream alone would not wait for them)
   unsigned v = 0;
-  EFG_HIP_TRY(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ticket_errors), sizeof(v)));   // (synchronises)
-  *count_out = v;
+  EFG_HIP_TRY(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ticket_errors), sizeof(v)));
+  int64_t residue = 0;
+  unsigned* ring = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ring_mu);
+    if (dev >= 0 && dev < 64) ring = g_ring[dev];
+  }
+  if (ring) {
+    std::vector<unsigned> host(kRing);
+    EFG_HIP_TRY(hipMemcpy(host.data(), ring, sizeof(unsigned) * kRing, hipMemcpyDeviceToHost));
+    for (unsigned w : host) residue += w != 0;
+    if (reset && residue) EFG_HIP_TRY(hipMemset(ring, 0, sizeof(unsigned) * kRing));
+  }
+  *count_out = (int64_t)v + residue;
   if (reset && v) {
     const unsigned zero = 0;
     EFG_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ticket_errors), &zero, sizeof(zero)));

@@ -1034,12 +1034,37 @@ struct VoxState {
 std::mutex g_vox_mu;
 std::map<std::pair<int, hipStream_t>, VoxState> g_vox_pool;
 
+constexpr size_t kVoxPoolMax = 32;   // (device, stream) entries kept; a process that keeps creating streams recycles them
+
 int vox_state_for_stream(hipStream_t stream, size_t words, VoxState** out) {
   int dev = 0;
   EFG_HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_vox_mu);
-  VoxState& st = g_vox_pool[std::make_pair(dev, stream)];
+  const auto key = std::make_pair(dev, stream);
+  // hipMalloc / hipFree below synchronise the device; under a capture in progress on ANOTHER stream (global capture mode) that
+  // would invalidate it: this thread's allocation calls run in relaxed mode, which the other thread's capture tolerates
+  struct RelaxedCapture {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool on = false;
+    void enter() {
+      if (!on) on = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    }
+    ~RelaxedCapture() {
+      if (on) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    }
+  } relaxed;
+  if (!g_vox_pool.count(key) && g_vox_pool.size() >= kVoxPoolMax) {
+    // streams that were destroyed (or are simply many): drop every other entry (hipFree synchronises, so no launch still
+    // reads a buffer that goes); a stream handle that is reused later starts from a fresh, zeroed buffer
+    relaxed.enter();
+    for (auto it = g_vox_pool.begin(); it != g_vox_pool.end();) {
+      if (it->second.words) (void)hipFree(it->second.words);
+      it = g_vox_pool.erase(it);
+    }
+  }
+  VoxState& st = g_vox_pool[key];
   if (st.cap < words) {
+    relaxed.enter();
     if (st.words) EFG_HIP_TRY(hipFree(st.words));   // (synchronises: nothing of this stream still reads it)
     st.words = nullptr;
     st.cap = 0;
@@ -1048,12 +1073,15 @@ int vox_state_for_stream(hipStream_t stream, size_t words, VoxState** out) {
     st.cap = cap;
     st.dirty = true;
   }
-  if (st.dirty) {
-    EFG_HIP_TRY(hipMemsetAsync(st.words, 0, st.cap * sizeof(unsigned), stream));
-    st.dirty = false;
-  }
+  if (st.dirty) EFG_HIP_TRY(hipMemsetAsync(st.words, 0, st.cap * sizeof(unsigned), stream));
+  st.dirty = true;   // until the call's last launch has been issued (vox_state_done)
   *out = &st;
   return EFG_OK;
+}
+
+void vox_state_done(VoxState* st) {   // every launch of the call is queued: the counters are zero again when K2 has run
+  std::lock_guard<std::mutex> lock(g_vox_mu);
+  st->dirty = false;
 }
 
 }  // namespace
@@ -1141,7 +1169,6 @@ int bins_hard_voxelize(const HardArgs& a) {
       part2 = own->words + (size_t)L.nchunks * batch * 2;
       err = own->words + record_words - 4;
       count = own->words + kOwnRecordWords;
-      own->dirty = true;   // until this call's last launch has been issued
     }
   }
   if (!own) {
@@ -1199,7 +1226,7 @@ int bins_hard_voxelize(const HardArgs& a) {
 #undef EFG_VOX_WRITE
     EFG_LAUNCH_CHECK();
   }
-  if (own) own->dirty = false;   // every launch of the call is queued: the counters are zero again when K2 has run
+  if (own) vox_state_done(own);
   return EFG_OK;
 }
 

@@ -10,6 +10,11 @@ FFN half, and autograd adds their gradients with separate element-wise kernels -
 [B, 35 344, 256] gradient (72 MB each) per layer.  Here the LayerNorm backward's `dz` IS the residual gradient, and
 each projection's data gradient is accumulated into it by its own GEMM (`addmm_`, beta = 1): no addition kernel, 144 MB
 of traffic less per accumulation, and one Python autograd node per half instead of six / four.
+
+The fused halves read the submodules' PARAMETERS and never call the submodules: forward / backward hooks registered on
+`value_proj`, `out_proj`, `linear1`, `linear2`, `norm1`, `norm2` do not fire while the single-node form is in use (the same
+holds for spconv.conv_bn_act and spconv.run_modules' conv + BatchNorm fusion).  EFG_FUSED_ENCODER=0 (EFG_FUSED_CONV_BN=0)
+restores the module-by-module form for code that depends on such hooks.
 """
 import os
 
@@ -116,7 +121,12 @@ def usable(layer, src, pos, ref_windows):
             and not (layer.training and (layer.dropout.p > 0 or layer.dropout1.p > 0 or layer.dropout2.p > 0))
             and attn.head_dim == 32 and attn.num_level * attn.num_point <= 32 and not ref_windows.requires_grad
             and ref_windows.dim() == 3 and src.shape[0] * src.shape[1] >= _lin._FUSED_MIN_ROWS and src.shape[-1] % 4 == 0
-            and (pos is None or pos.shape == src.shape)
+            and (pos is None or (pos.shape == src.shape and not pos.requires_grad))   # (backward returns no gradient for pos)
+            # what add_layer_norm and the addmm-with-bias products of the two halves assume of the modules
+            and all(n.elementwise_affine and n.weight is not None and n.bias is not None and n.normalized_shape[-1] <= 1024
+                    for n in (layer.norm1, layer.norm2))
+            and all(b is not None for b in (attn.value_proj.bias, attn.linear_attn_bias, attn.linear_box_bias,
+                                            attn.out_proj.bias, layer.linear1.bias, layer.linear2.bias))
             and all(p.requires_grad for p in (attn.value_proj.weight, attn.linear_attn_weight, attn.linear_box_weight,
                                               attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight)))
 

@@ -537,7 +537,8 @@ class Trainer:
             from . import _lib
 
             ring = ctypes.c_int64(0)
-            _lib.check(_lib.lib().efg_ticket_ring_errors(ctypes.byref(ring), 1))
+            with torch.cuda.device(self.model.device):   # the ring (and its error word) of THIS model's device
+                _lib.check(_lib.lib().efg_ticket_ring_errors(ctypes.byref(ring), 1))
             if ring.value:
                 raise RuntimeError("efg_amd: %d ticket counters of the fused column / focal sums were found not at rest at or "
                                    "before iteration=%d: bias gradients or loss sums since then are unreliable" % (

@@ -274,7 +274,7 @@ def build_sparse_resnet_backbone(config, in_channels):
     out_channels = _get(config, "res1_out_channels")
     num_blocks_per_stage = {18: [2, 2, 2, 2], "18b": [2, 2, 2, 2], "18c": [2, 2, 2, 2], 34: [3, 4, 6, 3],
                             "34b": [3, 4, 6, 3], "34c": [3, 4, 6, 3], 50: [3, 4, 6, 3]}[depth]
-    bottleneck = depth == 50   # (:380-387: basic blocks for 18 / 34, bottleneck blocks otherwise)
+    bottleneck = depth not in (18, "18b", "18c", 21, 34)   # (:380-387: basic blocks for these, bottleneck blocks otherwise -- "34b" / "34c" too)
     bottleneck_channels = _get(config, "num_groups") * _get(config, "width_per_group") if bottleneck else None
     max_stage_idx = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
     stages = []

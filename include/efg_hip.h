@@ -330,7 +330,9 @@ int efg_box_attn_fused_backward_f32(const float* value, const int64_t* shapes, c
 
 /* Column sums / split focal sums end inside their partial kernel: the block that draws the last ticket of a self-resetting
  * counter sums the partial rows.  A counter found beyond its launch's block count (a slot that was not at rest) is counted
- * on the device; this reads (and optionally clears) the count of the current device.  0 in a healthy process. */
+ * on the device; this call synchronises the CURRENT device, adds the number of ring words that are not zero at rest (a
+ * counter left at 0 < k < blocks, which no kernel can see) and optionally puts ring and count back to rest.  Call it
+ * between steps, with the device whose streams ran the sums current.  0 in a healthy process. */
 int efg_ticket_ring_errors(int64_t* count_out, int reset);
 
 /* The same two calls with ROW STRIDES (floats; 0 = dense) for the offsets and logits matrices and their gradients:
