@@ -55,6 +55,8 @@ _SIGS = {
     "efg_spconv_tile_plan": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_forward_tiled_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                              c_int64, c_int, c_void_p, c_void_p]),
+    "efg_spconv_tiled_pair_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                          c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_spconv_small_ok": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "efg_spconv_tile_bf16x3_ok": (c_int, [c_int, c_int, c_int, c_int64, c_int64]),
     "efg_spconv_streamk_fallbacks": (c_int, [c_void_p, c_int]),
@@ -69,6 +71,8 @@ _SIGS = {
     "efg_spconv_wgrad_sched": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "efg_spconv_wgrad_tiled_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efg_spconv_wgrad_tiled_pair_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "efg_sparse_to_dense_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_dense_to_sparse_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "efg_sparse_to_bev_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -167,6 +167,15 @@ struct TileArgs {
   int v4;                // 1: 16-byte gathers, natural-order packed weights (cin % 4 == 0)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
                          // the transposed table of a symmetric window is the table with the offsets reversed)
+  // PAIRS (efg_spconv_tiled_pair_f32): two convolutions over ONE table in one launch.
+  //   ny1 > 0 ("N pair", forward of a stage's main + shortcut convolution): the n-slices [0, ny1) multiply by `wp` and store
+  //     to `out`, the slices [ny1, 2 ny1) by `wp2` into `out2` -- per slice exactly what a launch of its own computes;
+  //   in2 != null ("K pair", their data gradient): the reduction runs over the channels of `in` (weights `wp`) and then over
+  //     those of `in2` (weights `wp2`), both cin wide: out = in (x) wp + in2 (x) wp2, accumulated in one pass.
+  const float* in2;
+  const float* wp2;
+  float* out2;
+  int ny1;
 };
 
 // 16 zero bytes every absent neighbour row (and every channel piece past cin) of the 16-byte gather points at
@@ -207,7 +216,10 @@ conv_tile_kernel(TileArgs a) {
   const long long t0 = ((long long)bx * WT + wt) * R;  // first 16-row tile of this wave tile
   const bool tile_ok = t0 < a.n_tiles;
   if (KS == 1 && !tile_ok) return;
-  const int n_tile0 = by * NT;
+  const bool second = a.ny1 > 0 && (int)by >= a.ny1;   // (N pair: this n-slice belongs to the second convolution; uniform)
+  const int n_tile0 = (second ? (int)by - a.ny1 : (int)by) * NT;
+  const float* wp_n = second ? a.wp2 : a.wp;
+  float* out_n = second ? a.out2 : a.out;
   float* at0 = a_tile[wv];
   int* nbs = nb_tile[wt];
 
@@ -270,7 +282,8 @@ conv_tile_kernel(TileArgs a) {
       acc[s][t] = f32x4{b, b, b, b};
     }
 
-  const int nchunk = (a.c16n * 16 + kCKt - 1) / kCKt;
+  const int nchunk1 = (a.c16n * 16 + kCKt - 1) / kCKt;
+  const int nchunk = a.in2 ? 2 * nchunk1 : nchunk1;   // (K pair: the chunks of `in`, then those of `in2`)
   float pre[V4 ? 1 : R * 16];
   unsigned pre_m[R];
 
@@ -298,7 +311,9 @@ conv_tile_kernel(TileArgs a) {
       }
       return;
     }
-    const unsigned cc4 = (unsigned)min(ch * kCKt + lane, a.cin - 1) * 4u;
+    const bool hi = __builtin_amdgcn_readfirstlane((int)(ch >= nchunk1)) != 0;   // (K pair, wave-uniform: the second operand's chunk)
+    const char* src = reinterpret_cast<const char*>(hi ? a.in2 : a.in);
+    const unsigned cc4 = (unsigned)min((hi ? ch - nchunk1 : ch) * kCKt + lane, a.cin - 1) * 4u;
 #pragma unroll
     for (int s = 0; s < R; ++s) {
       pre_m[s] = (unsigned)__builtin_amdgcn_readlane((int)vmr[s], col);
@@ -308,7 +323,7 @@ conv_tile_kernel(TileArgs a) {
         for (int j = 0; j < 16; ++j) offs[j] = (unsigned)nbs[s * 512 + col * 16 + j] + cc4;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          pre[s * 16 + j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.in) + offs[j]);
+          pre[s * 16 + j] = *reinterpret_cast<const float*>(src + offs[j]);
       }
     }
   };
@@ -342,10 +357,10 @@ conv_tile_kernel(TileArgs a) {
             (unsigned)(kk * 4)) * 4u;
   };
   const unsigned bstep = (unsigned)a.np * 64u;
-  auto load_b = [&](float4* b, unsigned boff0, int i) {
+  auto load_b = [&](float4* b, const float* wbase, unsigned boff0, int i) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.wp) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
+      b[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wbase) + boff0 + (unsigned)i * bstep + (unsigned)t * 1024u);
   };
   auto compute = [&](const float* at, int col, int ch, unsigned m0, unsigned m1) {
     if (BF3) {
@@ -387,9 +402,12 @@ conv_tile_kernel(TileArgs a) {
       }
       return;
     }
-    const int c16_lo = ch * (kCKt / 16);
+    const bool hi = __builtin_amdgcn_readfirstlane((int)(ch >= nchunk1)) != 0;   // (K pair: the second operand's weights, its own chunk numbering)
+    const int chl = hi ? ch - nchunk1 : ch;
+    const float* wbase = hi ? a.wp2 : wp_n;
+    const int c16_lo = chl * (kCKt / 16);
     const int m = lane & 15, kk = lane >> 4;
-    const unsigned boff0 = b_offset(col, ch);
+    const unsigned boff0 = b_offset(col, chl);
     const int nc = min(kCKt / 16, a.c16n - c16_lo);  // 16-channel steps of this chunk (4 unless the tail)
     auto mfmas = [&](const float4* b, int i) {
 #pragma unroll
@@ -416,18 +434,18 @@ conv_tile_kernel(TileArgs a) {
     // software pipeline over the (up to) four 16-channel steps: the weights of step i+1 are in flight during the
     // MFMAs of step i (they come from L2: ~200+ cycles, a 16-MFMA step is 512)
     float4 b0[NT], b1[NT];
-    load_b(b0, boff0, 0);
+    load_b(b0, wbase, boff0, 0);
     if (nc == 4 && a.pipe) {
-      load_b(b1, boff0, 1);
+      load_b(b1, wbase, boff0, 1);
       mfmas(b0, 0);
-      load_b(b0, boff0, 2);
+      load_b(b0, wbase, boff0, 2);
       mfmas(b1, 1);
-      load_b(b1, boff0, 3);
+      load_b(b1, wbase, boff0, 3);
       mfmas(b0, 2);
       mfmas(b1, 3);
     } else {
       for (int i = 0; i < nc; ++i) {
-        if (i > 0) load_b(b0, boff0, i);
+        if (i > 0) load_b(b0, wbase, boff0, i);
         mfmas(b0, i);
       }
     }
@@ -593,7 +611,7 @@ conv_tile_kernel(TileArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int j = s * 16 + (lane >> 4) * 4 + r;
         const int row = __shfl(prow, j, 64);
-        if (row >= 0 && co < a.cout) a.out[(long long)row * a.cout + co] = acc[s][t][r];
+        if (row >= 0 && co < a.cout) out_n[(long long)row * a.cout + co] = acc[s][t][r];
       }
     }
   };  // body
@@ -1038,8 +1056,13 @@ bool small_shape(int cin, int cout, int kvol, int* c16_out, int* nt_out) {
 }
 
 int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const float* bias, int cout, int kvol,
-              const void* plan, int64_t m_out, float* out, int flip, int natural_order, int bf3, hipStream_t stream) {
+              const void* plan, int64_t m_out, float* out, int flip, int natural_order, int bf3, hipStream_t stream,
+              const float* in2 = nullptr, const float* wp2 = nullptr, float* out2 = nullptr) {
   EFG_CHECK_ARG(cin >= 1 && cout >= 1, "spconv tiled: bad channel counts");
+  // pairs (TileArgs): wp2 + out2 = two convolutions of one input, wp2 + in2 = one convolution of two inputs
+  EFG_CHECK_ARG(!wp2 || ((in2 != nullptr) != (out2 != nullptr) && !bias && !natural_order && !bf3),
+                "spconv tiled pair: second weights need either a second input or a second output, no bias, the fp32 4-byte path");
+  EFG_CHECK_ARG(wp2 || (!in2 && !out2), "spconv tiled pair: second input / output without second weights");
   EFG_CHECK_ARG(!bf3 || (!natural_order && bf16x3_ok(cin, cout, kvol, m_in, m_out)),
                 "spconv tiled: the bf16x3 arm does not cover %d -> %d channels, kvol %d (ask efg_spconv_tile_bf16x3_ok)", cin,
                 cout, kvol);
@@ -1065,6 +1088,10 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.flip = flip;
   a.v4 = natural_order ? 1 : 0;
   a.bf3 = bf3 ? 1 : 0;
+  a.in2 = in2;
+  a.wp2 = wp2;
+  a.out2 = out2;
+  a.ny1 = 0;
   a.zero_off = 0;
   if (a.v4) {
     static const char* zero_piece[64] = {};  // per device: address of g_zero_piece
@@ -1083,7 +1110,7 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   {
     int c16 = 0, nt_s = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(wp) & 15) == 0;
-    if (small_shape(cin, cout, kvol, &c16, &nt_s) && !a.v4 && !a.bf3 && aligned) {
+    if (small_shape(cin, cout, kvol, &c16, &nt_s) && !a.v4 && !a.bf3 && aligned && !wp2) {
       const size_t lds = (size_t)kvol * c16 * nt_s * 1024 + (size_t)(kSmallThreads / 64) * kSmallKmax * 16 * sizeof(int);
       // as many workgroups as the device holds at once (up to 4 per CU; 2 with 55 KB of weights), a multiple of 8
       const long long fit = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)lds)) * 256;
@@ -1116,7 +1143,11 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   //  * NT = min(4, n-tiles): 64 output channels per wave, wider outputs tile over grid.y (each re-gathers A).
   int nt, r, ks, pipe;
   tile_shape(cin, cout, kvol, m_in, m_out, &nt, &r, &ks, &pipe);
-  const int ny = (ntiles + nt - 1) / nt;
+  int ny = (ntiles + nt - 1) / nt;
+  if (out2) {   // N pair: the second convolution's n-slices follow the first's in the unit grid
+    a.ny1 = ny;
+    ny *= 2;
+  }
   static const int deal_env = getenv("EFG_TILE_DEAL") ? atoi(getenv("EFG_TILE_DEAL")) : 1;
   a.pipe = pipe;
   a.deal = deal_env;
@@ -1201,6 +1232,15 @@ extern "C" int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, 
                                             int flip_offsets, float* out_feat, void* stream) {
   return run_tiles(in_feat, m_in, cin, packed_weight, bias, cout, kvol, plan, m_out, out_feat, flip_offsets & 1, (flip_offsets >> 1) & 1,
                    (flip_offsets >> 2) & 1, (hipStream_t)stream);
+}
+
+extern "C" int efg_spconv_tiled_pair_f32(const float* in_a, const float* in_b, int64_t m_in, int cin, const float* packed_a,
+                                         const float* packed_b, int cout, int kvol, const void* plan, int64_t m_out,
+                                         int flip_offsets, float* out_a, float* out_b, void* stream) {
+  EFG_CHECK_ARG(packed_a && packed_b && in_a && out_a, "spconv tiled pair: null pointer");
+  EFG_CHECK_ARG((flip_offsets & ~1) == 0, "spconv tiled pair: only the offset-flip flag is accepted");
+  return run_tiles(in_a, m_in, cin, packed_a, nullptr, cout, kvol, plan, m_out, out_a, flip_offsets & 1, 0, 0, (hipStream_t)stream,
+                   in_b, packed_b, out_b);
 }
 
 extern "C" int efg_spconv_streamk_fallbacks(int64_t* count_out, int reset) {

@@ -48,6 +48,11 @@ struct WgtArgs {
   int cin, cout, kvol;
   int cin_pad;          // row length of a partial block: cin, or 16 for a reduction width below 16 (the first layer's 5 / 6)
   int nci_blk;          // blocks along cin
+  // pair (efg_spconv_wgrad_tiled_pair_f32): the blocks [ny1, 2 ny1) of the launch are a SECOND layer of the same shape over the
+  // same input rows, plan and schedule -- its gradient rows `go2`, its workspace `partial2` (ny1 = 0: one layer)
+  const float* go2;
+  float* partial2;
+  int ny1;
 };
 
 // ---- schedule ---------------------------------------------------------------------------------------------------
@@ -251,7 +256,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int4 ent = a.entry[blockIdx.x];   // (the schedule: which offset, which tiles, which slot of the workspace)
   if (ent.x < 0) return;
-  const int k = ent.x, yb = blockIdx.y;
+  const bool second = a.ny1 > 0 && (int)blockIdx.y >= a.ny1;   // (uniform: the pair's second layer)
+  const int k = ent.x, yb = second ? (int)blockIdx.y - a.ny1 : (int)blockIdx.y;
+  const float* go = second ? a.go2 : a.go;
   const int co0 = (yb / a.nci_blk) * (NCO * 16), ci0 = (yb % a.nci_blk) * (NCI * 16);
   const int m = lane & 15, kk = lane >> 4;
   const int t_lo = ent.y, t_hi = ent.z;
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
       // 32-bit byte offsets (saddr + voffset loads; the host checks both tensors are below 4 GB)
       const unsigned ao = ((unsigned)max(ro[q], 0) * (unsigned)a.cout + (unsigned)(co0 + NCO * m)) * 4u;
       const unsigned bo = ((unsigned)max(rn[q], 0) * (unsigned)a.cin + (unsigned)min(ci0 + NCI * m, a.cin - NCI)) * 4u;
-      A[q] = *reinterpret_cast<const VA*>(reinterpret_cast<const char*>(a.go) + ao);
+      A[q] = *reinterpret_cast<const VA*>(reinterpret_cast<const char*>(go) + ao);
       B[q] = *reinterpret_cast<const VB*>(reinterpret_cast<const char*>(a.in) + bo);
       ok |= (rn[q] >= 0 ? 1u : 0u) << q;
     }
@@ -362,7 +369,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
   }
   __syncthreads();
   if (wv > 0) return;
-  float* p = a.partial + (long long)ent.w * a.cout * a.cin_pad;
+  float* p = (second ? a.partial2 : a.partial) + (long long)ent.w * a.cout * a.cin_pad;
   // C/D layout of 16x16x4: M = (lane >> 4) * 4 + reg, N = lane & 15; with the channel bijection of load_data
   // co = co0 + NCO * M + ct and ci = ci0 + NCI * N + it: a lane's NCI values of (ct, reg) are consecutive in memory
 #pragma unroll
@@ -384,10 +391,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_tile_kernel(WgtArgs a) {
 // (partial rows are cin_pad long: 16 for a reduction width below 16)
 __global__ void __launch_bounds__(256) wgt_reduce_kernel(const float* __restrict__ partial,
                                                           const int* __restrict__ kfirst, int kvol, int cout, int cin, int cin_pad,
-                                                          float* __restrict__ gw) {
+                                                          float* __restrict__ gw, const float* __restrict__ partial2,
+                                                          float* __restrict__ gw2) {
   __shared__ f32x4 sm[4][64];
   const long long blk = (long long)cout * cin_pad, per = (long long)kvol * blk;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (blockIdx.y) {   // (a pair's second layer: the same fold over its own workspace)
+    partial = partial2;
+    gw = gw2;
+  }
   const long long e = ((long long)blockIdx.x * 64 + lane) * 4;   // (k, co, ci); blk is a multiple of 256: k is block-uniform
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int k = 0;
@@ -508,10 +520,11 @@ extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, 
   return EFG_OK;
 }
 
-extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
-                                          int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,
-                                          size_t ws_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+int run_wgrad_tiled(const float* in_feat, int64_t m_in, int cin, const float* grad_out, const float* grad_out2, int64_t m_out,
+                    int cout, int kvol, const void* plan, const void* sched, float* grad_w, float* grad_w2, void* ws,
+                    size_t ws_bytes, hipStream_t stream) {
+  const bool pair = grad_out2 != nullptr;
   EFG_CHECK_ARG(wgt_ok(cin, cout, kvol), "spconv wgrad tiled: %d -> %d channels, kvol %d not covered (ask efg_spconv_wgrad_tiled_ok)",
                 cin, cout, kvol);
   EFG_CHECK_ARG(m_in >= 0 && m_out >= 0 && (unsigned long long)m_in * cin * 4ull < (1ull << 32) &&
@@ -520,16 +533,19 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   const size_t gw_bytes = (size_t)cout * kvol * cin * 4;
   if (m_out == 0 || m_in == 0) {
     EFG_HIP_TRY(hipMemsetAsync(grad_w, 0, gw_bytes, stream));
+    if (pair) EFG_HIP_TRY(hipMemsetAsync(grad_w2, 0, gw_bytes, stream));
     return EFG_OK;
   }
-  EFG_CHECK_ARG(plan && sched && in_feat && grad_out && grad_w, "spconv wgrad tiled: null pointer");
+  EFG_CHECK_ARG(plan && sched && in_feat && grad_out && grad_w && (!pair || grad_w2), "spconv wgrad tiled: null pointer");
   EFG_CHECK_ARG((reinterpret_cast<uintptr_t>(in_feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(grad_out2) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(plan) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(sched) & 15) == 0,
                 "spconv wgrad tiled: feature tensors, plan, schedule and workspace must be 16-byte aligned");
   const WgtLayout L = wgt_layout(m_out, cin, cout, kvol);
-  if (!ws || ws_bytes < L.bytes) {
-    set_error("spconv wgrad tiled workspace too small: need %zu bytes, got %zu", L.bytes + 256, ws_bytes);
+  const size_t need = pair ? 2 * align_up(L.bytes, 256) : L.bytes;
+  if (!ws || ws_bytes < need) {
+    set_error("spconv wgrad tiled workspace too small: need %zu bytes, got %zu", need + 256, ws_bytes);
     return EFG_E_WORKSPACE;
   }
   const PlanView pv = plan_view(const_cast<void*>(plan), m_out, kvol);
@@ -547,7 +563,10 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   a.kvol = kvol;
   a.cin_pad = wgt_cin_pad(cin);
   a.nci_blk = L.nci_blk;
-  const dim3 grid(sched_dispatch(L.slots), L.nco_blk * L.nci_blk);
+  a.go2 = grad_out2;
+  a.partial2 = pair ? reinterpret_cast<float*>(static_cast<char*>(ws) + align_up(L.bytes, 256)) : nullptr;
+  a.ny1 = pair ? L.nco_blk * L.nci_blk : 0;
+  const dim3 grid(sched_dispatch(L.slots), L.nco_blk * L.nci_blk * (pair ? 2 : 1));
   with_kernel(cin, cout, [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, a);
     return 0;
@@ -555,8 +574,25 @@ extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, in
   EFG_LAUNCH_CHECK();
   const long long per = (long long)kvol * cout * a.cin_pad;
   const int* kfirst = reinterpret_cast<const int*>(a.entry + sched_dispatch(L.slots));
-  hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 256)), dim3(256), 0, stream, a.partial, kfirst, kvol, cout,
-                     cin, a.cin_pad, grad_w);
+  hipLaunchKernelGGL(wgt_reduce_kernel, dim3((unsigned)ceil_div(per, 256), pair ? 2 : 1), dim3(256), 0, stream, a.partial, kfirst,
+                     kvol, cout, cin, a.cin_pad, grad_w, a.partial2, grad_w2);
   EFG_LAUNCH_CHECK();
   return EFG_OK;
+}
+}  // namespace
+
+extern "C" int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
+                                          int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,
+                                          size_t ws_bytes, void* stream_) {
+  return run_wgrad_tiled(in_feat, m_in, cin, grad_out, nullptr, m_out, cout, kvol, plan, sched, grad_w, nullptr, ws, ws_bytes,
+                         (hipStream_t)stream_);
+}
+
+extern "C" int efg_spconv_wgrad_tiled_pair_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out_a,
+                                               const float* grad_out_b, int64_t m_out, int cout, int kvol, const void* plan,
+                                               const void* sched, float* grad_w_a, float* grad_w_b, void* ws, size_t ws_bytes,
+                                               void* stream_) {
+  EFG_CHECK_ARG(grad_out_b && grad_w_b, "spconv wgrad tiled pair: null pointer");
+  return run_wgrad_tiled(in_feat, m_in, cin, grad_out_a, grad_out_b, m_out, cout, kvol, plan, sched, grad_w_a, grad_w_b, ws,
+                         ws_bytes, (hipStream_t)stream_);
 }

@@ -77,8 +77,18 @@ class SparseBasicResBlock(spconv.SparseModule):
         last = mods[-1]
         if type(self.activation) is nn.ReLU and isinstance(last, nn.BatchNorm1d):
             # relu(bn2(conv2(.)) + shortcut) as one fused op (operators/batchnorm.py) when the features are on the GPU
-            shortcut = self.shortcut(x) if self.shortcut is not None else x
-            pre = spconv.run_modules(mods[:-2], x)
+            pair = None
+            if self.shortcut is not None and self.stride != 1 and len(mods) == 5 and type(mods[2]) is nn.ReLU:
+                # the strided first convolution and the strided shortcut read the same input through the same rulebook: both
+                # products, their joint data gradient and both weight gradients as ONE launch each (spconv.conv_pair_bn_act)
+                sc = [m for m in self.shortcut._modules.values() if m is not None]
+                if len(sc) == 2:
+                    pair = spconv.conv_pair_bn_act(mods[0], mods[1], True, sc[0], sc[1], False, x)
+            if pair is not None:
+                pre, shortcut = pair
+            else:
+                shortcut = self.shortcut(x) if self.shortcut is not None else x
+                pre = spconv.run_modules(mods[:-2], x)
             # last convolution + norm + residual + ReLU as one autograd node where that applies (spconv.conv_bn_act)
             fused = spconv.conv_bn_act(mods[-2], pre, last, relu=True, residual=shortcut.features)
             if fused is not None:

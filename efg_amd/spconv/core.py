@@ -323,6 +323,55 @@ def _conv_wgrad(features, grad_out, rb):
     return grad_w
 
 
+def _pair_ok(rb, w_a, w_b, cin, cout):
+    """Can the two convolutions (weights [cout, kvol, cin] each) over `rb` run as the pair launches of csrc/spconv_tiles.hip /
+    spconv_wgt.hip?  (the tiled fp32 path with the default weight order; EFG_CONV_PAIR=0: two launches each, A/B)"""
+    return (os.environ.get("EFG_CONV_PAIR", "1") != "0" and _tiled() and rb.kvol <= 31 and rb.m_out > 0 and rb.m_in > 0
+            and w_a.shape == w_b.shape and not _natural_order(cin) and not _natural_order(cout)
+            and not _arm_bf16x3(cin, cout, rb.kvol, rb.m_in, rb.m_out) and not _arm_bf16x3(cout, cin, rb.kvol, rb.m_out, rb.m_in))
+
+
+def _conv_forward_pair(features, w_a, w_b, rb, owner_a, owner_b):
+    """(features (x) w_a, features (x) w_b) over one rulebook in ONE launch (efg_spconv_tiled_pair_f32, "N pair")."""
+    cout, kvol, cin = w_a.shape
+    pa, pb = _packed_weight(w_a, 0, owner_a), _packed_weight(w_b, 0, owner_b)
+    out_a = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
+    out_b = torch.empty_like(out_a)
+    plan = rb.plan_fwd()
+    with _prof.timed(_tile_kernel_name(cin, cout, kvol, rb.m_in, rb.m_out), _Cost(rb, cin, 2 * cout, "fwd pair")):
+        L.check(L.lib().efg_spconv_tiled_pair_f32(L.ptr(features), None, rb.m_in, cin, L.ptr(pa), L.ptr(pb), cout, kvol,
+                                                  L.ptr(plan), rb.m_out, 0, L.ptr(out_a), L.ptr(out_b), L.stream()))
+    return out_a, out_b
+
+
+def _conv_dgrad_pair(go_a, go_b, w_a, w_b, rb, owner_a, owner_b):
+    """dgrad(go_a, w_a) + dgrad(go_b, w_b) accumulated in ONE pass (efg_spconv_tiled_pair_f32, "K pair")."""
+    cout, kvol, cin = w_a.shape
+    pa, pb = _packed_weight(w_a, 1, owner_a), _packed_weight(w_b, 1, owner_b)
+    grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=go_a.device)
+    plan, flip = rb.plan_dgrad()
+    with _prof.timed(_tile_kernel_name(cout, cin, kvol, rb.m_out, rb.m_in), _Cost(rb, cin, 2 * cout, "dgrad pair")):
+        L.check(L.lib().efg_spconv_tiled_pair_f32(L.ptr(go_a), L.ptr(go_b), rb.m_out, cout, L.ptr(pa), L.ptr(pb), cin, kvol,
+                                                  L.ptr(plan), rb.m_in, flip, L.ptr(grad_in), None, L.stream()))
+    return grad_in
+
+
+def _conv_wgrad_pair(features, go_a, go_b, rb):
+    """The two weight gradients in one launch + one fold (efg_spconv_wgrad_tiled_pair_f32); bit-identical to two calls."""
+    lib = L.lib()
+    cin, cout, kvol = features.shape[1], go_a.shape[1], rb.kvol
+    plan, sched, ws_one = rb.plan_fwd(), *rb.wgrad_sched(cin, cout)
+    ws_bytes = 2 * ws_one + 512
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=go_a.device)
+    gw_a = torch.empty((cout, kvol, cin), dtype=torch.float32, device=go_a.device)
+    gw_b = torch.empty_like(gw_a)
+    with _prof.timed("conv_wgrad_tile_kernel+wgt_reduce_kernel", _Cost(rb, cin, 2 * cout, "wgrad pair")):
+        L.check(lib.efg_spconv_wgrad_tiled_pair_f32(L.ptr(features), rb.m_in, cin, L.ptr(go_a), L.ptr(go_b), rb.m_out, cout, kvol,
+                                                    L.ptr(plan), L.ptr(sched), L.ptr(gw_a), L.ptr(gw_b), L.ptr(ws), ws_bytes,
+                                                    L.stream()))
+    return gw_a, gw_b
+
+
 def _fwd_kernel_name(n_out_channels, n_rows, kvol=27):
     """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks (same rule)."""
     ntiles = (n_out_channels + 15) // 16
@@ -697,6 +746,87 @@ class _ConvBnActFunction(Function):
         conv = unpack(ctx, saved[:ctx.n_conv], "conv", (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False, False, False))
         grad_in, grad_w = _SparseConvFunction.backward(conv, dx)[:2]
         return grad_in, grad_w, None, None, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+class _ConvPairBnActFunction(Function):
+    """(relu?(bn_a(conv_a(x))), relu?(bn_b(conv_b(x)))) for TWO convolutions of one shape over one rulebook -- the main and the
+    shortcut SparseConv3d of a residual stage's first block (sparse_net.py:125-165) -- as ONE autograd node: one launch for
+    both forward products, one for the joint data gradient (the two gradients of x are never separate tensors, so nothing adds
+    them), one + one fold for both weight gradients; the BatchNorms are the kernels of operators/batchnorm.py."""
+
+    @staticmethod
+    def forward(ctx, features, w_a, w_b, rb, grad_on, ga, ba, rma, rva, nbta, moma, epsa, relu_a, gb, bb, rmb, rvb, nbtb, momb,
+                epsb, relu_b):
+        from .._fuse import Ctx, pack
+        from ..operators.batchnorm import BatchNormActFunction
+
+        features = features.contiguous()
+        cout, cin = w_a.shape[0], w_a.shape[-1]
+        wa, wb = w_a.reshape(cout, rb.kvol, cin).contiguous(), w_b.reshape(cout, rb.kvol, cin).contiguous()
+        out_a, out_b = _conv_forward_pair(features, wa, wb, rb, w_a, w_b)
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and grad_on:
+            rb.prepare_wgrad(cin, cout)
+        bna, bnb = Ctx(), Ctx()
+        ya = BatchNormActFunction.forward(bna, out_a, None, ga, ba, rma, rva, nbta, moma, epsa, relu_a)
+        yb = BatchNormActFunction.forward(bnb, out_b, None, gb, bb, rmb, rvb, nbtb, momb, epsb, relu_b)
+        ta, tb = pack(ctx, bna, "bna"), pack(ctx, bnb, "bnb")
+        ctx.n_a = len(ta)
+        ctx.save_for_backward(features, wa, wb, *ta, *tb)
+        ctx.rb, ctx.owners, ctx.wshape = rb, (w_a, w_b), w_a.shape
+        ctx.mark_non_differentiable(*[t for t in (rma, rva, nbta, rmb, rvb, nbtb) if t is not None])
+        return ya, yb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dya, dyb):
+        from .._fuse import unpack
+        from ..operators.batchnorm import BatchNormActFunction
+
+        saved = ctx.saved_tensors
+        features, wa, wb = saved[:3]
+        bna = unpack(ctx, saved[3:3 + ctx.n_a], "bna")
+        bnb = unpack(ctx, saved[3 + ctx.n_a:], "bnb")
+        dxa, _, dga, dba = BatchNormActFunction.backward(bna, dya)[:4]
+        dxb, _, dgb, dbb = BatchNormActFunction.backward(bnb, dyb)[:4]
+        rb = ctx.rb
+        grad_in = gwa = gwb = None
+        if ctx.needs_input_grad[0]:
+            grad_in = _conv_dgrad_pair(dxa, dxb, wa, wb, rb, *ctx.owners)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gwa, gwb = _conv_wgrad_pair(features, dxa, dxb, rb)
+            gwa, gwb = gwa.view(ctx.wshape), gwb.view(ctx.wshape)
+        return (grad_in, gwa, gwb, None, None, dga, dba, None, None, None, None, None, None, dgb, dbb, None, None, None, None,
+                None, None)
+
+
+def conv_pair_bn_act(conv_a, bn_a, relu_a, conv_b, bn_b, relu_b, x):
+    """(relu?(bn_a(conv_a(x))), relu?(bn_b(conv_b(x)))) -> two SparseConvTensors from ONE autograd node and one launch per
+    product, or None when that form does not apply (the caller then runs the two chains one after the other): two bias-free
+    strided SparseConv3d of the same shape and geometry, BatchNorms the fused kernels take, a layer the pair launches cover."""
+    if not (_CONV_BN_FUSED and isinstance(conv_a, SparseConvolution) and isinstance(conv_b, SparseConvolution)
+            and not conv_a.subm and not conv_b.subm and conv_a.bias is None and conv_b.bias is None
+            and conv_a.weight.shape == conv_b.weight.shape
+            and (conv_a.kernel_size, conv_a.stride, conv_a.padding) == (conv_b.kernel_size, conv_b.stride, conv_b.padding)
+            and x.features.is_cuda and x.features.dtype == torch.float32 and x.indices.shape[0] != 0
+            and conv_a.weight.requires_grad == conv_b.weight.requires_grad):
+        return None
+    c = conv_a.out_channels
+    for bn in (bn_a, bn_b):
+        if not (isinstance(bn, nn.BatchNorm1d) and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                and c % 4 == 0 and c <= 1024 and bn.num_features == c and os.environ.get("EFG_FUSED_BN", "1") != "0"):
+            return None
+    rb, geom = conv_a._rulebook(x)
+    cin = conv_a.in_channels
+    wa3 = conv_a.weight.reshape(c, rb.kvol, cin)
+    if rb.m_out < 2 or not _pair_ok(rb, wa3, wa3, cin, c) or not _wgrad_tiled(cin, c, rb.kvol, rb.m_out, rb.m_in):
+        return None
+    ya, yb = _ConvPairBnActFunction.apply(
+        x.features, conv_a.weight, conv_b.weight, rb, torch.is_grad_enabled(),
+        bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, bn_a.num_batches_tracked, bn_a.momentum, bn_a.eps, relu_a,
+        bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var, bn_b.num_batches_tracked, bn_b.momentum, bn_b.eps, relu_b)
+    out_indices, site_index, out_shape = geom
+    mk = lambda f: SparseConvTensor(f, out_indices, out_shape, x.batch_size, indice_dict=x.indice_dict, _site_index=site_index)  # noqa: E731
+    return mk(ya), mk(yb)
 
 
 _CONV_BN_FUSED = os.environ.get("EFG_FUSED_CONV_BN", "1") != "0"

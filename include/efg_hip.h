@@ -217,6 +217,20 @@ int efg_spconv_tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_o
 int efg_spconv_forward_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* packed_weight,
                                  const float* bias, int cout, int kvol, const void* plan, int64_t m_out,
                                  int flip_offsets, float* out_feat, void* stream);
+/* TWO convolutions over ONE table in one launch -- the main and the shortcut SparseConv3d of a residual stage's first block
+ * (efg/modeling/backbones/sparse_net.py:125-165: both read the block's input through the same strided rulebook), which as two
+ * launches are two ramps and two tails on a chip neither fills:
+ *   in_b == NULL, out_b != NULL ("N pair", the forward):  out_a = in_a (x) W_a,  out_b = in_a (x) W_b; the unit grid holds the
+ *     n-slices of both, each computed exactly as a launch of its own would (bit-identical to two efg_spconv_forward_tiled_f32
+ *     calls wherever those do not run stream-K; with stream-K the shares are cut over the joint item list);
+ *   in_b != NULL, out_b == NULL ("K pair", their data gradient):  out_a = in_a (x) W_a + in_b (x) W_b accumulated in ONE pass
+ *     over the reduction channels of in_a, then of in_b (both cin wide; packed_a / packed_b in the data-gradient layout, plan =
+ *     the plan of the transposed table): the sum two efg_spconv_forward_tiled_f32 calls and an addition kernel produce, to
+ *     fp32 rounding.
+ * Both operands [m_in][cin], both results [m_out][cout], default weight order, no bias.  flip_offsets as above (bit 0 only). */
+int efg_spconv_tiled_pair_f32(const float* in_a, const float* in_b, int64_t m_in, int cin, const float* packed_a,
+                              const float* packed_b, int cout, int kvol, const void* plan, int64_t m_out, int flip_offsets,
+                              float* out_a, float* out_b, void* stream);
 /* Stream-K's bounded wait (a share that does not arrive within EFG_TILE_SK_POLLS polls, ~20 ms: two processes
  * spinning on one device, a preempted queue) makes the owner RECOMPUTE the unit -- same sum, different order, twice the
  * work.  Every such event is counted on the device; this returns the count summed over the current device's streams
@@ -263,6 +277,13 @@ size_t efg_spconv_wgrad_tiled_workspace_bytes(int64_t m_out, int cin, int cout, 
 int efg_spconv_wgrad_tiled_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out, int64_t m_out,
                                int cout, int kvol, const void* plan, const void* sched, float* grad_w, void* ws,
                                size_t ws_bytes, void* stream);
+/* The weight gradients of TWO layers of one shape over the same input rows, plan and schedule (the pair above) in one launch +
+ * one fold: grad_w_a / grad_w_b are bit-identical to two efg_spconv_wgrad_tiled_f32 calls (same slots, same order).
+ * Workspace: 2 x efg_spconv_wgrad_tiled_workspace_bytes. */
+int efg_spconv_wgrad_tiled_pair_f32(const float* in_feat, int64_t m_in, int cin, const float* grad_out_a,
+                                    const float* grad_out_b, int64_t m_out, int cout, int kvol, const void* plan,
+                                    const void* sched, float* grad_w_a, float* grad_w_b, void* ws, size_t ws_bytes,
+                                    void* stream);
 
 /* SparseConvTensor.dense(): dense f32 [batch, c, D, H, W], fully written (zeros where inactive).
  * feat rows must be in canonical order (perm == NULL) or mapped through perm. */

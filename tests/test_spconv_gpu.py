@@ -273,3 +273,74 @@ def test_small_kernel_bits_equal_tile_kernel(dev, monkeypatch, cin, cout, kind):
         conv.zero_grad()
     assert torch.equal(outs["1"][0], outs["0"][0]), "forward bits differ"
     assert torch.equal(outs["1"][1], outs["0"][1]), "dgrad bits differ"
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (128, 256), (16, 64)])
+def test_pair_launch_equals_two_launches(dev, oracle_mod, cin, cout):
+    """The main + shortcut pair of a residual stage (sparse_net.py:125-165) in one launch per product
+    (efg_spconv_tiled_pair_f32 / efg_spconv_wgrad_tiled_pair_f32): the forward n-slices and both weight gradients are what the
+    two-launch form computes BIT FOR BIT (without stream-K: the joint item list cuts its shares elsewhere), the joint data
+    gradient is the sum of the two to fp32 rounding -- and all of it agrees with the fp64 oracle."""
+    import efg_amd.spconv as spconv
+    from efg_amd.spconv import core
+
+    rng = np.random.default_rng(cin * 13 + cout)
+    batch, shape = 2, (9, 40, 44)
+    idx, feat = random_sparse(rng, batch, shape, 12000, cin)
+    torch.manual_seed(cin + cout)
+    ca = spconv.SparseConv3d(cin, cout, 3, 2, padding=1, bias=False).to(dev)
+    cb = spconv.SparseConv3d(cin, cout, 3, 2, padding=1, bias=False).to(dev)
+    x = _tensor(dev, idx, feat, batch, shape)
+    rb = ca._rulebook(x)[0]
+    assert cb._rulebook(x)[0] is rb                       # one geometry for both
+    wa = ca.weight.detach().reshape(cout, rb.kvol, cin).contiguous()
+    wb = cb.weight.detach().reshape(cout, rb.kvol, cin).contiguous()
+    assert core._pair_ok(rb, wa, wb, cin, cout)
+    f = x.features
+    ya, yb = core._conv_forward(f, wa, None, rb, ca.weight), core._conv_forward(f, wb, None, rb, cb.weight)
+    pa, pb = core._conv_forward_pair(f, wa, wb, rb, ca.weight, cb.weight)
+    streamk = cin >= 128 and cout >= 128
+    if streamk:
+        torch.testing.assert_close(pa, ya, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(pb, yb, rtol=1e-5, atol=1e-5)
+    else:
+        assert torch.equal(pa, ya) and torch.equal(pb, yb), "forward pair differs from the two launches"
+    ga = torch.from_numpy(rng.standard_normal(tuple(ya.shape)).astype(np.float32)).to(dev)
+    gb = torch.from_numpy(rng.standard_normal(tuple(ya.shape)).astype(np.float32)).to(dev)
+    d2 = core._conv_dgrad(ga, wa, rb, ca.weight) + core._conv_dgrad(gb, wb, rb, cb.weight)
+    dp = core._conv_dgrad_pair(ga, gb, wa, wb, rb, ca.weight, cb.weight)
+    torch.testing.assert_close(dp, d2, rtol=1e-5, atol=2e-5)
+    nbr = rb.nbr.cpu().numpy()
+    ref = (oracle_mod.spconv_dgrad(ga.cpu().numpy(), wa.cpu().numpy(), nbr, feat.shape[0])
+           + oracle_mod.spconv_dgrad(gb.cpu().numpy(), wb.cpu().numpy(), nbr, feat.shape[0]))
+    np.testing.assert_allclose(dp.cpu().numpy(), ref, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(pb.cpu().numpy(), oracle_mod.spconv_forward(feat, wb.cpu().numpy(), None, nbr), rtol=1e-4, atol=1e-4)
+    wga, wgb = core._conv_wgrad(f, ga, rb), core._conv_wgrad(f, gb, rb)
+    wpa, wpb = core._conv_wgrad_pair(f, ga, gb, rb)
+    assert torch.equal(wpa, wga) and torch.equal(wpb, wgb), "weight-gradient pair differs from the two launches"
+
+
+def test_residual_stage_pair_node_matches_module_chain(dev, monkeypatch):
+    """SparseBasicResBlock(stride 2) with the pair node (EFG_CONV_PAIR=1, the default) against the chain of single fused
+    nodes (EFG_CONV_PAIR=0): outputs, running statistics and every gradient."""
+    from efg_amd.modeling.backbones.sparse_net import SparseBasicResBlock
+
+    rng = np.random.default_rng(3)
+    batch, shape = 2, (9, 40, 44)
+    idx, feat = random_sparse(rng, batch, shape, 12000, 32)
+    res = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("EFG_CONV_PAIR", sw)
+        torch.manual_seed(11)
+        blk = SparseBasicResBlock(32, 64, stride=2, norm="BN1d", activation={"type": "ReLU", "inplace": False}, indice_key="res2").to(dev).train()
+        x = _tensor(dev, idx, feat, batch, shape)
+        x.features.requires_grad_(True)
+        y = blk(x)
+        go = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(y.features.shape)).astype(np.float32)).to(dev)
+        y.features.backward(go)
+        res[sw] = ([y.features.detach().clone(), x.features.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+                   + [b.clone().float() for b in blk.buffers()])
+    assert len(res["1"]) == len(res["0"]) and len(res["1"]) > 10
+    for a, b in zip(res["1"], res["0"]):
+        scale = float(b.abs().max().clamp_min(1e-6))
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)
