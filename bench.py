@@ -298,6 +298,45 @@ def _rank_report(trainer, batch, world, dev):
     return {"rank_input_voxels": [int(t[0]) for t in every], "streamk_fallbacks": [int(t[1]) for t in every]}
 
 
+def _pin_rank(local_rank, world):
+    """N > 1: every rank's threads (Python main + autograd thread, ROCr's event thread: ~2 busy cores per rank, DESIGN.md
+    section 8) on a slice of the CPUs this process may use that no other rank of the node gets -- eight ranks otherwise
+    migrate over each other's cores.  A slice, not two cores: the scheduler keeps its freedom inside it (the boxes of this
+    pool are shared; pinning to fixed cores loses to whatever else runs there).  EFG_PIN_RANKS=0: off.  Returns the slice."""
+    if world <= 1 or os.environ.get("EFG_PIN_RANKS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    per = len(cpus) // max(local_world, 1)
+    if per < 2:
+        return None
+    mine = cpus[(local_rank % local_world) * per:(local_rank % local_world + 1) * per]
+    try:
+        for tid in os.listdir("/proc/self/task"):   # threads that exist already (the HIP runtime's); later ones inherit
+            try:
+                os.sched_setaffinity(int(tid), mine)
+            except OSError:
+                pass
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return [mine[0], mine[-1]]
+
+
+def _host_own_ms(trainer, pool, dev, steps=4):
+    """The host's OWN time to queue one step: issue time measured from EMPTY device queues (in steady state the launches
+    block on the full queue and `host_issue_ms_per_step` reads step - ~2 ms whatever the host needs).  Includes the blocking
+    site-count read-backs of the geometry stream, which wait for ~1 ms of device work."""
+    tot = 0.0
+    for s in range(steps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        trainer.step(pool[s % len(pool)])
+        tot += time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    return 1000.0 * tot / steps
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with one rank per
     GPU (what the reference's efg/engine/launch.py:52-57 does with mp.spawn), rendezvous on 127.0.0.1, rank 0 prints the
@@ -328,6 +367,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _self_launch(args.gpus)   # bare `python bench.py --gpus N`: start the N ranks ourselves
     rank, local_rank, world = init_distributed()
+    pinned = _pin_rank(local_rank, world)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
                          "or run `python bench.py --gpus %d` bare and it starts the ranks itself)"
@@ -425,6 +465,14 @@ def main():
         "host_issue_ms_per_step": round(stats["host_issue_ms_per_step"], 3),
     }
     line.update(_rank_report(trainer, pool[0], world, dev))
+    own = torch.tensor([_host_own_ms(trainer, pool, dev)], device=dev, dtype=torch.float64)
+    every = [own]
+    if world > 1:
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+    line["host_own_ms_per_step"] = [round(float(t[0]), 3) for t in every]   # per rank, from empty queues (see _host_own_ms)
+    line["rank_cpu_slice"] = pinned                                           # rank 0's [first, last] CPU, None = not pinned
+    line["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
     # ---- per-kernel numbers: extra steps, outside the timed region ------------------------------------------------
     if args.profile_steps > 0:
         _prof.enable(True)

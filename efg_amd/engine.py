@@ -80,16 +80,41 @@ def configure_hip_runtime():
     """Process-level HIP runtime settings of a TRAINING process (bench.py and Trainer call this; importing efg_amd
     does not touch the environment).
 
-    GPU_MAX_HW_QUEUES: the step uses three device queues at once -- the main stream, the high-priority geometry
-    stream (voxelization and sparse-conv site counts, whose read-backs the host waits on) and, with more than one
-    rank, RCCL's streams.  The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware
-    queues (default 4); once the RCCL communicator exists the geometry stream shares a hardware queue with other
-    work and its kernels wait behind unrelated ones: +1.4 ms/step with nothing else changed
-    (scripts/ubench/ddp_modes.py none vs none:comm: 35.4 -> 36.8 ms; 35.8 / 35.8 with 8 queues).  The runtime reads
-    the variable when it initialises, so this only has an effect before the first HIP call of the process; an
-    explicit setting in the environment wins.  Returns True if the setting can still take effect."""
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    GPU_MAX_HW_QUEUES: the HIP runtime multiplexes all streams of a process onto this many hardware queues.
+      * ONE rank (no collective beside backward): 8.  The step uses the main stream, the high-priority geometry stream
+        (voxelization and sparse-conv site counts, whose read-backs the host waits on) and the shared side stream; with the
+        runtime's default of 4 and a live communicator the geometry stream shared a queue with unrelated work: +1.4 ms/step
+        (scripts/ubench/ddp_modes.py none vs none:comm: 35.4 -> 36.8 ms; 35.8 / 35.8 with 8 queues).
+      * MORE than one rank over RCCL: 2.  A collective that runs BESIDE backward -- the bucketed, overlapped exchange that
+        `north_star` and the reference's DDP reducer ask for -- doubles the step with 8 queues on this stack (bucket 61-66 ms,
+        torch DDP static_graph 72 ms against 31.3 flat; measured in rounds 2, 4, 5 and 6), and does NOT with 2 or 3: flat
+        31.3-31.4, bucket 31.5-31.7 (profiles/r05d_ddp_modes_hw_queues.txt), and there it hides wire time --
+        scripts/ubench/ddp_overlap_probe.py adds a spin kernel of the all-reduce's length behind every collective: 3 ms of
+        simulated wire per step cost the flat exchange +2.9 ms and the bucketed one +1.4 (profiles/r06_ddp_overlap_probe.txt).
+        The flat exchange itself loses nothing at 2 queues.
+    The runtime reads the variable when it initialises, so this only has an effect before the first HIP call of the
+    process; an explicit setting in the environment wins.  Returns True if the setting can still take effect."""
+    try:
+        world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    except ValueError:
+        world = 1
+    rccl = os.environ.get("EFG_DIST_BACKEND", "nccl") == "nccl"
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if world > 1 and rccl else "8")
     return not torch.cuda.is_initialized()
+
+
+def default_ddp_mode():
+    """The gradient exchange a Trainer uses when neither its argument nor EFG_DDP_MODE names one: `bucket` (three all-reduces
+    issued DURING backward, overlapped with it) over RCCL when the process runs with the few hardware queues that make a
+    collective beside backward safe (configure_hip_runtime sets 2 for WORLD_SIZE > 1), else `flat` (one all-reduce after
+    backward: gloo, or a process whose environment pinned more queues)."""
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and queues <= 3:
+        return "bucket"
+    return "flat"
 
 
 def limit_host_threads():
@@ -446,19 +471,18 @@ class Trainer:
         self.grad_sync = None
         self.ddp_mode = None
         if use_ddp:
-            # "flat" (default): one all-reduce of a flat gradient buffer after backward (FlatGradientAllReduce).
-            # "bucket": three flat buckets, each all-reduced on a communication stream as soon as backward has produced it --
-            # the exchange OVERLAPS backward, as the reference's DDP reducer does (efg/engine/trainer.py:191-198) and
-            # BASELINE.json's north_star asks (BucketedGradientAllReduce).  NOT the default: with a live RCCL communicator
-            # and the 8 hardware queues the step otherwise wants, collectives that run beside backward double the step on
-            # this stack (1 rank, no wire: bucket 68-71 ms, torch DDP static_graph 72 ms, flat 32.3 ms; with
-            # GPU_MAX_HW_QUEUES=2 bucket 32.6 / flat 32.8; profiles/r04_ddp_modes_hw_queues.txt) -- until a multi-GPU node
-            # says otherwise the exchange that cannot run beside anything is the safe one.
+            # "bucket" (the default over RCCL, default_ddp_mode): three flat buckets, each all-reduced on a communication
+            # stream as soon as backward has produced it -- the exchange OVERLAPS backward, as the reference's DDP reducer
+            # does (efg/engine/trainer.py:191-198) and BASELINE.json's north_star asks (BucketedGradientAllReduce).  It
+            # needs the process to run with 2-3 hardware queues (configure_hip_runtime does that for WORLD_SIZE > 1): with
+            # 8, a collective beside backward doubles the step on this stack.
+            # "flat" (gloo, or more hardware queues pinned by the environment): one all-reduce of a flat gradient buffer
+            # after backward (FlatGradientAllReduce).
             # "static" / "find_unused" / "plain": torch DistributedDataParallel as in the reference, with
             # static_graph=True / find_unused_parameters=True ($CQ/config.yaml:183) / neither.  The literal
             # find_unused_parameters setting costs +14 ms/step: with locally unused parameters (the skipped FPN
             # levels) DDP makes a BLOCKING D2H copy of its "used" bitmap at the end of every backward.
-            mode = ddp_mode or os.environ.get("EFG_DDP_MODE", "flat")
+            mode = ddp_mode or os.environ.get("EFG_DDP_MODE") or default_ddp_mode()
             self.ddp_mode = mode
             if mode == "bucket" and not hasattr(self.model, "grad_watch"):
                 mode = self.ddp_mode = "flat"   # a model without the bucket hooks (CenterPoint, TrajectoryFormer)

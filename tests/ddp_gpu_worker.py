@@ -13,7 +13,7 @@ from efg_amd.engine import Trainer, init_distributed, synthetic_batch  # noqa: E
 rank, local_rank, world = init_distributed()
 dev = torch.device("cuda", torch.cuda.current_device())   # gloo: both ranks on cuda:0; RCCL: one device per rank
 ov = {"model.transformer.num_queries": 60, "model.transformer.enc_layers": 1, "model.transformer.dec_layers": 2}
-tr = Trainer(device=dev, overrides=ov, seed=0, ddp=True, max_iters=50)   # exchange: EFG_DDP_MODE, default flat
+tr = Trainer(device=dev, overrides=ov, seed=0, ddp=True, max_iters=50)   # exchange: EFG_DDP_MODE (default: flat over gloo, bucket over RCCL)
 tr.model.noise_generator = torch.Generator().manual_seed(100 + rank)
 for it in range(3):
     batch = synthetic_batch(700 + 10 * it + rank, 1, n_points=30000, n_boxes=12, device=dev)  # different scenes per rank

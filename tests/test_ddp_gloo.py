@@ -90,3 +90,20 @@ def test_two_rank_flat_and_bucketed_exchange_agree(oracle_mod):
 @pytest.mark.timeout(900)
 def test_two_rank_torch_ddp_wrapper(oracle_mod):
     _run("static")
+
+
+def test_exchange_defaults_follow_the_launch_environment(monkeypatch):
+    """N > 1 over RCCL: two hardware queues (a collective beside backward doubles the step with eight on this stack) and then
+    the overlapped bucket exchange; one rank, or gloo: eight queues and the flat exchange; an explicit setting always wins."""
+    from efg_amd import engine
+
+    for env, want in (({"WORLD_SIZE": "8"}, "2"), ({"WORLD_SIZE": "1"}, "8"), ({}, "8"),
+                      ({"WORLD_SIZE": "8", "EFG_DIST_BACKEND": "gloo"}, "8"), ({"WORLD_SIZE": "8", "GPU_MAX_HW_QUEUES": "5"}, "5")):
+        for k in ("WORLD_SIZE", "EFG_DIST_BACKEND", "GPU_MAX_HW_QUEUES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        engine.configure_hip_runtime()
+        assert os.environ["GPU_MAX_HW_QUEUES"] == want, (env, os.environ["GPU_MAX_HW_QUEUES"])
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    assert engine.default_ddp_mode() == "flat"      # no process group (and gloo would say the same): never the RCCL default

@@ -52,13 +52,15 @@ def _check_line(r, mode="flat", backend="gloo"):
     assert 0 < line["host_issue_ms_per_step"] <= line["ms_per_step"] * 1.001
     assert len(line["rank_input_voxels"]) == 2 and min(line["rank_input_voxels"]) > 1000
     assert len(line["streamk_fallbacks"]) == 2 and min(line["streamk_fallbacks"]) >= 0
+    assert len(line["host_own_ms_per_step"]) == 2 and min(line["host_own_ms_per_step"]) > 0   # per rank, from empty queues
     return line
 
 
 @pytest.mark.parametrize("mode", [None, "bucket"])
 def test_bench_two_ranks_one_gpu(dev, mode):
-    """launched exactly as the driver launches N > 1: under torch.distributed.run; default exchange = flat (one all-reduce
-    after backward; the overlapped bucket exchange is selectable)"""
+    """launched exactly as the driver launches N > 1: under torch.distributed.run; over gloo (two ranks on one device) the
+    default exchange is flat (one all-reduce after backward); over RCCL it is the overlapped bucket exchange
+    (engine.default_ddp_mode; test_rccl_two_ranks_when_the_node_has_two_devices)"""
     args = ["bench.py"] + _BENCH_ARGS + (["--ddp-mode", mode] if mode else [])
     _check_line(_torchrun(args, None), mode or "flat")
 
@@ -84,6 +86,9 @@ def test_rccl_two_ranks_when_the_node_has_two_devices():
     for mode in ("bucket", "flat"):
         line = _check_line(_torchrun(["bench.py"] + _BENCH_ARGS + ["--ddp-mode", mode], None, backend="nccl"), mode, "rccl")
         assert line["streamk_fallbacks"] == [0, 0]     # one process per device: a share is never late
+    # the default over RCCL: two hardware queues and the overlapped exchange (engine.configure_hip_runtime / default_ddp_mode)
+    line = _check_line(_torchrun(["bench.py"] + _BENCH_ARGS, None, backend="nccl"), "bucket", "rccl")
+    assert line["hw_queues"] == "2" and len(line["host_own_ms_per_step"]) == 2
     r = _torchrun(["tests/ddp_gpu_worker.py"], "bucket", backend="nccl")
     assert "DDP_GPU_OK" in r.stdout and "nan_step_skipped_on_all_ranks=1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
