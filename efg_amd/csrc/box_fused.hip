@@ -841,6 +841,427 @@ box_bwd_tile_kernel(const float* __restrict__ value, const long long* __restrict
   }  // tile loop
 }
 
+// ---- the same backward as TWO kernels (round 6) -------------------------------------------------------------------------------
+// box_bwd_tile_kernel holds, per 4 x 8-query tile, the value window, the grad_out tile, G / W, two softmax tables AND the
+// (cell, weight) pairs of pass A for pass B in registers: 256 VGPRs + 68 KB of LDS = two waves per SIMD, which issue a third
+// of their life (SQ counters, profiles/r05c_pmc_box_bwd_tile_*.txt): latency-bound, and three re-mappings of the same tile
+// did not change that.  Split along its only internal boundary, each half fits FOUR waves per SIMD:
+//   box_bwd_tile_a_kernel  S0 + S1 + pass A: G = GO . V^T, gradients of the offsets and logits.  G is written over the value
+//                          window (every wave holds its G blocks in registers until all reads of V are done): 40 KB of LDS.
+//                          No colour classes -- it writes nothing that overlaps -- so ONE launch over all tiles.
+//   box_bwd_tile_b_kernel  softmax + geometry again (a few hundred VALU instructions per tile against two fewer waves), the
+//                          W scatter in the order of the one-kernel form, GV = W . GO, window flush: 37 KB of LDS; per
+//                          colour class (plain read-modify-write) or one launch with atomics, as before.
+// Same arithmetic in the same order per element: grad_value / grad_offsets / grad_logits are the one-kernel form's bit for bit
+// (tests/test_box_fused_gpu.py::test_split_backward_bits_equal_one_kernel).  EFG_BOX_SPLIT=0: the one-kernel form (A/B).
+namespace bt {
+template <int TQY>
+constexpr size_t lds_bytes_a() {
+  using B = BT<TQY>;
+  constexpr int kVG = (B::NC * B::VS > B::NQ * B::GS) ? B::NC * B::VS : B::NQ * B::GS;
+  return sizeof(float) * (kVG + B::NQ * B::VS + 2 * B::NQ * PMAX + 2 * PMAX);
+}
+template <int TQY>
+constexpr size_t lds_bytes_b() {
+  using B = BT<TQY>;
+  return sizeof(float) * (B::NC * B::WS + B::NQ * B::VS + B::NQ * PMAX + 2 * PMAX);
+}
+}  // namespace bt
+
+template <int TQY>
+__global__ void __launch_bounds__(BT<TQY>::kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+box_bwd_tile_a_kernel(const float* __restrict__ value, const long long* __restrict__ shapes, const float* __restrict__ ref,
+                      const float* __restrict__ off, const float* __restrict__ logits, const float* __restrict__ kidx,
+                      const float* __restrict__ grad_out, BoxDims dm, float* __restrict__ grad_off,
+                      float* __restrict__ grad_logits) {
+  using B = BT<TQY>;
+  constexpr int TQX = B::TQX, R = B::R, WINY = B::WINY, WINX = B::WINX, NQ = B::NQ, NC = B::NC, D = B::D, VS = B::VS, GS = B::GS,
+                kThreads = B::kThreads, PMAX = bt::PMAX;
+  constexpr int kVG = (NC * VS > NQ * GS) ? NC * VS : NQ * GS;
+  extern __shared__ float lds[];
+  float* VG = lds;                     // V [NC][VS] in S0 / S1, then G [NQ][GS]
+  float* GOs = VG + kVG;               // [NQ][VS]
+  float* a_s = GOs + NQ * VS;          // [NQ][PMAX] un-normalised softmax weights
+  float* ga_s = a_s + NQ * PMAX;       // [NQ][PMAX]
+  float* k_s = ga_s + NQ * PMAX;       // [PMAX][2]
+  const int Hm = (int)shapes[0], Wm = (int)shapes[1];
+  if ((long long)Hm * Wm != dm.s) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2 * dm.p) k_s[tid] = kidx[tid];
+  const int slot = tid >> 3, sub = tid & 7, corner = sub & 3, half = sub >> 2;
+  const int m = blockIdx.y, bi = blockIdx.z;
+  const int np = dm.p;
+  const int tiles_x = (Wm + TQX - 1) / TQX, tiles_y = (Hm + TQY - 1) / TQY;
+  const int ntiles = tiles_x * tiles_y;
+  const long long S = dm.s;
+  constexpr int VPT = NC * (D / 4) / kThreads;
+  constexpr int EPT = PMAX / 2;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
+    const int wy0 = ty0 - R, wx0 = tx0 - R;
+    __syncthreads();  // the previous tile is done with the LDS
+    // ---- S0: global -> LDS (four workgroups per CU: the others' phases hide these loads) -------------------------
+    {
+      float4 v[VPT];
+#pragma unroll
+      for (int it = 0; it < VPT; ++it) {
+        const int idx = tid + it * kThreads;
+        const int cell = idx >> 3, c4 = (idx & 7) * 4;
+        const int cy = min(max(wy0 + cell / WINX, 0), Hm - 1), cx = min(max(wx0 + cell % WINX, 0), Wm - 1);
+        v[it] = ld4(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + c4);
+      }
+#pragma unroll
+      for (int it = 0; it < VPT; ++it) {
+        const int idx = tid + it * kThreads;
+        const int cell = idx >> 3, c4 = (idx & 7) * 4;
+        const int cy = wy0 + cell / WINX, cx = wx0 + cell % WINX;
+        const bool in = cy >= 0 && cy < Hm && cx >= 0 && cx < Wm;
+        *reinterpret_cast<float4*>(VG + cell * VS + c4) = in ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const int qy = ty0 + slot / TQX, qx = tx0 + slot % TQX;
+    const bool qok = qy < Hm && qx < Wm;
+    const long long bqs = qok ? ((long long)bi * dm.lq + (long long)qy * Wm + qx) : 0;
+    const long long t = bqs * dm.h + m;
+    {
+      const int qyc = min(qy, Hm - 1), qxc = min(qx, Wm - 1);
+      const long long bqc = (long long)bi * dm.lq + (long long)qyc * Wm + qxc;
+      const float4 go = ld4(grad_out + (bqc * dm.h + m) * D + sub * 4);
+      *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? go : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float lgv[4], rf[5], of[5];
+    {
+      const int qyc = min(qy, Hm - 1), qxc = min(qx, Wm - 1);
+      const long long bqc = (long long)bi * dm.lq + (long long)qyc * Wm + qxc;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lgv[k] = logits[bqc * dm.lg_rs + m * np + min(sub + 8 * k, np - 1)];
+      const float* r = ref + bqc * 7;
+      rf[0] = r[0], rf[1] = r[1], rf[2] = r[3], rf[3] = r[4], rf[4] = r[6];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) of[k] = off[bqc * dm.off_rs + m * dm.v + min(k, dm.v - 1)];
+    }
+    float* as = a_s + slot * PMAX;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) mx = fmaxf(mx, lgv[k]);
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) {
+        const float ex = expf(lgv[k] - mx);
+        as[sub + 8 * k] = ex;
+        den += ex;
+      }
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) den += __shfl_xor(den, dlt, 64);
+    const float inv = 1.0f / den;
+    const BoxGeo g = make_box_v(rf, of, dm.v);
+    __syncthreads();
+
+    // ---- S1: G = GO . V^T, the wave's blocks kept in registers until every wave has read its part of V --------------
+    {
+      const int mb = wave / B::WPM, nb0 = (wave % B::WPM) * B::NBW;
+      const int r16 = lane & 15, kk = lane >> 4;
+      float a[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) a[ks] = GOs[(16 * mb + r16) * VS + 4 * ks + kk];
+      f32x4 acc[B::NBW];
+#pragma unroll
+      for (int nbi = 0; nbi < B::NBW; nbi += 2) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* b0 = VG + (16 * (nb0 + nbi) + r16) * VS + kk;
+        const float* b1 = b0 + 16 * VS;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b0[4 * ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b1[4 * ks], acc1, 0, 0, 0);
+        }
+        acc[nbi] = acc0;
+        acc[nbi + 1] = acc1;
+      }
+      __syncthreads();   // V is dead: G goes over it
+#pragma unroll
+      for (int nbi = 0; nbi < B::NBW; ++nbi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) VG[(16 * mb + 4 * kk + r) * GS + 16 * (nb0 + nbi) + r16] = acc[nbi][r];
+    }
+    __syncthreads();
+
+    // ---- S2 (pass A), as in box_bwd_tile_kernel -----------------------------------------------------------------
+    float dcx = 0.f, dcy = 0.f, dw = 0.f, dh = 0.f, dth = 0.f, dot = 0.f;
+    const int cyo = corner >> 1, cxo = corner & 1;
+#pragma unroll 1
+    for (int j = 0; j < EPT / 4; ++j) {
+      const int op = half + 2 * (4 * j + corner);
+      const bool own = qok && op < np;
+      const float kxn = own ? k_s[op * 2] : 0.f, kyn = own ? k_s[op * 2 + 1] : 0.f;
+      const BoxPx px = box_point(g, kxn, kyn, Hm, Wm);
+      const float wgt = own ? as[op] * inv : 0.f;
+      const float h_im = px.h_im, w_im = px.w_im;
+      const bool inside = own && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+      const int h_pub = inside ? h_low : -(1 << 20);
+      float gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hb = quad_bcast_i(h_pub, c), wb = quad_bcast_i(w_low, c);
+        const int cy = hb + cyo, cx = wb + cxo;
+        const bool ok = (unsigned)cy < (unsigned)Hm && (unsigned)cx < (unsigned)Wm;
+        const int ly = cy - wy0, lx = cx - wx0;
+        const bool in_win = (unsigned)ly < (unsigned)WINY && (unsigned)lx < (unsigned)WINX;
+        float gval = 0.f;
+        if (ok) {
+          if (in_win) {
+            gval = VG[slot * GS + ly * WINX + lx];
+          } else {  // the box has grown out of the window: dot product against the global value row
+            const float4* vr = reinterpret_cast<const float4*>(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D);
+            const float4* gr = reinterpret_cast<const float4*>(GOs + slot * VS);
+#pragma unroll 1
+            for (int cc = 0; cc < D / 4; ++cc) {
+              const float4 v4 = vr[cc], g4 = gr[cc];
+              gval = fmaf(g4.w, v4.w, fmaf(g4.z, v4.z, fmaf(g4.y, v4.y, fmaf(g4.x, v4.x, gval))));
+            }
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float t4 = quad_bcast_f(gval, cc);
+          gq[cc] = (corner == c) ? t4 : gq[cc];
+        }
+      }
+      const float g0 = gq[0], g1 = gq[1], g2 = gq[2], g3 = gq[3];
+      const float hh = 1.f - lh, hw = 1.f - lwf;
+      const float gx = px.gx, gy = px.gy;
+      const float ga = fmaf(lh * lwf, g3, fmaf(lh * hw, g2, fmaf(hh * lwf, g1, hh * hw * g0)));
+      const float gwl = (float)Wm * wgt * fmaf(hh, g1 - g0, lh * (g3 - g2));
+      const float ghl = (float)Hm * wgt * fmaf(hw, g2 - g0, lwf * (g3 - g1));
+      dcx += gwl;
+      dcy += ghl;
+      dw += kxn * (gwl * g.cs + ghl * g.sn);
+      dh += kyn * (ghl * g.cs - gwl * g.sn);
+      dth += gwl * (-(gx * g.sn) - gy * g.cs) + ghl * (gx * g.cs - gy * g.sn);
+      dot = fmaf(wgt, ga, dot);
+      if (own) ga_s[slot * PMAX + op] = ga;
+    }
+    dcx = quad_sum(dcx);
+    dcy = quad_sum(dcy);
+    dw = quad_sum(dw);
+    dh = quad_sum(dh);
+    dth = quad_sum(dth);
+    dot = quad_sum(dot);
+    dcx += __shfl_xor(dcx, 4, 64);
+    dcy += __shfl_xor(dcy, 4, 64);
+    dw += __shfl_xor(dw, 4, 64);
+    dh += __shfl_xor(dh, 4, 64);
+    dth += __shfl_xor(dth, 4, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (qok && sub == 0) {
+      float* go = grad_off + bqs * dm.off_rs + m * dm.v;
+      go[0] = dcx * g.rw / 8.0f;
+      go[1] = dcy * g.rh / 8.0f;
+      go[2] = g.w_on ? dw * g.rw / 8.0f : 0.0f;
+      go[3] = g.h_on ? dh * g.rh / 8.0f : 0.0f;
+      if (dm.v == 5) go[4] = dth * (2.0f * 3.14159274f / 16.0f);
+    }
+    __syncthreads();  // ga_s complete
+    if (qok)
+      for (int e = sub; e < np; e += 8) grad_logits[bqs * dm.lg_rs + m * np + e] = as[e] * inv * (ga_s[slot * PMAX + e] - dot);
+    (void)t;
+  }
+}
+
+template <int TQY>
+__global__ void __launch_bounds__(BT<TQY>::kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+box_bwd_tile_b_kernel(const long long* __restrict__ shapes, const float* __restrict__ ref, const float* __restrict__ off,
+                      const float* __restrict__ logits, const float* __restrict__ kidx, const float* __restrict__ grad_out,
+                      BoxDims dm, float* __restrict__ grad_value, int* __restrict__ cursor, int2* __restrict__ entries,
+                      const int* __restrict__ bin_end, int* __restrict__ overflow, int color) {
+  using B = BT<TQY>;
+  constexpr int TQX = B::TQX, R = B::R, WINY = B::WINY, WINX = B::WINX, NQ = B::NQ, NC = B::NC, D = B::D, VS = B::VS, WS = B::WS,
+                kThreads = B::kThreads, PMAX = bt::PMAX;
+  extern __shared__ float lds[];
+  float* Wl = lds;                     // W [NC][WS]
+  float* GOs = Wl + NC * WS;           // [NQ][VS]
+  float* a_s = GOs + NQ * VS;          // [NQ][PMAX]
+  float* k_s = a_s + NQ * PMAX;        // [PMAX][2]
+  const int Hm = (int)shapes[0], Wm = (int)shapes[1];
+  if ((long long)Hm * Wm != dm.s) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2 * dm.p) k_s[tid] = kidx[tid];
+  const int slot = tid >> 3, sub = tid & 7, corner = sub & 3, half = sub >> 2;
+  const int m = blockIdx.y, bi = blockIdx.z;
+  const int np = dm.p;
+  const int tiles_x = (Wm + TQX - 1) / TQX, tiles_y = (Hm + TQY - 1) / TQY;
+  constexpr int NCY = (WINY + TQY - 1) / TQY, NCX = (WINX + TQX - 1) / TQX;   // colour classes, as in box_bwd_tile_kernel
+  const int cy0 = color >= 0 ? color / NCX : 0, cx0 = color >= 0 ? color % NCX : 0;
+  const int sy_ = color >= 0 ? NCY : 1, sx_ = color >= 0 ? NCX : 1;
+  const int ctx = (tiles_x - cx0 + sx_ - 1) / sx_, cty = (tiles_y - cy0 + sy_ - 1) / sy_;
+  const int ntiles = max(ctx, 0) * max(cty, 0);
+  const long long S = dm.s;
+  constexpr int EPT = PMAX / 2;
+  for (int tj = blockIdx.x; tj < ntiles; tj += gridDim.x) {
+    const int tile = (cy0 + sy_ * (tj / ctx)) * tiles_x + cx0 + sx_ * (tj % ctx);
+    const int ty0 = (tile / tiles_x) * TQY, tx0 = (tile % tiles_x) * TQX;
+    const int wy0 = ty0 - R, wx0 = tx0 - R;
+    __syncthreads();  // the previous tile's GEMM is done with GOs / W
+    const int qy = ty0 + slot / TQX, qx = tx0 + slot % TQX;
+    const bool qok = qy < Hm && qx < Wm;
+    const int qyc = min(qy, Hm - 1), qxc = min(qx, Wm - 1);
+    const long long bqc = (long long)bi * dm.lq + (long long)qyc * Wm + qxc;
+    const long long t = bqc * dm.h + m;   // (only used when qok)
+    {
+      const float4 go = ld4(grad_out + t * D + sub * 4);
+      *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? go : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float lgv[4], rf[5], of[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lgv[k] = logits[bqc * dm.lg_rs + m * np + min(sub + 8 * k, np - 1)];
+    {
+      const float* r = ref + bqc * 7;
+      rf[0] = r[0], rf[1] = r[1], rf[2] = r[3], rf[3] = r[4], rf[4] = r[6];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) of[k] = off[bqc * dm.off_rs + m * dm.v + min(k, dm.v - 1)];
+    }
+    for (int i = tid; i < NC * WS / 4; i += kThreads) reinterpret_cast<float4*>(Wl)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* as = a_s + slot * PMAX;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) mx = fmaxf(mx, lgv[k]);
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < np) {
+        const float ex = expf(lgv[k] - mx);
+        as[sub + 8 * k] = ex;
+        den += ex;
+      }
+#pragma unroll
+    for (int dlt = 4; dlt > 0; dlt >>= 1) den += __shfl_xor(den, dlt, 64);
+    const float inv = 1.0f / den;
+    const BoxGeo g = make_box_v(rf, of, dm.v);
+    __syncthreads();
+
+    // ---- the (cell, weight) of this lane's corner of every point, exactly as pass A of the one-kernel form computes them
+    int e_cell[EPT];    // window cell (>= 0), -1: nothing to add, -2: outside the window (binned / global path)
+    float e_w[EPT];
+    const int cyo = corner >> 1, cxo = corner & 1;
+    const float sy = cyo ? 1.f : -1.f, ay = cyo ? 0.f : 1.f, sx = cxo ? 1.f : -1.f, ax = cxo ? 0.f : 1.f;
+#pragma unroll
+    for (int j = 0; j < EPT / 4; ++j) {
+      const int op = half + 2 * (4 * j + corner);
+      const bool own = qok && op < np;
+      const float kxn = own ? k_s[op * 2] : 0.f, kyn = own ? k_s[op * 2 + 1] : 0.f;
+      const BoxPx px = box_point(g, kxn, kyn, Hm, Wm);
+      const float wgt = own ? as[op] * inv : 0.f;
+      const float h_im = px.h_im, w_im = px.w_im;
+      const bool inside = own && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hm) && (w_im < (float)Wm);
+      const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+      const float lh = h_im - (float)h_low, lwf = w_im - (float)w_low;
+      const int h_pub = inside ? h_low : -(1 << 20);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * j + c;
+        const int hb = quad_bcast_i(h_pub, c), wb = quad_bcast_i(w_low, c);
+        const float lhb = quad_bcast_f(lh, c), lwb = quad_bcast_f(lwf, c), wgb = quad_bcast_f(wgt, c);
+        const int cy = hb + cyo, cx = wb + cxo;
+        const bool ok = (unsigned)cy < (unsigned)Hm && (unsigned)cx < (unsigned)Wm;
+        const int ly = cy - wy0, lx = cx - wx0;
+        const bool in_win = (unsigned)ly < (unsigned)WINY && (unsigned)lx < (unsigned)WINX;
+        e_cell[k] = -1;
+        e_w[k] = 0.f;
+        if (ok) {
+          e_w[k] = wgb * (fmaf(sy, lhb, ay) * fmaf(sx, lwb, ax));
+          e_cell[k] = in_win ? ly * WINX + lx : -2;
+        }
+      }
+    }
+    // ---- S3 / S4: W[cell][q], the two halves in turn (box_bwd_tile_kernel: why plain read-modify-writes are safe) ------
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (half == hsel && e_cell[k] >= 0) Wl[e_cell[k] * WS + slot] += e_w[k];
+        asm volatile("" ::: "memory");
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (e_cell[k] == -2) {
+        const int pi = half + 2 * k;
+        const BoxPx px = box_point(g, k_s[pi * 2], k_s[pi * 2 + 1], Hm, Wm);
+        const int cy = (int)floorf(px.h_im) + (corner >> 1), cx = (int)floorf(px.w_im) + (corner & 1);
+        const long long bin = ((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m;
+        if (cursor) {
+          bin_push(cursor, bin_end, overflow, entries, bin, (int)t, e_w[k]);
+        } else {
+          float* gv = grad_value + bin * D;
+#pragma unroll 1
+          for (int c = 0; c < D; ++c) unsafeAtomicAdd(gv + c, e_w[k] * GOs[slot * VS + c]);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- S5: GV = W . GO and the window flush, as in box_bwd_tile_kernel ---------------------------------------------
+    {
+      const int r16 = lane & 15, kk = lane >> 4;
+      constexpr int CBW = B::CBW;
+      f32x4 acc[CBW][2];
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float cur[CBW][2][4];
+      if (color >= 0) {
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cell = 16 * (CBW * wave + i) + 4 * kk + r;
+            const int cy = min(max(wy0 + cell / WINX, 0), Hm - 1), cx = min(max(wx0 + cell % WINX, 0), Wm - 1);
+            const float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
+            cur[i][0][r] = gv[0];
+            cur[i][1][r] = gv[16];
+          }
+      }
+      const float* ap = Wl + (16 * (CBW * wave) + r16) * WS + kk;
+      const float* bp = GOs + kk * VS + r16;
+#pragma unroll
+      for (int ks = 0; ks < NQ / 4; ++ks) {
+        const float b0 = bp[4 * ks * VS], b1 = bp[4 * ks * VS + 16];
+#pragma unroll
+        for (int i = 0; i < CBW; ++i) {
+          const float av = ap[i * 16 * WS + 4 * ks];
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[i][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cell = 16 * (CBW * wave + i) + 4 * kk + r;
+          const int cy = wy0 + cell / WINX, cx = wx0 + cell % WINX;
+          if (cy >= 0 && cy < Hm && cx >= 0 && cx < Wm) {
+            float* gv = grad_value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D + r16;
+            if (color >= 0) {
+              if (acc[i][0][r] != 0.0f) gv[0] = __fadd_rn(cur[i][0][r], acc[i][0][r]);
+              if (acc[i][1][r] != 0.0f) gv[16] = __fadd_rn(cur[i][1][r], acc[i][1][r]);
+            } else {
+              if (acc[i][0][r] != 0.0f) unsafeAtomicAdd(gv, acc[i][0][r]);
+              if (acc[i][1][r] != 0.0f) unsafeAtomicAdd(gv + 16, acc[i][1][r]);
+            }
+          }
+        }
+    }
+  }
+}
+
 // ---- binned grad_value (decoder) -------------------------------------------------------------------------
 // Decoder queries sample anywhere, so their grad_value contributions cannot be tiled; as float atomics they are
 // D atomics per (query, head, point, corner), and on MI355X device-scope atomics are executed past the per-XCD
@@ -1226,9 +1647,24 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
       // (workgroups along x of a colour launch; measured 16: +1.1 ms, 32: +0.35 ms, 64: +0.1 ms per step against the atomic launch)
       static const int cgx_env = getenv("EFG_BOX_COLOR_GRIDX") ? atoi(getenv("EFG_BOX_COLOR_GRIDX")) : 64;
       const unsigned gx_launch = colored ? std::min<unsigned>(tile_gx, (unsigned)std::max(cgx_env, 1)) : tile_gx;
+      // EFG_BOX_SPLIT (default 1): pass A and pass B as two kernels at four waves per SIMD (see box_bwd_tile_a_kernel);
+      // 0 = the one-kernel form.  The 4 x 8 tile only.
+      const int split_env = getenv("EFG_BOX_SPLIT") ? atoi(getenv("EFG_BOX_SPLIT")) : 1;   // (read per call: tests flip it in-process)
+      const bool split = split_env != 0 && tqy == 4;
+      if (split) {
+        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_a_kernel<4>, bt::lds_bytes_a<4>());
+        hipLaunchKernelGGL(box_bwd_tile_a_kernel<4>, dim3(tile_gx, h, b), dim3(BT<4>::kThreads), bt::lds_bytes_a<4>(), st, value,
+                           (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_offsets,
+                           grad_logits);
+        EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_b_kernel<4>, bt::lds_bytes_b<4>());
+      }
       for (int col = 0; col < ncolors; ++col) {
         const int color = colored ? col : -1;
-        if (tqy == 8) {
+        if (split) {
+          hipLaunchKernelGGL(box_bwd_tile_b_kernel<4>, dim3(gx_launch, h, b), dim3(BT<4>::kThreads), bt::lds_bytes_b<4>(), st,
+                             (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
+                             cursor, entries, offs ? offs + 1 : nullptr, overflow, color);
+        } else if (tqy == 8) {
           EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
           hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(gx_launch, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
                              (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,

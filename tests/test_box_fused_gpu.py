@@ -232,3 +232,38 @@ def test_backward_is_reproducible_bit_for_bit(dev, case):
         assert torch.equal(again[1], first[1]) and torch.equal(again[0], first[0])
         for n in first[3]:
             assert torch.equal(again[3][n], first[3][n]), n
+
+
+@pytest.mark.parametrize("case", ["grid", "grid_rot", "grid_big"])
+def test_split_backward_bits_equal_one_kernel(dev, monkeypatch, case):
+    """The encoder backward as two kernels at four waves per SIMD (box_bwd_tile_a_kernel: G = GO.V^T + the gradients of
+    offsets and logits; box_bwd_tile_b_kernel: W scatter + W.GO + flush; EFG_BOX_SPLIT=1, the default) performs the one-kernel
+    form's arithmetic in its order: every gradient is the same bits (near boxes, rotated boxes, boxes whose corners leave the
+    window and take the binned path)."""
+    g = torch.Generator().manual_seed(4)
+    H, W = 44, 52
+    S = H * W
+    shapes = torch.tensor([[H, W]], device=dev)
+    start = torch.zeros(1, dtype=torch.int64, device=dev)
+    value = torch.randn(2, S, 256, generator=g).to(dev)
+    rot = case.endswith("rot")
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.zeros(2, S, 7)
+    ref[..., 0], ref[..., 1] = (xs / W).reshape(-1), (ys / H).reshape(-1)
+    ref[..., 2] = ref[..., 5] = 0.5
+    ref[..., 3] = ref[..., 4] = 0.4 if case.endswith("big") else 0.08
+    if rot:
+        ref[..., 6] = torch.rand(2, S, generator=g)
+    ref = ref.to(dev)
+    query = torch.randn(2, S, 256, generator=g).to(dev)
+    m = _module(dev, rot, 5)
+    res = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("EFG_BOX_SPLIT", sw)
+        res[sw] = _run(m, True, query, value, shapes, start, ref)
+    o1, q1, v1, p1 = res["1"]
+    o0, q0, v0, p0 = res["0"]
+    assert torch.equal(o1, o0) and torch.equal(v1, v0), "grad_value bits differ"
+    assert torch.equal(q1, q0), "query gradient (through grad_offsets / grad_logits) bits differ"
+    for n in p0:
+        assert torch.equal(p1[n], p0[n]), n
