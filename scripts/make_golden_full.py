@@ -345,6 +345,19 @@ def run(tag, model_dir, yaml_name, out_name):
         for n in grads:
             grads64[n] = p64[n].grad.detach().clone()
         print("   fp64 total loss %.9f (fp32 %.9f)" % (float(total64), float(total)))
+    if "--grad64-out" in sys.argv:
+        # the fp64 run's gradients of the same tensors, sliced like the fp32 ones: the ground truth of the measured gradient
+        # table (scripts/grad_tier_report.py -> profiles/r06_grad_tier_table.txt); the main fixture is left untouched
+        out64 = os.path.join(ROOT, "tests", "golden", sys.argv[sys.argv.index("--grad64-out") + 1])
+        save64 = {}
+        for k, v in grads64.items():
+            save64["grad64::" + k] = (v[:8].contiguous() if v.numel() > 65536 else v).numpy()
+            g32 = grads[k]
+            save64["ref32_err::" + k] = np.array(float((g32.double() - v).abs().max() / v.abs().max()))
+        save64["total_loss64"] = np.array(float(total64))
+        np.savez_compressed(out64, **save64)
+        print(tag, "saved", out64, os.path.getsize(out64) // 1024, "KiB;", len(grads64), "fp64 gradients")
+        return
     save = {"total_loss": total.detach(), "n_params": np.array(sum(p.numel() for p in params.values() if p.requires_grad))}
     light = "prepare_for_cdn" not in vars(voxel_detr)  # Voxel-DETR: same weights => same maps as the ConQueR fixture
     for k in ("memory", "topk") if light else ("bu_res3", "bu_res4", "fpn_p3", "src", "memory", "topk", "dn_label",

@@ -73,6 +73,13 @@ def _run(model, device):
     return cap, losses, total
 
 
+# gradients that do not pass through a sampling location or a BatchNorm (the 1e-4 tier; scripts/grad_tier_report.py prints the
+# measured error of every stored gradient against the reference's float64 run: profiles/r06_grad_tier_table.txt)
+EXACT_GRADS = ("detection_head", "proposal_head", "decoder.layers.2.norm", "decoder.layers.2.linear2",
+               "decoder.layers.2.multihead_attn.out_proj", "decoder.layers.2.multihead_attn.value_proj",
+               "decoder.layers.2.self_attn", "projector", "predictor")
+
+
 def _check(model, g, cap, losses, total, full_graph, act_tol=5e-5, loss_rtol=1e-4, grad_tol=3e-3, grad_tol_exact=1e-4):
     c = lambda x: x.detach().float().cpu().numpy()  # noqa: E731
 
@@ -114,9 +121,7 @@ def _check(model, g, cap, losses, total, full_graph, act_tol=5e-5, loss_rtol=1e-
     #    its own gradient), every other row agrees to 1e-7; that row's contribution is ~1e-3 of a weight gradient --
     #    with the HIP kernels and with PyTorch's own grid_sample on the GPU alike.  Convolutions in front of a
     #    BatchNorm are ill-conditioned on top: the reference's own fp32 gradient is 6-8e-4 off its fp64 run.
-    exact = ("detection_head", "proposal_head", "decoder.layers.2.norm", "decoder.layers.2.linear2",
-             "decoder.layers.2.multihead_attn.out_proj", "decoder.layers.2.multihead_attn.value_proj",
-             "decoder.layers.2.self_attn", "projector", "predictor")
+    exact = EXACT_GRADS
     for k, v in g.items():
         if k.startswith("grad::"):
             got = c(params[k[6:]].grad)
@@ -150,6 +155,60 @@ def test_reference_full_model_gpu(dev, full_graph):
     cap, losses, total = _run(model, dev)
     torch.cuda.synchronize()
     _check(model, g, cap, losses, total, full_graph)
+
+
+def _against_fp64(model):
+    """Every stored gradient against the reference model's FLOAT64 run (tests/golden/conquer_full_small_grad64.npz,
+    scripts/make_golden_full.py --grad64-out): (ours-vs-64, ref32-vs-64) per tensor, as max |diff| / max |g64|."""
+    g64 = golden("conquer_full_small_grad64.npz")
+    params = dict(model.named_parameters())
+    rows = {}
+    for k in g64:
+        if not k.startswith("grad64::"):
+            continue
+        name = k[8:]
+        got = params[name].grad.detach().double().cpu().numpy()
+        if got.size > 65536:
+            got = got[:8]
+        want = g64[k]
+        rows[name] = (float(np.abs(got - want).max() / np.abs(want).max()), float(g64["ref32_err::" + name]))
+    return rows
+
+
+def _check_fp64(rows):
+    """The gradient bar stated against the TRUTH instead of against the reference's fp32 run: the 1e-4 tier for every tensor
+    that does not sit behind a sampling location or a BatchNorm; for the others the old hard bound (one bilinear corner
+    9.5e-7 px from an integer may flip with the last bit of the geometry: 1e-3 of a tensor) AND their median at 1e-4 -- a
+    flip moves one tensor chain, not the median.  Measured: every tensor <= 6e-6 on the CPU (oracle ops), <= 1.7e-5 on the
+    GPU, i.e. CLOSER to the float64 run than the reference's own fp32 gradients are (6.4e-4 in front of a BatchNorm);
+    profiles/r06_grad_tier_table.txt."""
+    assert len(rows) >= 30
+    loose = []
+    for name, (err, ref_err) in rows.items():
+        if any(e in name for e in EXACT_GRADS):
+            assert err <= 1e-4, "%s: %.2e of the tensor max off the float64 reference run" % (name, err)
+        else:
+            assert err <= 3e-3, "%s: %.2e of the tensor max off the float64 reference run" % (name, err)
+            loose.append(err)
+    assert float(np.median(loose)) <= 1e-4, "median error of the BatchNorm / sampling tier %.2e" % float(np.median(loose))
+
+
+def test_gradients_against_the_reference_float64_run_cpu(oracle_mod):
+    from oracle import cpu_backend
+
+    torch.set_num_threads(8)
+    model, g = _build(torch.device("cpu"), full_graph=True)
+    with cpu_backend.install():
+        _run(model, torch.device("cpu"))
+    _check_fp64(_against_fp64(model))
+
+
+@pytest.mark.gpu
+def test_gradients_against_the_reference_float64_run_gpu(dev):
+    model, g = _build(dev, True)
+    _run(model, dev)
+    torch.cuda.synchronize()
+    _check_fp64(_against_fp64(model))
 
 
 VD = dict(fixture="voxeldetr_full_small.npz", yaml_name="voxeldetr_waymo_res18.yaml")
