@@ -1614,13 +1614,12 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
     // encoder self-attention (queries on the value map): fp64 LDS window per 8x8 query tile.  H, W are
     // device-side, so the launch is sized for a square map and the kernel strides over the tiles.
     const int side = (int)std::ceil(std::sqrt((double)s));
-    // tile shape: 4 x 8 queries (two workgroups per CU) unless EFG_BOX_TQY=8 asks for the 8 x 8 tile of round 2
-    static const int tqy_env = getenv("EFG_BOX_TQY") ? atoi(getenv("EFG_BOX_TQY")) : 4;
-    const int tqy = tqy_env == 8 ? 8 : 4;
+    // tile shape: 4 x 8 queries (the 8 x 8 tile of round 2 -- BT<8>, one workgroup per CU -- was retired in round 6)
+    constexpr int tqy = 4;
     const unsigned tiles_sq = (unsigned)(((side + tqy - 1) / tqy) * ((side + 7) / 8));
     // workgroups along x of the tile kernel: it strides over the tiles and fetches one tile ahead (64 x h x b workgroups,
     // two rounds of the 512 resident ones: 507 -> 490 us against one workgroup per tile)
-    static const int gx_env = getenv("EFG_BOX_GRIDX") ? atoi(getenv("EFG_BOX_GRIDX")) : 0;
+    constexpr int gx_env = 0;
     const unsigned tile_gx = std::min<unsigned>((unsigned)(gx_env > 0 ? gx_env : 64), tiles_sq);
     if (l * p <= bt::PMAX) {
       // corners that leave the tile's window are binned per (cell, head) row when a workspace is given (see the kernel)
@@ -1641,16 +1640,14 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
       // out-of-window corners, whose reduction is order-independent).  0: one launch, float atomics.
       static const int det_env = getenv("EFG_BOX_DETERMINISTIC") ? atoi(getenv("EFG_BOX_DETERMINISTIC")) : 1;
       const bool colored = det_env != 0 && binned;
-      const int ncolors = colored ? (tqy == 8 ? ((BT<8>::WINY + 7) / 8) * ((BT<8>::WINX + BT<8>::TQX - 1) / BT<8>::TQX)
-                                              : ((BT<4>::WINY + 3) / 4) * ((BT<4>::WINX + BT<4>::TQX - 1) / BT<4>::TQX))
-                                  : 1;
+      const int ncolors = colored ? ((BT<4>::WINY + 3) / 4) * ((BT<4>::WINX + BT<4>::TQX - 1) / BT<4>::TQX) : 1;
       // (workgroups along x of a colour launch; measured 16: +1.1 ms, 32: +0.35 ms, 64: +0.1 ms per step against the atomic launch)
-      static const int cgx_env = getenv("EFG_BOX_COLOR_GRIDX") ? atoi(getenv("EFG_BOX_COLOR_GRIDX")) : 64;
+      constexpr int cgx_env = 64;
       const unsigned gx_launch = colored ? std::min<unsigned>(tile_gx, (unsigned)std::max(cgx_env, 1)) : tile_gx;
       // EFG_BOX_SPLIT (default 1): pass A and pass B as two kernels at four waves per SIMD (see box_bwd_tile_a_kernel);
       // 0 = the one-kernel form.  The 4 x 8 tile only.
       const int split_env = getenv("EFG_BOX_SPLIT") ? atoi(getenv("EFG_BOX_SPLIT")) : 1;   // (read per call: tests flip it in-process)
-      const bool split = split_env != 0 && tqy == 4;
+      const bool split = split_env != 0;
       if (split) {
         EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_a_kernel<4>, bt::lds_bytes_a<4>());
         hipLaunchKernelGGL(box_bwd_tile_a_kernel<4>, dim3(tile_gx, h, b), dim3(BT<4>::kThreads), bt::lds_bytes_a<4>(), st, value,
@@ -1664,11 +1661,6 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
           hipLaunchKernelGGL(box_bwd_tile_b_kernel<4>, dim3(gx_launch, h, b), dim3(BT<4>::kThreads), bt::lds_bytes_b<4>(), st,
                              (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
                              cursor, entries, offs ? offs + 1 : nullptr, overflow, color);
-        } else if (tqy == 8) {
-          EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<8>, bt::lds_bytes<8>());
-          hipLaunchKernelGGL(box_bwd_tile_kernel<8>, dim3(gx_launch, h, b), dim3(BT<8>::kThreads), bt::lds_bytes<8>(), st, value,
-                             (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_value,
-                             grad_offsets, grad_logits, cursor, entries, offs ? offs + 1 : nullptr, overflow, color);
         } else {
           EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_kernel<4>, bt::lds_bytes<4>());
           hipLaunchKernelGGL(box_bwd_tile_kernel<4>, dim3(gx_launch, h, b), dim3(BT<4>::kThreads), bt::lds_bytes<4>(), st, value,

@@ -639,7 +639,7 @@ WgradPlan wgrad_plan(int64_t m_out, int cin, int cout, int kvol) {
   const size_t per = (size_t)kvol * cout * cin * 4;
   // ~2048 workgroups (8 per CU) when the level is large enough (as fast as 4096 with half the partial-block traffic;
   // 1024 is 15-30 % slower: scripts/tile_sweep.sh), >= 512 rows per chunk, <= 128 MB partials
-  static const int64_t fill_env = getenv("EFG_WGRAD_FILL") ? atoll(getenv("EFG_WGRAD_FILL")) : 2048;
+  constexpr int64_t fill_env = 2048;
   const int64_t by_fill = std::max<int64_t>(1, fill_env / ((int64_t)p.nco_blk * p.nci_blk * kvol));
   const int64_t by_rows = std::max<int64_t>(1, ceil_div(std::max<int64_t>(m_out, 1), 512));
   const int64_t by_mem = std::max<int64_t>(1, (int64_t)((128ull << 20) / std::max<size_t>(per, 1)));
@@ -698,8 +698,8 @@ int run_conv(const float* in, int64_t m_in, int cin, const float* wp, const floa
   // With the kernel offsets split over the 4 waves of a workgroup (KS, below) a row tile already is 4 waves, so the
   // 3x3x3 layers fill the chip with fewer tiles: 1400 instead of 2048 lets the 256-channel layers (371 row tiles) take
   // 4 n-tiles per wave instead of 2 -- half the gathers per MFMA: 205 -> 170 us, 60 -> 72 TFLOP/s (EFG_CONV_FILL).
-  static const long long fill_env = getenv("EFG_CONV_FILL") ? atoll(getenv("EFG_CONV_FILL")) : 0;
-  static const int ks_env = getenv("EFG_CONV_KS") ? atoi(getenv("EFG_CONV_KS")) : 4;
+  constexpr long long fill_env = 0;
+  constexpr int ks_env = 4;
   const long long fill = fill_env > 0 ? fill_env : ((kvol >= 8 && ks_env > 1) ? 1400 : 2048);
   while (nt > 1 && (nt / 2 >= ntiles || row_waves * ((ntiles + nt - 1) / nt) < fill)) nt >>= 1;
   if (nt > ntiles) nt = ntiles >= 16 ? 16 : ntiles >= 8 ? 8 : ntiles >= 4 ? 4 : ntiles >= 2 ? 2 : 1;
@@ -905,7 +905,7 @@ extern "C" int efg_spconv_wgrad_f32(const float* in_feat, int64_t m_in, int cin,
   a.kvol = kvol;
   a.rows_per_split = p.rows_per_split;
   a.nci_blk = p.nci_blk;
-  static const bool small_env = !(getenv("EFG_WGRAD_SMALL") && atoi(getenv("EFG_WGRAD_SMALL")) == 0);
+  constexpr bool small_env = true;
   if (small_env && cin <= 16 && cout <= 32 && m_in == m_out) {
     // low-channel submanifold layers (dense tables: ~15 of 27 offsets per row; the strided stem conv has 4 of 27 and
     // keeps the compacting kernel): one workgroup per (row chunk, group of <= 4 offsets), see conv_wgrad_small_kernel

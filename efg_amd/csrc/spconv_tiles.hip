@@ -162,9 +162,7 @@ struct TileArgs {
   int sk_polls;          // polls of a share's flag before the unit is recomputed instead (EFG_TILE_SK_POLLS, default 20000)
   int* sk_fallbacks;     // device counter: units recomputed because a share did not arrive in time (efg_spconv_streamk_fallbacks)
   unsigned ux, uy;       // the unit grid (what gridDim is otherwise)
-  long long zero_off;    // byte offset from `in` of 16 zero bytes (absent rows / channel pieces past cin gather those)
   int bf3;               // 1: split-precision arm (MODE & 4), weights packed by efg_spconv_pack_weight_f32 with flag 4
-  int v4;                // 1: 16-byte gathers, natural-order packed weights (cin % 4 == 0)
   int flip;              // 1: offset k of the WEIGHTS reads table column kvol-1-k (dgrad of a submanifold conv:
                          // the transposed table of a symmetric window is the table with the offsets reversed)
   // PAIRS (efg_spconv_tiled_pair_f32): two convolutions over ONE table in one launch.
@@ -178,13 +176,9 @@ struct TileArgs {
   int ny1;
 };
 
-// 16 zero bytes every absent neighbour row (and every channel piece past cin) of the 16-byte gather points at
-__device__ float4 g_zero_piece;  // (zero-initialised, never written; not const: keeps the select in the global address space)
-
-// V4 = 1 (reduction channels a multiple of 4; weights packed in natural order): the gather is 16 bytes per lane
-// (4 rows x 16 pieces per instruction instead of one row), the A tile is stored as 16-byte pieces at slot
-// piece ^ row (conflict-free 16-byte writes and fragment reads without padding) and a lane's four A operands of a
-// 16-channel step come from ONE ds_read_b128.  V4 = 0: the 4-byte path (any channel count).
+// (The 16-byte-gather variant of rounds 2-5 -- template parameter V4, EFG_TILE_V4=1: natural-order packed weights, XOR-swizzled A
+// tile, one ds_read_b128 per fragment -- measured 3-13 % SLOWER on every res18 layer (profiles/r02_v4_sweep.txt) and was retired
+// in round 6; the template parameter stays 0.)
 #ifndef EFG_TILE_WPE_R2
 #define EFG_TILE_WPE_R2 4   // waves per SIMD asked of the compiler for the stream-K R = 2 shape (A/B builds: scripts/build_ab.sh)
 #endif
@@ -197,8 +191,8 @@ conv_tile_kernel(TileArgs a) {
   constexpr int SK = (MODE >> 1) & 1;  // stream-K: the (unit, offset) items are cut into equal shares, one per workgroup
   constexpr int WT = 4 / KS;                         // wave tiles (of R * 16 rows) per workgroup
   constexpr int BF3 = (MODE >> 2) & 1;  // A/B arm: three bf16 MFMA products of split operands instead of the fp32 MFMA
-  // LDS row stride of the A tile (V4: swizzled pieces, no padding; BF3: 16-byte aligned rows for the 32-byte fragment reads)
-  constexpr int kAStr = V4 ? kCKt : (BF3 ? kCKt + 4 : kCKt + 2);
+  // LDS row stride of the A tile (BF3: 16-byte aligned rows for the 32-byte fragment reads)
+  constexpr int kAStr = BF3 ? kCKt + 4 : kCKt + 2;
   __shared__ __attribute__((aligned(16))) float a_tile[4][R * 16 * kAStr];  // wave-private A staging
   __shared__ int nb_tile[WT][R * 32 * 16];           // byte offsets of the neighbour rows, [sub][k][16]
   __shared__ int s_redo_flag;                        // stream-K: a share did not arrive in time, recompute the unit
@@ -284,33 +278,10 @@ conv_tile_kernel(TileArgs a) {
 
   const int nchunk1 = (a.c16n * 16 + kCKt - 1) / kCKt;
   const int nchunk = a.in2 ? 2 * nchunk1 : nchunk1;   // (K pair: the chunks of `in`, then those of `in2`)
-  float pre[V4 ? 1 : R * 16];
+  float pre[R * 16];
   unsigned pre_m[R];
 
-  f32x4 pre4[V4 ? R * 4 : 1];
   auto gather = [&](int col, int ch) {
-    if (V4) {
-      const int piece = lane & 15, sub = lane >> 4;
-      const unsigned c0 = (unsigned)(ch * kCKt + piece * 4);
-      const bool c_ok = c0 < (unsigned)a.cin;
-#pragma unroll
-      for (int s = 0; s < R; ++s) {
-        pre_m[s] = (unsigned)__builtin_amdgcn_readlane((int)vmr[s], col);
-        if (pre_m[s]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = q * 4 + sub;
-            const bool ok = c_ok && ((pre_m[s] >> j) & 1u);
-            // one base, two offsets (select on the offset, not on the pointer: stays a v_cndmask pair, no branch)
-            const long long row_off = (long long)((unsigned)nbs[s * 512 + col * 16 + j] + c0 * 4u);
-            const long long sel = -(long long)ok;  // bit select: the compiler turns `ok ? row_off : zero_off` into branches
-            const long long off = (row_off & sel) | (a.zero_off & ~sel);
-            pre4[s * 4 + q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.in) + off);
-          }
-        }
-      }
-      return;
-    }
     const bool hi = __builtin_amdgcn_readfirstlane((int)(ch >= nchunk1)) != 0;   // (K pair, wave-uniform: the second operand's chunk)
     const char* src = reinterpret_cast<const char*>(hi ? a.in2 : a.in);
     const unsigned cc4 = (unsigned)min((hi ? ch - nchunk1 : ch) * kCKt + lane, a.cin - 1) * 4u;
@@ -328,19 +299,6 @@ conv_tile_kernel(TileArgs a) {
     }
   };
   auto stash = [&](float* at) {
-    if (V4) {
-      const int piece = lane & 15, sub = lane >> 4;
-#pragma unroll
-      for (int s = 0; s < R; ++s)
-        if (pre_m[s]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = q * 4 + sub;
-            *reinterpret_cast<f32x4*>(at + (s * 16 + j) * kAStr + ((piece ^ j) << 2)) = pre4[s * 4 + q];
-          }
-        }
-      return;
-    }
 #pragma unroll
     for (int s = 0; s < R; ++s)
       if (pre_m[s]) {
@@ -413,14 +371,8 @@ conv_tile_kernel(TileArgs a) {
 #pragma unroll
       for (int s = 0; s < R; ++s) {
         if ((s == 0 ? m0 : m1) == 0) continue;  // wave-uniform: this sub-tile has no neighbour at the column
-        float a0, a1, a2, a3;
-        if (V4) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(at + (s * 16 + m) * kAStr + (((i * 4 + kk) ^ m) << 2));
-          a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3];
-        } else {
-          const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
-          a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-        }
+        const float* ap = at + (s * 16 + m) * kAStr + i * 16 + kk;
+        const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[t].x, acc[s][t], 0, 0, 0);
 #pragma unroll
@@ -970,8 +922,7 @@ void launch_tiles_v(const TileArgs& a, int ny, int ks, hipStream_t stream) {
 
 template <int NT, int R>
 void launch_tiles(const TileArgs& a, int ny, int ks, hipStream_t stream) {
-  if (a.v4) launch_tiles_v<NT, R, 1>(a, ny, ks, stream);
-  else launch_tiles_v<NT, R, 0>(a, ny, ks, stream);
+  launch_tiles_v<NT, R, 0>(a, ny, ks, stream);
 }
 
 // The launch shape of a (cin, cout, kvol, rows) convolution: NT n-tiles per wave, R sub-tiles per wave, KS split-K
@@ -984,10 +935,10 @@ int streamk_mode() {
 }
 
 void tile_shape(int cin, int cout, int kvol, int64_t m_in, int64_t m_out, int* nt_out, int* r_out, int* ks_out, int* pipe_out) {
-  static const int r_env = getenv("EFG_TILE_R") ? atoi(getenv("EFG_TILE_R")) : 0;
-  static const int ks_env = getenv("EFG_TILE_KS") ? atoi(getenv("EFG_TILE_KS")) : 0;
-  static const int nt_env = getenv("EFG_TILE_NT") ? atoi(getenv("EFG_TILE_NT")) : 0;
-  static const int pipe_env = getenv("EFG_TILE_PIPE") ? atoi(getenv("EFG_TILE_PIPE")) : -1;
+  constexpr int r_env = 0;
+  constexpr int ks_env = 0;
+  constexpr int nt_env = 0;
+  constexpr int pipe_env = -1;
   const int ntiles = (cout + 15) / 16;
   int nt = ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1);
   if (nt_env > 0) nt = nt_env <= 1 ? 1 : (nt_env <= 2 ? 2 : 4);
@@ -1086,31 +1037,17 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   a.c16n = (cin + 15) / 16;
   a.np = (cout + 15) / 16 * 16;
   a.flip = flip;
-  a.v4 = natural_order ? 1 : 0;
   a.bf3 = bf3 ? 1 : 0;
   a.in2 = in2;
   a.wp2 = wp2;
   a.out2 = out2;
   a.ny1 = 0;
-  a.zero_off = 0;
-  if (a.v4) {
-    static const char* zero_piece[64] = {};  // per device: address of g_zero_piece
-    int dev = 0;
-    EFG_HIP_TRY(hipGetDevice(&dev));
-    EFG_CHECK_ARG(dev >= 0 && dev < 64, "spconv tiled: device ordinal %d out of range", dev);
-    if (!zero_piece[dev]) {
-      void* p = nullptr;
-      EFG_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_piece)));
-      zero_piece[dev] = static_cast<const char*>(p);
-    }
-    a.zero_off = (long long)(zero_piece[dev] - reinterpret_cast<const char*>(in));
-  }
-  EFG_CHECK_ARG(!natural_order || cin % 4 == 0, "spconv tiled: natural-order weights need cin %% 4 == 0, got %d", cin);
+  EFG_CHECK_ARG(!natural_order, "spconv tiled: the natural-order (16-byte gather) variant was retired in round 6 (3-13 %% slower, profiles/r02_v4_sweep.txt)");
   // narrow layers (conv_small_kernel): EFG_CONV_SMALL=0 keeps them on the tile kernel (A/B)
   {
     int c16 = 0, nt_s = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(wp) & 15) == 0;
-    if (small_shape(cin, cout, kvol, &c16, &nt_s) && !a.v4 && !a.bf3 && aligned && !wp2) {
+    if (small_shape(cin, cout, kvol, &c16, &nt_s) && !a.bf3 && aligned && !wp2) {
       const size_t lds = (size_t)kvol * c16 * nt_s * 1024 + (size_t)(kSmallThreads / 64) * kSmallKmax * 16 * sizeof(int);
       // as many workgroups as the device holds at once (up to 4 per CU; 2 with 55 KB of weights), a multiple of 8
       const long long fit = std::max<long long>(1, std::min<long long>(4, (150 * 1024) / (long long)lds)) * 256;
@@ -1148,10 +1085,10 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
     a.ny1 = ny;
     ny *= 2;
   }
-  static const int deal_env = getenv("EFG_TILE_DEAL") ? atoi(getenv("EFG_TILE_DEAL")) : 1;
+  constexpr int deal_env = 1;
   a.pipe = pipe;
   a.deal = deal_env;
-  static const int xcd_env = getenv("EFG_TILE_XCD") ? atoi(getenv("EFG_TILE_XCD")) : 1;
+  constexpr int xcd_env = 1;
   a.xcd = xcd_env;
   // Stream-K (see the kernel): on by default where it was measured to win -- the 64-channel-wide split-K shape on
   // submanifold tables (every level: -3 % at 64 channels, -5 % at 128, -9 % at 256) and on the strided tables with
@@ -1170,7 +1107,7 @@ int run_tiles(const float* in, int64_t m_in, int cin, const float* wp, const flo
   // hipMalloc / hipMemset would invalidate the capture as well.  Captured launches take the plain (non-split) path.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (stream) (void)hipStreamIsCapturing(stream, &cap);
-  if (cap == hipStreamCaptureStatusNone && sk_env && nt == 4 && ks == 4 && !a.v4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
+  if (cap == hipStreamCaptureStatusNone && sk_env && nt == 4 && ks == 4 && (sk_env == 2 || m_in == m_out || (cin >= 128 && cout >= 128))) {
     StreamKState* st = nullptr;
     if (int rc = streamk_for_stream(stream, &st)) return rc;
     a.sk_prefix = r == 2 ? pv.pfx2 : pv.pfx1;

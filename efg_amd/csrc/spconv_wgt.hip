@@ -76,7 +76,7 @@ constexpr int kMaxSlots = 2048;
 inline int sched_slots(long long n_tiles, int kvol, int nblk, int resident) {
   // ~0.55 of the (tile, offset) pairs of a submanifold window are active, fewer on strided tables: an estimate is enough,
   // it only sets the slot size
-  static const int units_env = getenv("EFG_WGT_UNITS") ? std::max(atoi(getenv("EFG_WGT_UNITS")), 8) : kUnitsPerSlot;
+  constexpr int units_env = kUnitsPerSlot;
   const double want = (double)n_tiles * kvol * 0.55 / units_env * nblk;          // workgroups
   const long long fills = std::max<long long>(1, (long long)(want / resident + 0.5));
   long long slots = fills * resident / nblk;
@@ -514,7 +514,7 @@ extern "C" int efg_spconv_wgrad_sched(const void* plan, int64_t m_out, int cin, 
   int* kfirst = reinterpret_cast<int*>(dispatch + sched_dispatch(slots));
   int4* entry = reinterpret_cast<int4*>(kfirst + 36);
   hipLaunchKernelGGL(wgt_schedule_kernel, dim3(kvol), dim3(256), 0, stream, pv.vm, pv.n_tiles, kvol, slots, entry, kfirst);
-  static const int order_env = getenv("EFG_WGT_ORDER") ? atoi(getenv("EFG_WGT_ORDER")) : 1;   // 0: table order (A/B)
+  constexpr int order_env = 1;   // (0: table order -- the losing A/B arm of round 3, profiles/r03_wgrad_dispatch_order_ab.txt)
   hipLaunchKernelGGL(wgt_order_kernel, dim3(1), dim3(1024), 0, stream, entry, slots, dispatch, order_env);
   EFG_LAUNCH_CHECK();
   return EFG_OK;

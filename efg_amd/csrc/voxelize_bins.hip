@@ -1024,7 +1024,6 @@ bool bins_layout(int64_t n_total, int batch, int f, const VoxGeom& g, BinsLayout
 // stream are issued by one thread at a time (as for stream-K, include/efg_hip.h).  While the stream is being CAPTURED into a HIP
 // graph the call takes its cleared words from the caller's workspace and clears them with vox_clear_kernel, as before (a
 // replay must not depend on what eager calls left behind, and the first-use allocation would invalidate the capture).
-// EFG_VOX_OWN_STATE=0: always the workspace + clear kernel (A/B).
 constexpr size_t kOwnRecordWords = 49152;   // >= the records of any call the binned path takes (<= 2^22 supercells, < 2^28 points)
 struct VoxState {
   unsigned* words = nullptr;
@@ -1156,11 +1155,10 @@ int bins_hard_voxelize(const HardArgs& a) {
   // the cleared words: the library's own, self-cleaning buffer of this stream (see VoxState) unless the stream is being captured
   VoxState* own = nullptr;
   {
-    const char* env = getenv("EFG_VOX_OWN_STATE");
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (stream) (void)hipStreamIsCapturing(stream, &cap);
     const size_t record_words = cleared_words - L.s_total * kXcd;
-    if (cap == hipStreamCaptureStatusNone && !(env && atoi(env) == 0) && record_words <= kOwnRecordWords) {
+    if (cap == hipStreamCaptureStatusNone && record_words <= kOwnRecordWords) {
       // [records: kOwnRecordWords, zeroed by K1 of the call that uses them][counters: zero at rest].  The records sit at a
       // FIXED place in front: behind the counters their offset would change with the grid and the batch, and the stale records
       // of one call would be the next layout's counters.

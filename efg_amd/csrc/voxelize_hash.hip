@@ -295,7 +295,7 @@ int hash_hard_voxelize(const HardArgs& a) {
     hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)std::min<size_t>(ceil_div((int64_t)words, 1024), 1024)), blk, 0, stream,
                        reinterpret_cast<unsigned*>(table), words, 0xffffffffu);
   }
-  static const int precheck = getenv("EFG_VOX_PRECHECK") ? atoi(getenv("EFG_VOX_PRECHECK")) : 1;  // 0: every point of a voxel issues its atomicMin (A/B)
+  constexpr int precheck = 1;  // (0: every point of a voxel issues its atomicMin -- the losing A/B arm, profiles/r03_vox_precheck*.txt)
   if (n_total > 0) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(max_scene, 256), 1), 2048);
     hipLaunchKernelGGL(vox_insert_kernel, dim3(gx, batch), blk, 0, stream, a.points, so, f, g, (unsigned)vol, table,

@@ -21,8 +21,8 @@ from ..operators import box_attention_func as _baf
 from ..operators.linear import Linear, linear
 
 
-# EFG_BOX_SHARED_PROJ=0: logits and offsets from two projections, as the reference module computes them (A/B)
-_SHARED_PROJECTION = os.environ.get("EFG_BOX_SHARED_PROJ", "1") != "0"
+# (False: logits and offsets from two projections, as the reference module computes them -- the A/B of round 5)
+_SHARED_PROJECTION = True   # (module attribute: the A/B of round 5 and the tests flip it in-process)
 
 
 def _lattice(k):

@@ -278,33 +278,22 @@ class VoxelDETR(nn.Module):
         nq = self.num_queries
         outputs = {"pred_logits": outputs_class[-1][:, :nq], "pred_boxes": outputs_coord[-1][:, :nq],
                    "aux_outputs": self._set_aux_loss(outputs_class[:-1, :, :nq], outputs_coord[:-1, :, :nq])}
-        # the encoder-proposal and the decoder matchings in ONE assignment launch (losses.match_together); host tensors and
-        # EFG_MATCH_TOGETHER=0: every loss matches for itself, as the reference does
+        # the encoder-proposal and the decoder matchings in ONE assignment launch (losses.match_together); host tensors:
+        # every loss matches for itself, as the reference does
         phead = self.transformer.proposal_head
         prep_e = prep_d = q_e = q_d = sim = None
-        if outputs_class.is_cuda and os.environ.get("EFG_MATCH_TOGETHER", "1") != "0":
+        if outputs_class.is_cuda:
             prep_e, prep_d = phead.losses.prepare(enc_outputs, bin_targets), head.losses.prepare(outputs, targets)
-            # EFG_MATCH_STREAM=1: the assignment (one workgroup per problem, ~200 us with the device otherwise idle) on the side
-            # stream, the matching-independent half of the contrastive loss (its projections and the similarity product) on
-            # the main one meanwhile.  Off by default: measured neutral on the shared side stream (31.69 / 31.74 against
-            # 31.68 / 31.76) -- and 61-65 ms per step on a stream of its own (streams.py)
-            side = main = None
-            if os.environ.get("EFG_MATCH_STREAM", "0") == "1":
-                from ..streams import side_stream
-
-                side, main = side_stream(outputs_class.device, "matching"), torch.cuda.current_stream(outputs_class.device)
-            both = match_together([(phead.losses.matcher, prep_e), (head.losses.matcher, prep_d)], side=side)
+            # (on the main stream: the assignment on the shared side stream beside the matching-independent half of the
+            # contrastive loss measured neutral in round 4 -- 31.69 / 31.74 against 31.68 / 31.76 -- and 61-65 ms per step on a
+            # stream of its own, streams.py; the switch was retired in round 6)
+            both = match_together([(phead.losses.matcher, prep_e), (head.losses.matcher, prep_d)])
             if self.is_conquer and dn_meta is not None and sum(t["gt_boxes"].shape[0] for t in targets) > 0:
                 sim = self._contrastive_similarity(outputs_class, outputs_coord)
-            if side is not None:
-                main.wait_stream(side)
             if both is None:
                 prep_e = prep_d = None
             else:
                 q_e, q_d = both
-                if side is not None:
-                    q_e.record_stream(main)
-                    q_d.record_stream(main)
         enc_losses = phead.compute_losses(enc_outputs, bin_targets, prepared=prep_e, q_of_g=q_e)
         losses.merge(enc_losses, "_enc")
         with record_function("efg::losses.decoder"):

@@ -444,10 +444,6 @@ class Trainer:
             # instead of taking the immediate-mode pick: fwd 1.24 -> 0.66 ms, bwd-data 0.85 -> 0.66 ms per step
             if os.environ.get("EFG_MIOPEN_FIND", "1") == "1":
                 torch.backends.cudnn.benchmark = True
-            # EFG_MIOPEN_DETERMINISTIC=1: only MIOpen solvers without atomics (the weight gradient of the one dense 3 x 3
-            # BEV convolution is the last run-to-run difference of a training step, scripts/ubench/determinism_probe.py)
-            if os.environ.get("EFG_MIOPEN_DETERMINISTIC", "0") == "1":
-                torch.backends.cudnn.deterministic = True
         torch.manual_seed(seed)
         self.cfg = cfg
         from .streams import create_side_streams
@@ -507,8 +503,7 @@ class Trainer:
                 self.model.plain_loss_dict = True
                 self.wrapped = torch.nn.parallel.DistributedDataParallel(
                     self.model, device_ids=dev_ids, broadcast_buffers=False,
-                    bucket_cap_mb=int(os.environ.get("EFG_DDP_BUCKET_MB", "50")),
-                    gradient_as_bucket_view=os.environ.get("EFG_DDP_BUCKET_VIEW", "1") == "1", **kw)
+                    bucket_cap_mb=50, gradient_as_bucket_view=True, **kw)
                 _weights_written_behind_autograd()   # (its constructor broadcasts rank 0's parameters through .data)
 
     def _collect_garbage(self):

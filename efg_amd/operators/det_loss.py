@@ -118,7 +118,6 @@ def box_refine(delta, anchor, eps=1e-5):
     """(delta + inverse_sigmoid(anchor)).sigmoid() -- $CQ/heads.py:78.  GPU fp32 tensors of equal shape take the fused
     kernel; anything else the PyTorch formulation (same math)."""
     if (delta.is_cuda and delta.dtype == torch.float32 and anchor.dtype == torch.float32 and delta.shape == anchor.shape
-            and (not anchor.requires_grad or os.environ.get("EFG_SMALL_FUSED", "1") != "0")
             and os.environ.get("EFG_FUSED_LOSS", "1") != "0"):
         return BoxRefineFunction.apply(delta, anchor, eps)
     x = anchor.clamp(min=0, max=1)

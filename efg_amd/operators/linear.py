@@ -48,10 +48,11 @@ def relu_backward_column_sum(g2, y):
 
 
 _SPLIT_MIN_ROWS = 32768
-_FUSED_MIN_ROWS = int(os.environ.get("EFG_LINEAR_MIN_ROWS", "16384"))  # linear(): rows from which the custom backward is used
+_FUSED_MIN_ROWS = 16384  # linear(): rows from which the custom backward is used
 _SPLITS = 16
-# EFG_SMALL_FUSED=0: the decoder-sized Linear + ReLU layers and the self-attention in-projection as plain PyTorch ops (A/B)
-_SMALL_FUSED = os.environ.get("EFG_SMALL_FUSED", "1") != "0"
+# the decoder-sized Linear + ReLU layers and the self-attention in-projection as fused functions (module attribute: the A/B
+# of round 4, profiles/r04_small_fused_ab.txt, flipped it through EFG_SMALL_FUSED; retired as a switch in round 6)
+_SMALL_FUSED = True
 
 
 # The A/B arm of the bench (EFG_GEMM_ARM=bf16x3, never the default): forward and data-gradient products of the long

@@ -73,8 +73,10 @@ def _build_rnbr(nbr, m_out, kvol, m_in):
 
 
 def _tiled():
-    """Mask-sorted row tiles (csrc/spconv_tiles.hip) for forward / dgrad; EFG_CONV_TILED=0 = generation-one kernels."""
-    return os.environ.get("EFG_CONV_TILED", "1") != "0"
+    """Mask-sorted row tiles (csrc/spconv_tiles.hip) for forward / dgrad of every window of at most 31 offsets; the
+    generation-one kernels (csrc/spconv_conv.hip) remain for larger windows only (the EFG_CONV_TILED=0 switch of rounds 2-5 was
+    retired in round 6: profiles/r02_gen1_vs_tiled_per_layer.txt)."""
+    return True
 
 
 _SHAPE_CACHE = {}
@@ -139,15 +141,6 @@ def _wgrad_tiled(cin, cout, kvol, m_out, m_in=0):
     return ok
 
 
-def _natural_order(reduce_channels):
-    """2 when the tile kernel should take its 16-byte-gather path for this reduction width (weights packed in natural
-    channel order), else 0.  OFF by default: measured 3-13 % SLOWER than the 4-byte path on every res18 layer
-    (profiles/r02_v4_sweep.txt) -- 4x fewer gather / LDS instructions buy nothing (the vector L1 moves 64 B/clk either
-    way and the kernel is not issue-bound) while the 16 extra VGPRs cost a wave per SIMD.  EFG_TILE_V4=1 enables it
-    (a tested A/B arm, tests/test_spconv_dense_gpu.py)."""
-    return 2 if reduce_channels % 4 == 0 and os.environ.get("EFG_TILE_V4", "0") == "1" else 0
-
-
 _ARM_OK = {}
 
 
@@ -169,9 +162,9 @@ def _arm_bf16x3(cin, cout, kvol, m_in, m_out):
 # backward was ~40 launches per ConQueR step.  The packed copy lives on the PARAMETER object (so it dies with it) and is
 # valid while (parameter._version, weight epoch) is unchanged.  The epoch is bumped by a global post-step hook on every
 # torch optimizer (the fused AdamW updates parameters without moving `_version`) and by `weights_updated()`, which code
-# that writes weights behind autograd's back (`p.data.copy_(...)`) must call.  EFG_SPCONV_PACK_CACHE=0 packs per call.
+# that writes weights behind autograd's back (`p.data.copy_(...)`) must call..
 _WEIGHT_EPOCH = [0]
-_PACK_CACHE_ON = os.environ.get("EFG_SPCONV_PACK_CACHE", "1") != "0"
+_PACK_CACHE_ON = True
 
 
 def weights_updated(*_args, **_kwargs):
@@ -262,9 +255,7 @@ def _conv_forward(features, w, bias, rb, owner=None):
     lib = L.lib()
     cout, kvol, cin = w.shape
     tiled = _tiled() and kvol <= 31 and rb.m_out > 0
-    nat = _natural_order(cin) if tiled else 0
-    if tiled and not nat:
-        nat = _arm_bf16x3(cin, cout, kvol, rb.m_in, rb.m_out)   # (bit 2 of the same flag word)
+    nat = _arm_bf16x3(cin, cout, kvol, rb.m_in, rb.m_out) if tiled else 0   # (bit 2 of the flag word: the split-precision arm)
     packed = _packed_weight(w, 0 | nat, owner)
     out = torch.empty((rb.m_out, cout), dtype=torch.float32, device=features.device)
     if tiled:
@@ -283,9 +274,7 @@ def _conv_dgrad(grad_out, w, rb, owner=None):
     lib = L.lib()
     cout, kvol, cin = w.shape
     tiled = _tiled() and kvol <= 31 and rb.m_in > 0
-    nat = _natural_order(cout) if tiled else 0
-    if tiled and not nat:
-        nat = _arm_bf16x3(cout, cin, kvol, rb.m_out, rb.m_in)
+    nat = _arm_bf16x3(cout, cin, kvol, rb.m_out, rb.m_in) if tiled else 0
     packed = _packed_weight(w, 1 | nat, owner)
     grad_in = torch.empty((rb.m_in, cin), dtype=torch.float32, device=grad_out.device)
     if tiled:
@@ -327,7 +316,7 @@ def _pair_ok(rb, w_a, w_b, cin, cout):
     """Can the two convolutions (weights [cout, kvol, cin] each) over `rb` run as the pair launches of csrc/spconv_tiles.hip /
     spconv_wgt.hip?  (the tiled fp32 path with the default weight order; EFG_CONV_PAIR=0: two launches each, A/B)"""
     return (os.environ.get("EFG_CONV_PAIR", "1") != "0" and _tiled() and rb.kvol <= 31 and rb.m_out > 0 and rb.m_in > 0
-            and w_a.shape == w_b.shape and not _natural_order(cin) and not _natural_order(cout)
+            and w_a.shape == w_b.shape
             and not _arm_bf16x3(cin, cout, rb.kvol, rb.m_in, rb.m_out) and not _arm_bf16x3(cout, cin, rb.kvol, rb.m_out, rb.m_in))
 
 
@@ -376,7 +365,7 @@ def _fwd_kernel_name(n_out_channels, n_rows, kvol=27):
     """Symbol of the forward/dgrad instantiation csrc/spconv_conv.hip:run_conv picks (same rule)."""
     ntiles = (n_out_channels + 15) // 16
     row_waves = (n_rows + 15) // 16
-    fill = int(os.environ.get("EFG_CONV_FILL", "0")) or (1400 if kvol >= 8 and os.environ.get("EFG_CONV_KS", "4") != "1" else 2048)
+    fill = 1400 if kvol >= 8 else 2048
     nt = 16
     while nt > 1 and (nt // 2 >= ntiles or row_waves * ((ntiles + nt - 1) // nt) < fill):
         nt >>= 1
@@ -575,8 +564,8 @@ class Rulebook:
     def dgrad_order(self):
         """int32 [m_in] row order for the dgrad of a strided geometry: input rows grouped by coordinate parity, so the
         16 rows of a tile share their reachable offsets (csrc/spconv_conv.hip: efg_spconv_parity_order); None for
-        submanifold geometries (every row reaches every offset) or with EFG_DGRAD_ORDER=0."""
-        if self.subm or self.in_indices is None or self.m_in == 0 or os.environ.get("EFG_DGRAD_ORDER", "1") == "0":
+        submanifold geometries (every row reaches every offset)."""
+        if self.subm or self.in_indices is None or self.m_in == 0:
             return None
         if self._order is None:
             idx = self.in_indices
@@ -901,8 +890,8 @@ def prefetch_downsample_chain(x, chain, branches=()):
     previous level's neighbour tables, tile plans and weight-gradient schedules (~300 us of kernels): ~1.2 ms of a step's host
     time spent blocked, which IS step time on a loaded host (step = host issue time + ~2 ms there).  Asked for up front the
     read-backs wait for one marking kernel each, and the plans queue up behind them.  Same kernels, same results; only the
-    order of issue on the geometry stream changes.  EFG_GEOM_PREFETCH=0: off (A/B)."""
-    if _GEO is None or os.environ.get("EFG_GEOM_PREFETCH", "1") == "0" or x.indices.shape[0] == 0:
+    order of issue on the geometry stream changes (A/B of round 5: profiles/r05c_geom_prefetch.txt)."""
+    if _GEO is None or x.indices.shape[0] == 0:
         return
     with _on_geometry_stream(wait=False):
         levels = [_Sites(x.indices, x.spatial_shape, x.batch_size)]

@@ -1,6 +1,6 @@
 """How much does the DDP wrapper itself cost per step (1 rank, RCCL backend, so no wire time)?
 
-    python scripts/ubench/ddp_modes.py [mode ...]     modes: none flat find_unused static plain, options after a colon: noview, mb=<bucket MB>
+    python scripts/ubench/ddp_modes.py [mode ...]     modes: none flat bucket find_unused static plain; `:comm` creates the communicator without using it
 
 `find_unused` is the reference's setting (find_unused_parameters: True); DDP then all-reduces a "used" bitmap and,
 because the skipped FPN levels leave locally unused parameters, makes a BLOCKING D2H copy of it at the end of
@@ -21,9 +21,7 @@ from efg_amd.engine import Trainer, synthetic_batch  # noqa: E402
 
 
 def run(mode, steps=20, warmup=6):
-    mode, _, opts = mode.partition(":")  # e.g. static:noview,mb=100
-    os.environ["EFG_DDP_BUCKET_VIEW"] = "0" if "noview" in opts else "1"
-    os.environ["EFG_DDP_BUCKET_MB"] = opts.split("mb=")[1].split(",")[0] if "mb=" in opts else "50"
+    mode, _, opts = mode.partition(":")  # e.g. none:comm
     os.environ["EFG_DDP_MODE"] = mode
     if "comm" in opts:  # create the RCCL communicator without using it in the step
         dist.all_reduce(torch.zeros(4, device="cuda:0"))

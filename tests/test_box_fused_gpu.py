@@ -153,10 +153,8 @@ def test_fused_kernels_match_oracle(dev, oracle_mod, case):
     exp = _OracleSampling.apply(v_c, shapes, start, grid, attn)
     exp.backward(gout)
 
-    if case.startswith("encoder_mixed"):   # how many corners fall outside the window of their TQY x 8 query tile
-        import os
-
-        tqy = 8 if os.environ.get("EFG_BOX_TQY") == "8" else 4      # csrc/box_fused.hip: BT<TQY>, window = tile + 4 cells
+    if case.startswith("encoder_mixed"):   # how many corners fall outside the window of their 4 x 8 query tile
+        tqy = 4      # csrc/box_fused.hip: BT<4>, window = tile + 4 cells
         px = grid.detach()[..., 0] * W - 0.5
         py = grid.detach()[..., 1] * H - 0.5
         q = torch.arange(lq)
@@ -181,21 +179,6 @@ def test_fused_kernels_match_oracle(dev, oracle_mod, case):
     close(o_d.grad, o_c.grad, "grad_offsets", 1e-4)
     close(l_d.grad, l_c.grad, "grad_logits", 1e-4)
 
-
-def test_eight_by_eight_tile_variant_matches_oracle_too(dev):
-    """box_bwd_tile_kernel<8> (the 8 x 8-query tile of round 2, EFG_BOX_TQY=8; the library reads the switch once, hence the
-    child process): the same oracle comparison as above for the encoder cases."""
-    import os
-    import subprocess
-    import sys
-
-    from conftest import ROOT
-
-    env = dict(os.environ, EFG_BOX_TQY="8", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), EFG_TEST_LOG_TAG="_tqy8")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_box_fused_gpu.py"), "-q", "-x", "-m", "gpu",
-                        "-p", "no:cacheprovider", "-k", "test_fused_kernels_match_oracle and encoder"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("case", ["encoder_grid", "encoder_grid_big", "decoder_many"])

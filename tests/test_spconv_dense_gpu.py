@@ -157,15 +157,6 @@ def test_backbone_block_equals_dense(dev):
     _close("residual block", y.features.detach().cpu().numpy(), want, rel=1e-4)
 
 
-def test_16_byte_gather_variant_equals_dense(dev, monkeypatch):
-    """EFG_TILE_V4=1 (16-byte gathers, swizzled A tile, natural-order packed weights; an A/B arm, off by default:
-    profiles/r02_v4_sweep.txt) computes the same convolution, forward and both gradients."""
-    monkeypatch.setenv("EFG_TILE_V4", "1")
-    for geom in ("res18 subm k3", "res18 stem/stage conv k3 s2 p1", "centerpoint conv4 k3 s2 p(0,1,1)"):
-        for cin, cout in ((16, 32), (64, 64), (64, 128), (256, 256), (20, 36)):
-            test_sparse_conv_equals_fp64_dense_conv3d(dev, geom, cin, cout)
-
-
 @pytest.mark.parametrize("stride", [1, 2])
 def test_bottleneck_block_equals_dense(dev, stride):
     """The depth-50 block (1x1x1 SubM -> 3x3x3 -> 1x1x1 SubM + the basic block's shortcut; reference
