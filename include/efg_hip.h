@@ -84,7 +84,7 @@ size_t efg_hard_voxelize_workspace_bytes(int64_t n_total, int batch, int f, int 
  * hipMemset on first use, left ZERO by every call for the next one (so a call has no clear launch) and kept for the life
  * of the process.  Calls on ONE stream must be issued by one thread at a time.  A call issued while its stream is being
  * captured into a HIP graph takes those words from the workspace and clears them with a kernel instead (a replay must
- * not depend on what eager calls left behind); EFG_VOX_OWN_STATE=0 does so always.
+ * not depend on what eager calls left behind).
  */
 int efg_hard_voxelize_f32(const float* points, const int64_t* point_offsets_host, int batch, int f,
                           const float* voxel_size_host, const float* coors_range_host, int max_points,
@@ -167,7 +167,8 @@ int efg_spconv_build_rnbr(const int32_t* nbr, int64_t m_out, int kvol, int64_t m
  * v_mfma_f32_16x16x4_f32):  for_dgrad = 0: packed[k][cin/16][cout_pad][16]  (reduce over cin)
  *                           for_dgrad = 1: packed[k][cout/16][cin_pad][16]  (reduce over cout).
  * Within a 16-channel group the lane kk's fragment holds channels {kk, kk+4, kk+8, kk+12}; for_dgrad | 2 ("natural
- * order", what efg_spconv_forward_tiled_f32 takes with flip_offsets | 2) holds {4kk .. 4kk+3} instead.
+ * order": {4kk .. 4kk+3}) is the layout of the 16-byte-gather tile kernel that was retired in round 6 -- the packer still
+ * writes it, no convolution entry point takes it.
  * for_dgrad | 4: the split-precision (bf16 x 3) layout of the tile kernel's A/B arm (flip_offsets | 4 there; reduction
  * width a multiple of 32, output width a multiple of 64; same size): per (offset, 32-channel step, n-tile of 16) the 64
  * lanes' 8 bf16 of W_hi, then of W_lo.  efg_spconv_tile_bf16x3_ok says whether a layer is covered. */
@@ -201,8 +202,8 @@ int efg_spconv_tile_plan(const int32_t* nbr, int64_t m, int kvol, void* plan, si
  * with weight offset kvol-1-c: the dgrad of a submanifold conv on the FORWARD table's plan (packed: for_dgrad = 1,
  * in = grad_out, cin/cout swapped by the caller), since the transposed table of a symmetric window is the table
  * with its offsets reversed.  The dgrad of a strided conv passes the plan of its transposed table and flip 0.
- * flip_offsets | 2: `packed_weight` is in natural channel order (for_dgrad | 2) and cin % 4 == 0: the kernel gathers
- * 16 bytes per lane and reads its A fragments with one 16-byte LDS load per 16-channel step.
+ * flip_offsets | 2 (natural-order weights, the 16-byte-gather kernel variant: 3-13 % slower on every res18 layer) is refused
+ * since round 6.
  * Stream-K (default; EFG_TILE_STREAMK=0 turns it off): on the 64-output-channel split-K shapes of submanifold tables
  * (and of strided tables with >= 128 channels on both sides) the launch is as many workgroups as the device holds and
  * the (row tile, active offset) items of the plan -- its prefix sums are part of the plan buffer -- are cut into equal
