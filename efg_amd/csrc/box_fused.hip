@@ -19,6 +19,7 @@ namespace efg {
 namespace {
 
 constexpr int kMaxLevels = 8;
+constexpr int kAbsmaxSlots = 63;   // words 1..63 of the bin workspace's flag block: partial maxima of |grad_out| (absmax_bits_kernel)
 constexpr int kMaxPts = 128;  // L * P upper bound for the fused path (LDS scratch)
 constexpr int kSoftmaxLds = 4096;  // floats: (pairs per workgroup) x (L*P) must fit
 
@@ -873,10 +874,13 @@ __global__ void __launch_bounds__(BT<TQY>::kThreads) __attribute__((amdgpu_waves
 box_bwd_tile_a_kernel(const float* __restrict__ value, const long long* __restrict__ shapes, const float* __restrict__ ref,
                       const float* __restrict__ off, const float* __restrict__ logits, const float* __restrict__ kidx,
                       const float* __restrict__ grad_out, BoxDims dm, float* __restrict__ grad_off,
-                      float* __restrict__ grad_logits) {
+                      float* __restrict__ grad_logits, int* __restrict__ counts, unsigned* __restrict__ absmax) {
+  // counts / absmax (both or neither): what box_bin_count_kernel and absmax_bits_kernel compute for the binned far corners,
+  // taken along -- this pass classifies every corner with the test pass B pushes with and reads every grad_out row once
   using B = BT<TQY>;
   constexpr int TQX = B::TQX, R = B::R, WINY = B::WINY, WINX = B::WINX, NQ = B::NQ, NC = B::NC, D = B::D, VS = B::VS, GS = B::GS,
                 kThreads = B::kThreads, PMAX = bt::PMAX;
+  unsigned go_max = 0u;
   constexpr int kVG = (NC * VS > NQ * GS) ? NC * VS : NQ * GS;
   extern __shared__ float lds[];
   float* VG = lds;                     // V [NC][VS] in S0 / S1, then G [NQ][GS]
@@ -928,6 +932,10 @@ box_bwd_tile_a_kernel(const float* __restrict__ value, const long long* __restri
       const long long bqc = (long long)bi * dm.lq + (long long)qyc * Wm + qxc;
       const float4 go = ld4(grad_out + (bqc * dm.h + m) * D + sub * 4);
       *reinterpret_cast<float4*>(GOs + slot * VS + sub * 4) = qok ? go : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qok) {
+        go_max = max(max(go_max, __float_as_uint(go.x) & 0x7fffffffu), __float_as_uint(go.y) & 0x7fffffffu);
+        go_max = max(max(go_max, __float_as_uint(go.z) & 0x7fffffffu), __float_as_uint(go.w) & 0x7fffffffu);
+      }
     }
     float lgv[4], rf[5], of[5];
     {
@@ -1018,7 +1026,9 @@ box_bwd_tile_a_kernel(const float* __restrict__ value, const long long* __restri
           if (in_win) {
             gval = VG[slot * GS + ly * WINX + lx];
           } else {  // the box has grown out of the window: dot product against the global value row
-            const float4* vr = reinterpret_cast<const float4*>(value + (((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m) * D);
+            const long long cellrow = ((long long)bi * S + (long long)cy * Wm + cx) * dm.h + m;
+            if (counts) atomicAdd(counts + cellrow, 1);   // one entry of pass B in the bin of this (cell, head) row
+            const float4* vr = reinterpret_cast<const float4*>(value + cellrow * D);
             const float4* gr = reinterpret_cast<const float4*>(GOs + slot * VS);
 #pragma unroll 1
             for (int cc = 0; cc < D / 4; ++cc) {
@@ -1071,6 +1081,12 @@ box_bwd_tile_a_kernel(const float* __restrict__ value, const long long* __restri
     if (qok)
       for (int e = sub; e < np; e += 8) grad_logits[bqs * dm.lg_rs + m * np + e] = as[e] * inv * (ga_s[slot * PMAX + e] - dot);
     (void)t;
+  }
+  if (absmax) {   // the largest |grad_out| this workgroup has seen: one atomic per wave (box_bin_reduce_kernel takes the max of the slots)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) go_max = max(go_max, (unsigned)__shfl_xor((int)go_max, d, 64));
+    if (lane == 0 && go_max)
+      atomicMax(absmax + 1 + (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) + wave) % kAbsmaxSlots, go_max);
   }
 }
 
@@ -1377,7 +1393,7 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(int* __restrict__ offse
 // max |x| of a tensor as float bits (0x7f800000 and above: an Inf / NaN is present) into 63 slots (out[1 + block % 63]: one
 // address is one serial atomic unit, ~15 ns per atomic); eight 16-byte loads in flight per thread, one atomic per block.
 // (First version: one load per trip and an atomic per wave on ONE word -- 66 us for 72 MB.)
-constexpr int kAbsmaxSlots = 63;
+// (kAbsmaxSlots: defined with the tile kernels above)
 __global__ void __launch_bounds__(256) absmax_bits_kernel(const float* __restrict__ x, long long n4, unsigned* __restrict__ out) {
   __shared__ unsigned sm[4];
   unsigned m = 0u;
@@ -1505,28 +1521,40 @@ BinPlan bin_plan(int b, int s, int h, int l, int lq, int p) {
 
 // count -> exclusive scan over nbins + 1 counters (the last one stays 0, so offsets[nbins] = number of entries and
 // offsets[bin + 1] ends every bin); cursor = copy of offsets
+int bin_scan(const BinPlan& pl, void* ws, hipStream_t st) {
+  char* base = static_cast<char*>(ws);
+  int* offs = reinterpret_cast<int*>(base + pl.off_offsets);
+  int* cursor = reinterpret_cast<int*>(base + pl.off_cursor);
+  int* totals = reinterpret_cast<int*>(base + pl.off_totals);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins + 1, totals);
+  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, offs, pl.nbins + 1, totals, cursor);
+  EFG_LAUNCH_CHECK();
+  return EFG_OK;
+}
+
+// count_here = false: only the pointers and the memset -- the caller's pass A counts the corners and takes the largest
+// |grad_out| along (box_bwd_tile_a_kernel), then calls bin_scan
 int bin_prepare(const BinPlan& pl, void* ws, const long long* shapes, const long long* starts, const float* ref,
                 const float* off, const float* kidx, const BoxDims& dm, int outside_tile_window, int tqy, hipStream_t st,
-                int** offs, int** cursor, int2** entries, int** overflow, const float* grad_out, long long grad_out_floats) {
+                int** offs, int** cursor, int2** entries, int** overflow, const float* grad_out, long long grad_out_floats,
+                bool count_here = true) {
   char* base = static_cast<char*>(ws);
   *overflow = reinterpret_cast<int*>(base + pl.off_flag);
   *offs = reinterpret_cast<int*>(base + pl.off_offsets);
   *cursor = reinterpret_cast<int*>(base + pl.off_cursor);
-  int* totals = reinterpret_cast<int*>(base + pl.off_totals);
   *entries = reinterpret_cast<int2*>(base + pl.off_entries);
   // flag + offsets are adjacent: one memset
   EFG_HIP_TRY(hipMemsetAsync(base + pl.off_flag, 0, 256 + sizeof(int) * (size_t)(pl.nbins + 1), st));
+  if (!count_here) return EFG_OK;
   // words 1..63 of the (zeroed) flag block: largest |grad_out| of the call as float bits (the scale of box_bin_reduce_kernel)
   hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(ceil_div(grad_out_floats / 4, 2048), 1), 1024)),
                      dim3(256), 0, st, grad_out, grad_out_floats / 4, reinterpret_cast<unsigned*>(*overflow));
   const long long nboxes = (long long)dm.b * dm.lq * dm.h * dm.l;
   hipLaunchKernelGGL(box_bin_count_kernel, dim3((unsigned)ceil_div(nboxes, 256)), dim3(256), 0, st, shapes, starts, ref,
                      off, kidx, dm, *offs, outside_tile_window, tqy);
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals);
-  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, totals, pl.ntiles);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(pl.ntiles), dim3(256), 0, st, *offs, pl.nbins + 1, totals, *cursor);
   EFG_LAUNCH_CHECK();
-  return EFG_OK;
+  return bin_scan(pl, ws, st);
 }
 
 constexpr long long kBinMinEntries = 200000;  // below this the extra launches cost more than the atomics
@@ -1628,11 +1656,16 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
       const bool binned = ws != nullptr && pl.nentries < (1ll << 31) && pl.nbins + 1 < (1ll << 31);
       int *cursor = nullptr, *offs = nullptr, *overflow = nullptr;
       int2* entries = nullptr;
+      // EFG_BOX_SPLIT (default 1): pass A and pass B as two kernels at four waves per SIMD (see box_bwd_tile_a_kernel);
+      // 0 = the one-kernel form.
+      const int split_env = getenv("EFG_BOX_SPLIT") ? atoi(getenv("EFG_BOX_SPLIT")) : 1;   // (read per call: tests flip it in-process)
+      const bool split = split_env != 0;
       if (binned) {
         EFG_CHECK_ARG(ws_bytes >= pl.bytes, "box_attn_fused backward: workspace too small (%zu < %zu)", ws_bytes, pl.bytes);
+        // split: pass A counts the out-of-window corners and takes the largest |grad_out| along (two launches less per call)
         if (int rc = bin_prepare(pl, ws, (const long long*)shapes, (const long long*)level_start, ref_windows, offsets,
                                  kernel_indices, dm, 1, tqy, st, &offs, &cursor, &entries, &overflow, grad_out,
-                                 (long long)dm.b * dm.lq * dm.h * dm.d))
+                                 (long long)dm.b * dm.lq * dm.h * dm.d, /*count_here=*/!split))
           return rc;
       }
       // EFG_BOX_DETERMINISTIC (default 1): the tiles in NCY x NCX colour classes whose windows never overlap, one launch
@@ -1644,15 +1677,14 @@ extern "C" int efg_box_attn_fused_backward_strided_f32(const float* value, const
       // (workgroups along x of a colour launch; measured 16: +1.1 ms, 32: +0.35 ms, 64: +0.1 ms per step against the atomic launch)
       constexpr int cgx_env = 64;
       const unsigned gx_launch = colored ? std::min<unsigned>(tile_gx, (unsigned)std::max(cgx_env, 1)) : tile_gx;
-      // EFG_BOX_SPLIT (default 1): pass A and pass B as two kernels at four waves per SIMD (see box_bwd_tile_a_kernel);
-      // 0 = the one-kernel form.  The 4 x 8 tile only.
-      const int split_env = getenv("EFG_BOX_SPLIT") ? atoi(getenv("EFG_BOX_SPLIT")) : 1;   // (read per call: tests flip it in-process)
-      const bool split = split_env != 0;
       if (split) {
         EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_a_kernel<4>, bt::lds_bytes_a<4>());
         hipLaunchKernelGGL(box_bwd_tile_a_kernel<4>, dim3(tile_gx, h, b), dim3(BT<4>::kThreads), bt::lds_bytes_a<4>(), st, value,
                            (const long long*)shapes, ref_windows, offsets, logits, kernel_indices, grad_out, dm, grad_offsets,
-                           grad_logits);
+                           grad_logits, binned ? offs : nullptr, binned ? reinterpret_cast<unsigned*>(overflow) : nullptr);
+        EFG_LAUNCH_CHECK();
+        if (binned)
+          if (int rc = bin_scan(pl, ws, st)) return rc;
         EFG_ALLOW_DYNAMIC_LDS(box_bwd_tile_b_kernel<4>, bt::lds_bytes_b<4>());
       }
       for (int col = 0; col < ncolors; ++col) {
