@@ -5,12 +5,16 @@ losses are restated without host round trips: the reference tests `num_pos == 0`
 (centernet_loss.py:54); here that is a `torch.where` on the device."""
 import copy
 import math
+import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from ..modeling.common import get_norm
-from ..operators.batchnorm import run_sequential
+from ..operators.batchnorm import BatchNormActFunction, run_sequential
 from ..operators.iou3d_nms import nms_gpu
 
 
@@ -47,6 +51,45 @@ class FastFocalLoss(nn.Module):
         return torch.where(num_pos > 0, -(pos + neg) / num_pos.clamp(min=1), -neg)
 
 
+# The task stacks of a SepHead as one 320-wide stack (SepHead._forward_fused): A/B switch of the head, default on.
+_HEAD_FUSE = os.environ.get("EFG_HEAD_FUSE", "1") != "0"
+
+
+class _BlockDiagonalWeight(Function):
+    """[k_i, C, kh, kw] x n  ->  [sum k_i, n * C, kh, kw] with weight i in rows (sum k_<i ..) and input channels
+    (i * C ..), zeros elsewhere; backward hands every weight its block of the joint gradient (one multi-tensor copy
+    each way)."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        c = ws[0].shape[1]
+        ks = [w.shape[0] for w in ws]
+        joint = ws[0].new_zeros((sum(ks), c * len(ws)) + tuple(ws[0].shape[2:]))
+        if ws[0].dim() == 4 and ws[0].is_contiguous(memory_format=torch.channels_last) and not ws[0].is_contiguous():
+            joint = joint.contiguous(memory_format=torch.channels_last)
+        torch._foreach_copy_(_BlockDiagonalWeight._blocks(joint, ks, c), [w.detach() for w in ws])
+        ctx.ks, ctx.c = ks, c
+        return joint
+
+    @staticmethod
+    def _blocks(joint, ks, c):
+        out, o = [], 0
+        for i, k in enumerate(ks):
+            out.append(joint[o:o + k, i * c:(i + 1) * c])
+            o += k
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        blocks = _BlockDiagonalWeight._blocks(g, ctx.ks, ctx.c)
+        outs = [torch.empty_like(b, memory_format=torch.preserve_format).contiguous(
+            memory_format=torch.channels_last if g.is_contiguous(memory_format=torch.channels_last) and not g.is_contiguous()
+            else torch.contiguous_format) for b in blocks]
+        torch._foreach_copy_(outs, blocks)
+        return tuple(outs)
+
+
 class SepHead(nn.Module):
     """One small conv stack per regression target + the heat map ($CP1/center_head.py:18-52)."""
 
@@ -73,7 +116,71 @@ class SepHead(nn.Module):
             setattr(self, name, stack)
 
     def forward(self, x):
+        if _HEAD_FUSE and self._fusable(x):
+            return self._forward_fused(x)
         return {name: run_sequential(getattr(self, name), x) for name in self.heads}
+
+    # ---- the stacks as ONE stack ----------------------------------------------------------------------------------
+    # Every stack reads the same map: conv3x3(C -> 64) + BN + ReLU + conv3x3(64 -> k), k = 2 / 1 / 3 / 2 / 3 on Waymo.  Ten
+    # convolutions of 64 output channels or fewer, each with its own BatchNorm launches forward and backward, fill a
+    # fraction of the chip.  Here: the first convolutions as one of 5 x 64 output channels (weights concatenated along
+    # Cout), ONE BatchNorm + ReLU over the 320 channels (batch statistics are per channel: the same numbers), the
+    # second ones as one convolution with a block-diagonal weight [sum k, 320, 3, 3] (the products with the zero blocks
+    # are exact zeros).  The modules, their parameters, buffers and state-dict names stay the reference's; the
+    # concatenations are differentiable, so every parameter receives its own gradient (a slice of the joint one).
+    # 2.17 -> 1.77 ms forward + backward on [2, 64, 188, 188] (scripts/ubench/head_fuse.py).
+    def _fusable(self, x):
+        stacks = [getattr(self, name) for name in self.heads]
+        first = stacks[0]
+        if len(stacks) < 2 or x.dim() != 4:
+            return False
+        for s in stacks:
+            if len(s) != 4 or type(s[0]) is not nn.Conv2d or type(s[1]) is not nn.BatchNorm2d or type(s[2]) is not nn.ReLU \
+                    or type(s[3]) is not nn.Conv2d:
+                return False
+            c1, bn, c2 = s[0], s[1], s[3]
+            if (c1.kernel_size, c1.padding, c1.stride, c1.dilation, c1.groups) != \
+                    (first[0].kernel_size, first[0].padding, (1, 1), (1, 1), 1) or c1.bias is None or c2.bias is None:
+                return False
+            if (c2.kernel_size, c2.padding, c2.stride, c2.dilation, c2.groups) != \
+                    (first[3].kernel_size, first[3].padding, (1, 1), (1, 1), 1) or c1.padding_mode != "zeros" \
+                    or c2.padding_mode != "zeros":
+                return False
+            if c1.out_channels != first[0].out_channels or not bn.affine or not bn.track_running_stats \
+                    or bn.momentum is None or (bn.eps, bn.momentum, bn.training) != (first[1].eps, first[1].momentum,
+                                                                                     first[1].training):
+                return False
+        return True
+
+    def _forward_fused(self, x):
+        names = list(self.heads)
+        stacks = [getattr(self, name) for name in names]
+        conv1, bns, conv2 = [s[0] for s in stacks], [s[1] for s in stacks], [s[3] for s in stacks]
+        mid = conv1[0].out_channels
+        y = F.conv2d(x, torch.cat([c.weight for c in conv1]), torch.cat([c.bias for c in conv1]), padding=conv1[0].padding)
+        gamma, beta = torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns])
+        mean, var = torch.cat([bn.running_mean for bn in bns]), torch.cat([bn.running_var for bn in bns])
+        training = bns[0].training
+        if (training and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last)
+                and y.shape[1] <= 1024 and os.environ.get("EFG_FUSED_BN", "1") != "0"):
+            b, c, h, w = y.shape
+            rows = BatchNormActFunction.apply(y.permute(0, 2, 3, 1).reshape(b * h * w, c), None, gamma, beta, mean, var, None,
+                                              bns[0].momentum, bns[0].eps, True)
+            y = rows.view(b, h, w, c).permute(0, 3, 1, 2)
+        else:
+            y = F.relu(F.batch_norm(y, mean, var, gamma, beta, training, bns[0].momentum, bns[0].eps))
+        if training:
+            with torch.no_grad():   # the joint running statistics back into the modules' own buffers: one multi-tensor copy
+                torch._foreach_copy_([bn.running_mean for bn in bns] + [bn.running_var for bn in bns],
+                                     list(mean.split(mid)) + list(var.split(mid)))
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        out = F.conv2d(y, _BlockDiagonalWeight.apply(*[c.weight for c in conv2]), torch.cat([c.bias for c in conv2]),
+                       padding=conv2[0].padding)
+        res, o = {}, 0
+        for name, c in zip(names, conv2):
+            res[name] = out[:, o:o + c.out_channels]
+            o += c.out_channels
+        return res
 
 
 class CenterHead(nn.Module):

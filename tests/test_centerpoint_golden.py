@@ -161,3 +161,87 @@ def test_reference_centerpoint_inference_cpu(oracle_mod):
 def test_reference_centerpoint_inference_gpu(dev):
     model, cfg, g = _build(dev)
     _check_inference(model, g, cfg, dev, contextlib.nullcontext)
+
+
+def _head_pair(device, dtype):
+    """Two copies of one SepHead ($CP1/center_head.py:18-52) with non-trivial BatchNorm parameters, an input map and
+    output gradients."""
+    from efg_amd.centerpoint import center_head as ch
+
+    torch.manual_seed(0)
+    heads = {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "hm": (3, 2)}
+    a = ch.SepHead(64, heads, bn="BN", final_kernel=3).to(device=device, dtype=dtype)
+    for m in a.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_()
+    b = copy.deepcopy(a)
+    x = torch.randn(2, 64, 24, 20, device=device, dtype=dtype)
+    if device.type == "cuda":
+        a, b = a.to(memory_format=torch.channels_last), b.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    gos = {k: torch.randn(2, v[0], 24, 20, device=device, dtype=dtype) for k, v in heads.items()}
+    return ch, a, b, x, gos
+
+
+def _head_fused_against_stacks(device, dtype, tol):
+    ch, fused, plain, x, gos = _head_pair(device, dtype)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    assert fused._fusable(xa)
+    saved = ch._HEAD_FUSE
+    try:
+        ch._HEAD_FUSE = True
+        ya = fused(xa)
+        ch._HEAD_FUSE = False
+        yb = plain(xb)
+    finally:
+        ch._HEAD_FUSE = saved
+    assert list(ya) == list(yb)
+    torch.autograd.backward([ya[k] for k in ya], [gos[k] for k in ya])
+    torch.autograd.backward([yb[k] for k in yb], [gos[k] for k in yb])
+
+    def close(u, v, what):
+        err = float((u.double() - v.double()).abs().max()) / max(float(v.double().abs().max()), 1e-30)
+        assert err <= tol, "%s: %.2e" % (what, err)
+
+    for k in ya:
+        assert ya[k].shape == yb[k].shape
+        close(ya[k], yb[k], k)
+    close(xa.grad, xb.grad, "input gradient")
+    pa, pb = dict(fused.named_parameters()), dict(plain.named_parameters())
+    for k in pa:   # every parameter of every stack gets ITS block of the joint gradient
+        assert pa[k].grad is not None and pa[k].grad.shape == pa[k].shape, k
+        if k.endswith(".0.bias"):   # a bias in front of a BatchNorm: its gradient is exactly zero, both forms carry rounding noise
+            scale = float(pb[k[:-4] + "weight"].grad.abs().max())
+            assert float(pa[k].grad.abs().max()) <= 1e-4 * scale and float(pb[k].grad.abs().max()) <= 1e-4 * scale, k
+            continue
+        close(pa[k].grad, pb[k].grad, k)
+    ba, bb = dict(fused.named_buffers()), dict(plain.named_buffers())
+    for k in ba:   # running statistics and num_batches_tracked land in the modules' own buffers
+        close(ba[k], bb[k], k)
+    assert int(ba["hm.1.num_batches_tracked"]) == 1
+    # eval mode: running statistics, same maps
+    fused.eval(), plain.eval()
+    with torch.no_grad():
+        try:
+            ch._HEAD_FUSE = True
+            ea = fused(x)
+            ch._HEAD_FUSE = False
+            eb = plain(x)
+        finally:
+            ch._HEAD_FUSE = saved
+    for k in ea:
+        close(ea[k], eb[k], "eval " + k)
+
+
+def test_task_stacks_as_one_stack_cpu():
+    """SepHead's five conv + BN + ReLU + conv stacks evaluated as ONE 320-wide stack (block-diagonal second weight) are the
+    five stacks: outputs, input gradient, every parameter's gradient, the BatchNorm buffers; float64 so that only the
+    summation order differs."""
+    _head_fused_against_stacks(torch.device("cpu"), torch.float64, 1e-11)
+
+
+@pytest.mark.gpu
+def test_task_stacks_as_one_stack_gpu(dev):
+    """The same on the GPU path (MIOpen convolutions on channels-last maps, the HIP BatchNorm over 320 channels)."""
+    _head_fused_against_stacks(dev, torch.float32, 2e-5)
