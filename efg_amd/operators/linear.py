@@ -50,6 +50,7 @@ def relu_backward_column_sum(g2, y):
 _SPLIT_MIN_ROWS = 32768
 _FUSED_MIN_ROWS = 16384  # linear(): rows from which the custom backward is used
 _SPLITS = 16
+_WGRAD_ROWMAJOR = os.environ.get("EFG_WGRAD_ROWMAJOR", "1") != "0"   # A/B of round 6 (profiles/r06o_wgrad_rowmajor.txt)
 # the decoder-sized Linear + ReLU layers and the self-attention in-projection as fused functions (module attribute: the A/B
 # of round 4, profiles/r04_small_fused_ab.txt, flipped it through EFG_SMALL_FUSED; retired as a switch in round 6)
 _SMALL_FUSED = True
@@ -87,7 +88,12 @@ def weight_grad(x2, g2):
         gs = g2.view(_SPLITS, k // _SPLITS, g2.shape[1])
         xs = x2.view(_SPLITS, k // _SPLITS, x2.shape[1])
         return torch.bmm(gs.transpose(1, 2), xs).sum(0)
-    return x2.t().mm(g2).t()  # the call autograd makes for F.linear (tuned solutions apply)
+    if _WGRAD_ROWMAJOR:
+        # [out, in] row-major, the parameter's own layout: AccumulateGrad takes the tensor as it is (the transposed view of
+        # x2^T . g2 costs a copy launch per parameter and step), and it is the product autograd issues for F.linear on a
+        # transposed-view weight (mm_mat2_backward: grad^T . mat1), so the tuned solutions of the plain Linear layers apply
+        return g2.t().mm(x2)
+    return x2.t().mm(g2).t()
 
 
 class LinearFunction(Function):

@@ -122,9 +122,11 @@ def test_weight_grad_split_matches_single_product():
         e_split, e_one = float((got.double() - ref).abs().max()) / scale, float((one.double() - ref).abs().max()) / scale
         assert e_split < 2e-5 and e_split <= 4 * e_one + 1e-7, (k, cin, cout, e_split, e_one)
         assert torch.equal(got, weight_grad(x, go))  # deterministic
-    # short matrices keep the single product
-    x, go = torch.randn(2480, 256, device="cuda"), torch.randn(2480, 256, device="cuda")
-    assert torch.equal(weight_grad(x, go), x.t().mm(go).t())
+    # short matrices keep the single product, in the parameter's own [out, in] row-major layout (AccumulateGrad then takes the
+    # tensor as it is: no copy launch per parameter) -- the product autograd issues for F.linear
+    x, go = torch.randn(2480, 256, device="cuda"), torch.randn(2480, 1024, device="cuda")
+    got = weight_grad(x, go)
+    assert got.shape == (1024, 256) and got.is_contiguous() and torch.equal(got, go.t().mm(x))
 
 
 def test_linear_without_bias_and_pointwise_conv():
