@@ -50,7 +50,7 @@ def relu_backward_column_sum(g2, y):
 _SPLIT_MIN_ROWS = 32768
 _FUSED_MIN_ROWS = 16384  # linear(): rows from which the custom backward is used
 _SPLITS = 16
-_WGRAD_ROWMAJOR = os.environ.get("EFG_WGRAD_ROWMAJOR", "1") != "0"   # A/B of round 6 (profiles/r06o_wgrad_rowmajor.txt)
+_WGRAD_ROWMAJOR = True   # (module attribute: the A/B of round 6, profiles/r06o_wgrad_rowmajor.txt, flipped it through an environment switch)
 # the decoder-sized Linear + ReLU layers and the self-attention in-projection as fused functions (module attribute: the A/B
 # of round 4, profiles/r04_small_fused_ab.txt, flipped it through EFG_SMALL_FUSED; retired as a switch in round 6)
 _SMALL_FUSED = True
