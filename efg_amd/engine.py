@@ -195,7 +195,7 @@ class FlatGradientAllReduce:
             self.flat = torch.zeros(total + 1, dtype=self.params[0].dtype, device=self.params[0].device)
             self.views, off = [], 0
             for p in self.params:
-                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                self.views.append(_flat_view(self.flat, off, p))
                 off += p.numel()
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):  # a data-dependent branch skipped a parameter this step: it sends zeros
@@ -210,6 +210,22 @@ class FlatGradientAllReduce:
         for p, v in zip(self.params, self.views):
             p.grad = v
         self.found_inf = _unpack_found_inf(self.flat, self.found_inf)
+
+
+def _flat_view(buf, off, p):
+    """The slice of an exchange buffer that stands for `p`'s gradient, in `p`'s OWN memory layout: the view becomes `p.grad`,
+    and the fused optimizer kernel walks parameter, gradient and moments as flat memory (it refuses lists whose strides
+    differ) -- a channels-last convolution weight (CenterPoint's neck and head on the GPU) needs a channels-last view."""
+    n = p.numel()
+    if p.dim() > 1:
+        expect = 1     # dense and non-overlapping <=> the strides are a permutation of a contiguous tensor's
+        for size, stride in sorted(zip(p.shape, p.stride()), key=lambda t: (t[1], t[0])):
+            if size != 1 and stride != expect:
+                break
+            expect *= size
+        else:
+            return buf[off:off + n].as_strided(p.shape, p.stride())
+    return buf[off:off + n].view_as(p)
 
 
 def _pack_found_inf(buf, flag):
@@ -385,7 +401,7 @@ class BucketedGradientAllReduce:
             buf = torch.zeros(total, dtype=params[0].dtype if params else torch.float32, device=dev)
             views, off = [], 0
             for p in params:
-                views.append(buf[off:off + p.numel()].view_as(p))
+                views.append(_flat_view(buf, off, p))
                 off += p.numel()
             self.layout[key] = (params, buf, views)
 

@@ -107,3 +107,29 @@ def test_exchange_defaults_follow_the_launch_environment(monkeypatch):
         assert os.environ["GPU_MAX_HW_QUEUES"] == want, (env, os.environ["GPU_MAX_HW_QUEUES"])
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
     assert engine.default_ddp_mode() == "flat"      # no process group (and gloo would say the same): never the RCCL default
+
+
+def test_exchange_views_keep_the_parameters_layout():
+    """The flat / bucket buffers hand every parameter its reduced gradient as a view in the parameter's OWN strides (the fused
+    optimizer refuses a gradient whose layout differs from its parameter's: CenterPoint's channels-last neck / head)."""
+    from efg_amd.engine import FlatGradientAllReduce
+
+    port = _free_port()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 4, 1))
+        model = model.to(memory_format=torch.channels_last)
+        x = torch.randn(2, 8, 12, 12).contiguous(memory_format=torch.channels_last)
+        model(x).square().sum().backward()
+        want = {n: p.grad.clone() for n, p in model.named_parameters()}
+        sync = FlatGradientAllReduce(model, 1)
+        sync.reduce()
+        for n, p in model.named_parameters():
+            assert p.grad.stride() == p.stride(), n
+            assert p.grad.data_ptr() >= sync.flat.data_ptr() and torch.equal(p.grad, want[n]), n
+        w = model[0].weight
+        assert not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last)
+        torch.optim.AdamW(model.parameters(), lr=1e-3, foreach=True).step()
+    finally:
+        dist.destroy_process_group()

@@ -110,3 +110,17 @@ def test_two_rank_gradients_and_parameters_agree(dev):
     # DESIGN.md §10); two runs of the SAME exchange differ by a few 1e-4 of the norm after 3 steps (measured 3.1e-4)
     assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=1e-3)
     assert res["bucket"][2] == pytest.approx(res["flat"][2], rel=1e-4)
+
+
+@pytest.mark.parametrize("model", ["centerpoint", "voxeldetr", "trajectoryformer"])
+def test_bench_two_ranks_other_models(dev, model):
+    """The other configurations through the same N > 1 launch (two ranks on one device over gloo).  CenterPoint's neck and
+    head are channels-last on the GPU: the exchange has to hand every parameter its gradient in the parameter's own layout
+    (engine._flat_view), or the fused optimizer refuses the step."""
+    r = _torchrun(["bench.py", "--model", model, "--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "30000",
+                   "--scenes", "1", "--objects", "20", "--no-cpu-baseline", "--profile-steps", "1", "--soak-steps", "0"], None)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 2
