@@ -107,8 +107,9 @@ def test_two_rank_gradients_and_parameters_agree(dev):
     # which add the same two addends per element -- would agree to the last digit if the two runs' gradients did.  They do
     # not at the worker's reduced shapes (60 queries): the GEMM library picks atomic split-K solutions for the skinny
     # class-head weight gradients there, whose sums depend on arrival order (scripts/ubench/determinism_probe.py --small;
-    # DESIGN.md §10); two runs of the SAME exchange differ by a few 1e-4 of the norm after 3 steps (measured 3.1e-4)
-    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=1e-3)
+    # DESIGN.md §10); two runs of the SAME exchange differ by up to 2.2e-3 of the norm after 3 steps (ten runs of the flat
+    # exchange on the round-6 tree: 2.6623e-1 .. 2.6695e-1; the losses agree to 1e-6) -- 1e-3 here failed one run in ~ten
+    assert res["bucket"][1] == pytest.approx(res["flat"][1], rel=6e-3)
     assert res["bucket"][2] == pytest.approx(res["flat"][2], rel=1e-4)
 
 
